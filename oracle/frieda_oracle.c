@@ -1,0 +1,1272 @@
+/*
+ * frieda_oracle.c — CPU restatement of frieda's commit / generate_proof / verify path.
+ *
+ * TEST INFRASTRUCTURE ONLY (see frieda_oracle.h).  Single-threaded scalar C that mirrors, step for
+ * step, what the reference executes: frieda's glue (/root/reference/src/{utils,commit,proof}.rs) on top
+ * of stwo-prover@19d12d7's CpuBackend (un-vendored; restated from its published algorithm, SURVEY.md
+ * Appendix A).  It deliberately keeps the reference's cost profile (twiddles recomputed per call, a
+ * domain-point scalar multiplication and a field inversion per fold pair) so that it can double as the
+ * "port" CPU baseline in bench.py.
+ *
+ * Parity: codec + domain + twiddles + FFT + Merkle are PINNED by the golden root of
+ * src/commit.rs:31-37.  Channel / folds / grind / queries / decommit / verify: parity unpinned.
+ */
+#include "frieda_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define P FO_P
+
+/* ------------------------------------------------------------------------------------------------
+ * M31 / CM31 / QM31 (stwo core/fields/m31.rs, cm31.rs, qm31.rs)
+ * ---------------------------------------------------------------------------------------------- */
+static inline uint32_t m31_reduce(uint64_t v) {
+    /* M31::reduce: ((((v >> 31) + v + 1) >> 31) + v) & P, valid for v < P^2 */
+    return (uint32_t)((((v >> 31) + v + 1) >> 31) + v) & P;
+}
+static inline uint32_t m31_add(uint32_t a, uint32_t b) {
+    uint32_t s = a + b;
+    return s >= P ? s - P : s;
+}
+static inline uint32_t m31_sub(uint32_t a, uint32_t b) { return a >= b ? a - b : a + P - b; }
+static inline uint32_t m31_neg(uint32_t a) { return a ? P - a : 0; }
+static inline uint32_t m31_mul(uint32_t a, uint32_t b) { return m31_reduce((uint64_t)a * b); }
+static uint32_t m31_pow(uint32_t a, uint32_t e) {
+    uint32_t r = 1;
+    while (e) {
+        if (e & 1) r = m31_mul(r, a);
+        a = m31_mul(a, a);
+        e >>= 1;
+    }
+    return r;
+}
+static inline uint32_t m31_inv(uint32_t a) { return m31_pow(a, P - 2); }
+
+uint32_t fo_m31_add(uint32_t a, uint32_t b) { return m31_add(a, b); }
+uint32_t fo_m31_sub(uint32_t a, uint32_t b) { return m31_sub(a, b); }
+uint32_t fo_m31_mul(uint32_t a, uint32_t b) { return m31_mul(a, b); }
+uint32_t fo_m31_inv(uint32_t a) { return m31_inv(a); }
+
+typedef struct {
+    uint32_t a, b;
+} cm31; /* a + b i, i^2 = -1 */
+typedef struct {
+    cm31 c0, c1;
+} qm31; /* c0 + c1 u, u^2 = 2 + i */
+
+static inline cm31 cm_add(cm31 x, cm31 y) { return (cm31){m31_add(x.a, y.a), m31_add(x.b, y.b)}; }
+static inline cm31 cm_sub(cm31 x, cm31 y) { return (cm31){m31_sub(x.a, y.a), m31_sub(x.b, y.b)}; }
+static inline cm31 cm_mul(cm31 x, cm31 y) {
+    return (cm31){m31_sub(m31_mul(x.a, y.a), m31_mul(x.b, y.b)), m31_add(m31_mul(x.a, y.b), m31_mul(x.b, y.a))};
+}
+static inline cm31 cm_scale(cm31 x, uint32_t s) { return (cm31){m31_mul(x.a, s), m31_mul(x.b, s)}; }
+static inline qm31 qm_add(qm31 x, qm31 y) { return (qm31){cm_add(x.c0, y.c0), cm_add(x.c1, y.c1)}; }
+static inline qm31 qm_sub(qm31 x, qm31 y) { return (qm31){cm_sub(x.c0, y.c0), cm_sub(x.c1, y.c1)}; }
+static inline qm31 qm_mul(qm31 x, qm31 y) {
+    /* (x0 + x1 u)(y0 + y1 u) = x0 y0 + R x1 y1 + (x0 y1 + x1 y0) u,  R = 2 + i */
+    const cm31 R = {2, 1};
+    cm31 t = cm_mul(x.c1, y.c1);
+    return (qm31){cm_add(cm_mul(x.c0, y.c0), cm_mul(R, t)), cm_add(cm_mul(x.c0, y.c1), cm_mul(x.c1, y.c0))};
+}
+static inline qm31 qm_scale(qm31 x, uint32_t s) { return (qm31){cm_scale(x.c0, s), cm_scale(x.c1, s)}; }
+static inline qm31 qm_from(const uint32_t v[4]) { return (qm31){{v[0], v[1]}, {v[2], v[3]}}; }
+static inline void qm_to(qm31 x, uint32_t v[4]) {
+    v[0] = x.c0.a;
+    v[1] = x.c0.b;
+    v[2] = x.c1.a;
+    v[3] = x.c1.b;
+}
+static inline int qm_eq(qm31 x, qm31 y) {
+    return x.c0.a == y.c0.a && x.c0.b == y.c0.b && x.c1.a == y.c1.a && x.c1.b == y.c1.b;
+}
+static inline int qm_is_zero(qm31 x) { return !(x.c0.a | x.c0.b | x.c1.a | x.c1.b); }
+static const qm31 QM_ZERO = {{0, 0}, {0, 0}};
+
+void fo_qm31_mul(const uint32_t a[4], const uint32_t b[4], uint32_t out[4]) { qm_to(qm_mul(qm_from(a), qm_from(b)), out); }
+
+/* ------------------------------------------------------------------------------------------------
+ * Codec (src/utils.rs:10-33)
+ * ---------------------------------------------------------------------------------------------- */
+size_t fo_felt_count(size_t len) { return (8 * len + 29) / 30; } /* BitVec::chunks(30) */
+
+void fo_bytes_to_felt_le(const uint8_t* data, size_t len, uint32_t* out) {
+    /* src/utils.rs:11-18: Lsb0 bit stream cut into 30-bit chunks, chunk.load::<u32>() (little-endian bit
+     * significance), last chunk short => zero-extended. */
+    size_t n = fo_felt_count(len);
+    for (size_t k = 0; k < n; k++) {
+        uint32_t v = 0;
+        size_t bit0 = 30 * k;
+        for (unsigned j = 0; j < 30; j++) {
+            size_t bit = bit0 + j;
+            if ((bit >> 3) >= len) break;
+            v |= (uint32_t)((data[bit >> 3] >> (bit & 7)) & 1u) << j;
+        }
+        out[k] = v;
+    }
+}
+
+size_t fo_padded_len(size_t n_felts) {
+    /* src/utils.rs:23: 1 << ((len as f64).log2().ceil() as u32).max(2); `as u32` saturates (-inf -> 0) */
+    double l = ceil(log2((double)n_felts));
+    uint32_t e = (l > 0.0) ? (uint32_t)l : 0u;
+    if (e < 2) e = 2;
+    return (size_t)1 << e;
+}
+
+void fo_polynomial_from_bytes(const uint8_t* data, size_t len, uint32_t* coef, uint32_t* log_size) {
+    size_t f = fo_felt_count(len), fp = fo_padded_len(f);
+    fo_bytes_to_felt_le(data, len, coef);
+    memset(coef + f, 0, (fp - f) * sizeof(uint32_t)); /* src/utils.rs:24 */
+    uint32_t lg = 0;
+    while (((size_t)1 << lg) < fp) lg++;
+    *log_size = lg - 2; /* src/utils.rs:27: 4 chunks of len/4 */
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * Circle group (stwo core/circle.rs)
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+    uint32_t x, y;
+} cpoint;
+static const cpoint CIRCLE_GEN = {2, 1268011823u}; /* M31_CIRCLE_GEN, order 2^31 */
+
+static inline cpoint cp_add(cpoint p, cpoint q) {
+    return (cpoint){m31_sub(m31_mul(p.x, q.x), m31_mul(p.y, q.y)), m31_add(m31_mul(p.x, q.y), m31_mul(p.y, q.x))};
+}
+static cpoint cp_from_index(uint32_t index) {
+    /* CirclePointIndex::to_point = M31_CIRCLE_GEN.mul(index): double-and-add */
+    cpoint res = {1, 0}, cur = CIRCLE_GEN;
+    index &= 0x7fffffffu;
+    while (index) {
+        if (index & 1) res = cp_add(res, cur);
+        cur = cp_add(cur, cur);
+        index >>= 1;
+    }
+    return res;
+}
+void fo_point_from_index(uint32_t index, uint32_t* x, uint32_t* y) {
+    cpoint p = cp_from_index(index);
+    *x = p.x;
+    *y = p.y;
+}
+
+typedef struct {
+    uint32_t initial; /* CirclePointIndex mod 2^31 */
+    uint32_t step;
+    uint32_t log_size;
+} coset;
+#define IDX_MASK 0x7fffffffu
+static inline uint32_t subgroup_gen(uint32_t log_size) { return 1u << (31 - log_size); }
+static coset coset_half_odds(uint32_t log_size) {
+    /* Coset::half_odds(k) = Coset::new(subgroup_gen(k + 2), k) */
+    coset c = {subgroup_gen(log_size + 2), log_size == 0 ? 0u : subgroup_gen(log_size), log_size};
+    return c;
+}
+static inline uint32_t coset_index_at(coset c, uint32_t i) { return (c.initial + (uint32_t)((uint64_t)c.step * i)) & IDX_MASK; }
+static inline cpoint coset_at(coset c, uint32_t i) { return cp_from_index(coset_index_at(c, i)); }
+static inline coset coset_double(coset c) {
+    coset d = {(c.initial * 2u) & IDX_MASK, (c.step * 2u) & IDX_MASK, c.log_size - 1};
+    return d;
+}
+
+uint32_t fo_bit_reverse_index(uint32_t i, uint32_t log_size) {
+    uint32_t r = 0;
+    for (uint32_t b = 0; b < log_size; b++) r |= ((i >> b) & 1u) << (log_size - 1 - b);
+    return r;
+}
+#define brev fo_bit_reverse_index
+
+static uint32_t circle_domain_index_at(uint32_t n, uint32_t i) {
+    /* CircleDomain::index_at: half_coset for i < N/2, conjugate (negated index) otherwise */
+    coset h = coset_half_odds(n - 1);
+    uint32_t half = 1u << (n - 1);
+    if (i < half) return coset_index_at(h, i);
+    return (0u - coset_index_at(h, i - half)) & IDX_MASK;
+}
+void fo_circle_domain_at(uint32_t n, uint32_t i, uint32_t* x, uint32_t* y) {
+    cpoint p = cp_from_index(circle_domain_index_at(n, i));
+    *x = p.x;
+    *y = p.y;
+}
+
+static void bit_reverse_u32(uint32_t* v, uint32_t log_size) {
+    uint32_t n = 1u << log_size;
+    for (uint32_t i = 0; i < n; i++) {
+        uint32_t j = brev(i, log_size);
+        if (i < j) {
+            uint32_t t = v[i];
+            v[i] = v[j];
+            v[j] = t;
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * Twiddles (stwo backend/cpu/circle.rs::{slow_precompute_twiddles, precompute_twiddles})
+ * ---------------------------------------------------------------------------------------------- */
+void fo_precompute_twiddles(uint32_t n, uint32_t* tw, uint32_t* itw) {
+    coset c = coset_half_odds(n - 1); /* root coset, size N/2 (src/commit.rs:14-15) */
+    size_t pos = 0;
+    for (uint32_t lv = 0; lv < n - 1; lv++) {
+        uint32_t half = 1u << (c.log_size - 1);
+        /* coset.iter().take(size/2).map(|p| p.x): iterate by repeated addition of the step point */
+        cpoint p = cp_from_index(c.initial), step = cp_from_index(c.step);
+        for (uint32_t i = 0; i < half; i++) {
+            tw[pos + i] = p.x;
+            p = cp_add(p, step);
+        }
+        bit_reverse_u32(tw + pos, c.log_size - 1);
+        pos += half;
+        c = coset_double(c);
+    }
+    tw[pos] = 1; /* pad to a power of two */
+    size_t total = (size_t)1 << (n - 1);
+    for (size_t i = 0; i < total; i++) itw[i] = m31_inv(tw[i]);
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * Circle FFT (stwo backend/cpu/circle.rs::evaluate, core/fft.rs::butterfly)
+ * ---------------------------------------------------------------------------------------------- */
+static inline void butterfly(uint32_t* v0, uint32_t* v1, uint32_t twid) {
+    uint32_t t = m31_mul(*v1, twid);
+    uint32_t a = *v0;
+    *v0 = m31_add(a, t);
+    *v1 = m31_sub(a, t);
+}
+static void fft_layer_loop(uint32_t* v, uint32_t i, uint32_t h, uint32_t t) {
+    for (uint32_t l = 0; l < (1u << i); l++) {
+        uint32_t idx0 = (h << (i + 1)) + l;
+        uint32_t idx1 = idx0 + (1u << i);
+        butterfly(&v[idx0], &v[idx1], t);
+    }
+}
+/* offset of line-twiddle level `lv` (domain log size n) inside the twiddle buffer */
+static inline size_t tw_level_offset(uint32_t n, uint32_t lv) { return ((size_t)1 << (n - 1)) - ((size_t)1 << (n - 1 - lv)); }
+
+void fo_circle_evaluate(const uint32_t* coef, uint32_t L, uint32_t n, const uint32_t* tw, uint32_t* out) {
+    size_t N = (size_t)1 << n;
+    /* poly.extend(domain.log_size()): zero-pad the coefficient vector */
+    memcpy(out, coef, ((size_t)1 << L) * sizeof(uint32_t));
+    memset(out + ((size_t)1 << L), 0, (N - ((size_t)1 << L)) * sizeof(uint32_t));
+    coset h0 = coset_half_odds(n - 1);
+    cpoint init = cp_from_index(h0.initial);
+    if (n == 1) {
+        butterfly(&out[0], &out[1], init.y);
+        return;
+    }
+    if (n == 2) {
+        butterfly(&out[0], &out[2], init.x);
+        butterfly(&out[1], &out[3], init.x);
+        butterfly(&out[0], &out[1], init.y);
+        butterfly(&out[2], &out[3], m31_neg(init.y));
+        return;
+    }
+    /* line layers, largest stride first */
+    for (int lv = (int)n - 2; lv >= 0; lv--) {
+        const uint32_t* t = tw + tw_level_offset(n, (uint32_t)lv);
+        uint32_t cnt = 1u << (n - 2 - lv);
+        for (uint32_t h = 0; h < cnt; h++) fft_layer_loop(out, (uint32_t)lv + 1, h, t[h]);
+    }
+    /* circle layer: twiddles [y, -y, -x, x] from consecutive pairs (x, y) of the first line level */
+    for (uint32_t j = 0; j < (1u << (n - 3)); j++) {
+        uint32_t x = tw[2 * j], y = tw[2 * j + 1];
+        fft_layer_loop(out, 0, 4 * j + 0, y);
+        fft_layer_loop(out, 0, 4 * j + 1, m31_neg(y));
+        fft_layer_loop(out, 0, 4 * j + 2, m31_neg(x));
+        fft_layer_loop(out, 0, 4 * j + 3, x);
+    }
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * Blake2s compression + Merkle (stwo core/vcs/{blake2s_ref,blake2_merkle,prover}.rs)
+ * ---------------------------------------------------------------------------------------------- */
+static const uint32_t B2S_IV[8] = {0x6A09E667u, 0xBB67AE85u, 0x3C6EF372u, 0xA54FF53Au,
+                                   0x510E527Fu, 0x9B05688Cu, 0x1F83D9ABu, 0x5BE0CD19u};
+static const uint8_t B2S_SIGMA[10][16] = {
+    {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15}, {14, 10, 4, 8, 9, 15, 13, 6, 1, 12, 0, 2, 11, 7, 5, 3},
+    {11, 8, 12, 0, 5, 2, 15, 13, 10, 14, 3, 6, 7, 1, 9, 4}, {7, 9, 3, 1, 13, 12, 11, 14, 2, 6, 5, 10, 4, 0, 15, 8},
+    {9, 0, 5, 7, 2, 4, 10, 15, 14, 1, 11, 12, 6, 8, 3, 13}, {2, 12, 6, 10, 0, 11, 8, 3, 4, 13, 7, 5, 15, 14, 1, 9},
+    {12, 5, 1, 15, 14, 13, 4, 10, 0, 7, 6, 3, 9, 2, 8, 11}, {13, 11, 7, 14, 12, 1, 3, 9, 5, 0, 15, 4, 8, 6, 2, 10},
+    {6, 15, 14, 9, 11, 3, 0, 8, 12, 2, 13, 7, 1, 4, 10, 5}, {10, 2, 8, 4, 7, 6, 1, 5, 15, 11, 9, 14, 3, 12, 13, 0}};
+static inline uint32_t rotr32(uint32_t x, unsigned r) { return (x >> r) | (x << (32 - r)); }
+
+void fo_blake2s_compress(const uint32_t h[8], const uint32_t m[16], uint32_t t0, uint32_t t1, uint32_t f0,
+                         uint32_t f1, uint32_t out[8]) {
+    uint32_t v[16];
+    for (int i = 0; i < 8; i++) {
+        v[i] = h[i];
+        v[i + 8] = B2S_IV[i];
+    }
+    v[12] ^= t0;
+    v[13] ^= t1;
+    v[14] ^= f0;
+    v[15] ^= f1;
+#define G(a, b, c, d, x, y)                \
+    do {                                   \
+        v[a] = v[a] + v[b] + (x);          \
+        v[d] = rotr32(v[d] ^ v[a], 16);    \
+        v[c] = v[c] + v[d];                \
+        v[b] = rotr32(v[b] ^ v[c], 12);    \
+        v[a] = v[a] + v[b] + (y);          \
+        v[d] = rotr32(v[d] ^ v[a], 8);     \
+        v[c] = v[c] + v[d];                \
+        v[b] = rotr32(v[b] ^ v[c], 7);     \
+    } while (0)
+    for (int r = 0; r < 10; r++) {
+        const uint8_t* s = B2S_SIGMA[r];
+        G(0, 4, 8, 12, m[s[0]], m[s[1]]);
+        G(1, 5, 9, 13, m[s[2]], m[s[3]]);
+        G(2, 6, 10, 14, m[s[4]], m[s[5]]);
+        G(3, 7, 11, 15, m[s[6]], m[s[7]]);
+        G(0, 5, 10, 15, m[s[8]], m[s[9]]);
+        G(1, 6, 11, 12, m[s[10]], m[s[11]]);
+        G(2, 7, 8, 13, m[s[12]], m[s[13]]);
+        G(3, 4, 9, 14, m[s[14]], m[s[15]]);
+    }
+#undef G
+    for (int i = 0; i < 8; i++) out[i] = h[i] ^ v[i] ^ v[i + 8];
+}
+
+static inline uint32_t ld32(const uint8_t* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
+static inline void st32(uint8_t* p, uint32_t v) {
+    p[0] = (uint8_t)v;
+    p[1] = (uint8_t)(v >> 8);
+    p[2] = (uint8_t)(v >> 16);
+    p[3] = (uint8_t)(v >> 24);
+}
+
+/* Blake2sMerkleHasher::hash_node: zero initial state, raw compress per 64-byte block, no finalisation */
+static void hash_node(const uint8_t* left, const uint8_t* right, const uint32_t* values, size_t n_values, uint8_t out[32]) {
+    uint32_t state[8] = {0}, m[16], nxt[8];
+    if (left) {
+        for (int i = 0; i < 8; i++) {
+            m[i] = ld32(left + 4 * i);
+            m[8 + i] = ld32(right + 4 * i);
+        }
+        fo_blake2s_compress(state, m, 0, 0, 0, 0, nxt);
+        memcpy(state, nxt, sizeof state);
+    }
+    for (size_t off = 0; off < n_values; off += 16) {
+        for (size_t i = 0; i < 16; i++) m[i] = (off + i < n_values) ? values[off + i] : 0u;
+        fo_blake2s_compress(state, m, 0, 0, 0, 0, nxt);
+        memcpy(state, nxt, sizeof state);
+    }
+    for (int i = 0; i < 8; i++) st32(out + 4 * i, state[i]);
+}
+
+void fo_merkle_commit_layer(uint32_t log_size, const uint8_t* prev, const uint32_t* const* cols, uint32_t ncols,
+                            uint8_t* out) {
+    /* CpuBackend::commit_on_layer */
+    size_t n = (size_t)1 << log_size;
+    uint32_t vals[64];
+    for (size_t i = 0; i < n; i++) {
+        for (uint32_t c = 0; c < ncols && c < 64; c++) vals[c] = cols[c][i];
+        hash_node(prev ? prev + 64 * i : NULL, prev ? prev + 64 * i + 32 : NULL, vals, ncols, out + 32 * i);
+    }
+}
+
+size_t fo_merkle_layer_offset(uint32_t log_size, uint32_t layer_log) {
+    /* layers stored leaves first: sizes 2^log_size, 2^(log_size-1), ..., 1 */
+    size_t off = 0;
+    for (uint32_t l = log_size; l > layer_log; l--) off += (size_t)32 << l;
+    return off;
+}
+
+void fo_merkle_commit(const uint32_t* const* cols, uint32_t ncols, uint32_t log_size, uint8_t* layers_out) {
+    /* MerkleProver::commit with all columns of one length: the leaf layer carries the columns, the
+     * upper layers carry none */
+    fo_merkle_commit_layer(log_size, NULL, cols, ncols, layers_out);
+    for (int l = (int)log_size - 1; l >= 0; l--) {
+        const uint8_t* prev = layers_out + fo_merkle_layer_offset(log_size, (uint32_t)l + 1);
+        fo_merkle_commit_layer((uint32_t)l, prev, NULL, 0, layers_out + fo_merkle_layer_offset(log_size, (uint32_t)l));
+    }
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * Folds (stwo backend/cpu/fri.rs::{fold_circle_into_line, fold_line}, core/fft.rs::ibutterfly)
+ * ---------------------------------------------------------------------------------------------- */
+static inline void ibutterfly_q(qm31* v0, qm31* v1, uint32_t itwid) {
+    qm31 t = *v0;
+    *v0 = qm_add(t, *v1);
+    *v1 = qm_scale(qm_sub(t, *v1), itwid);
+}
+static inline qm31 col_at(const uint32_t* const c[4], size_t i) { return (qm31){{c[0][i], c[1][i]}, {c[2][i], c[3][i]}}; }
+static inline void col_set(uint32_t* const c[4], size_t i, qm31 v) {
+    c[0][i] = v.c0.a;
+    c[1][i] = v.c0.b;
+    c[2][i] = v.c1.a;
+    c[3][i] = v.c1.b;
+}
+
+void fo_fold_circle_into_line(uint32_t* const dst[4], const uint32_t* const src[4], uint32_t n, const uint32_t alpha_[4]) {
+    qm31 alpha = qm_from(alpha_), alpha_sq = qm_mul(alpha, alpha);
+    size_t half = (size_t)1 << (n - 1);
+    for (size_t i = 0; i < half; i++) {
+        /* p = domain.at(bit_reverse_index(i << 1, log_size)) — recomputed per pair, as the CPU backend does */
+        cpoint p = cp_from_index(circle_domain_index_at(n, brev((uint32_t)(i << 1), n)));
+        qm31 f0 = col_at(src, 2 * i), f1 = col_at(src, 2 * i + 1);
+        ibutterfly_q(&f0, &f1, m31_inv(p.y));
+        qm31 f_prime = qm_add(qm_mul(alpha, f1), f0);
+        qm31 d = col_at((const uint32_t* const*)dst, i);
+        col_set(dst, i, qm_add(qm_mul(d, alpha_sq), f_prime));
+    }
+}
+
+/* coset of the line domain with log size m reached from half_odds(domain_n - 1) by doubling */
+static coset line_coset(uint32_t domain_n, uint32_t m) {
+    coset c = coset_half_odds(domain_n - 1);
+    while (c.log_size > m) c = coset_double(c);
+    return c;
+}
+
+void fo_fold_line(const uint32_t* const src[4], uint32_t m, uint32_t domain_n, const uint32_t alpha_[4],
+                  uint32_t* const dst[4]) {
+    qm31 alpha = qm_from(alpha_);
+    coset c = line_coset(domain_n, m);
+    size_t half = (size_t)1 << (m - 1);
+    for (size_t i = 0; i < half; i++) {
+        uint32_t x = coset_at(c, brev((uint32_t)(i << 1), m)).x;
+        qm31 f0 = col_at(src, 2 * i), f1 = col_at(src, 2 * i + 1);
+        ibutterfly_q(&f0, &f1, m31_inv(x));
+        col_set(dst, i, qm_add(f0, qm_mul(alpha, f1)));
+    }
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * Standard Blake2s-256 (RFC 7693; blake2 0.10.6 via stwo core/vcs/blake2_hash.rs) — channel only
+ * ---------------------------------------------------------------------------------------------- */
+void fo_blake2s256(const uint8_t* in, size_t len, uint8_t out[32]) {
+    uint32_t h[8], m[16], nxt[8];
+    for (int i = 0; i < 8; i++) h[i] = B2S_IV[i];
+    h[0] ^= 0x01010020u; /* digest 32, key 0, fanout 1, depth 1 */
+    uint64_t t = 0;
+    size_t off = 0;
+    uint8_t block[64];
+    while (len - off > 64) {
+        for (int i = 0; i < 16; i++) m[i] = ld32(in + off + 4 * i);
+        t += 64;
+        fo_blake2s_compress(h, m, (uint32_t)t, (uint32_t)(t >> 32), 0, 0, nxt);
+        memcpy(h, nxt, sizeof h);
+        off += 64;
+    }
+    memset(block, 0, 64);
+    memcpy(block, in + off, len - off);
+    t += len - off;
+    for (int i = 0; i < 16; i++) m[i] = ld32(block + 4 * i);
+    fo_blake2s_compress(h, m, (uint32_t)t, (uint32_t)(t >> 32), 0xFFFFFFFFu, 0, nxt);
+    for (int i = 0; i < 8; i++) st32(out + 4 * i, nxt[i]);
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * Blake2sChannel (stwo core/channel/blake2s.rs) + Blake2sMerkleChannel::mix_root
+ * ---------------------------------------------------------------------------------------------- */
+void fo_channel_init(fo_channel* c) { memset(c, 0, sizeof *c); }
+static void channel_update_digest(fo_channel* c, const uint8_t d[32]) {
+    memcpy(c->digest, d, 32);
+    c->n_challenges += 1;
+    c->n_sent = 0;
+}
+void fo_channel_mix_u64(fo_channel* c, uint64_t v) {
+    /* raw compress with h = digest words, msg = [lo, hi, 0 x 14], t = f = 0 */
+    uint32_t h[8], m[16] = {0}, r[8];
+    uint8_t d[32];
+    for (int i = 0; i < 8; i++) h[i] = ld32(c->digest + 4 * i);
+    m[0] = (uint32_t)v;
+    m[1] = (uint32_t)(v >> 32);
+    fo_blake2s_compress(h, m, 0, 0, 0, 0, r);
+    for (int i = 0; i < 8; i++) st32(d + 4 * i, r[i]);
+    channel_update_digest(c, d);
+}
+void fo_channel_mix_root(fo_channel* c, const uint8_t root[32]) {
+    uint8_t buf[64], d[32];
+    memcpy(buf, c->digest, 32);
+    memcpy(buf + 32, root, 32);
+    fo_blake2s256(buf, 64, d);
+    channel_update_digest(c, d);
+}
+void fo_channel_mix_felts(fo_channel* c, const uint32_t* q, size_t n_qm31) {
+    size_t len = 32 + 16 * n_qm31;
+    uint8_t* buf = (uint8_t*)malloc(len);
+    uint8_t d[32];
+    memcpy(buf, c->digest, 32);
+    for (size_t i = 0; i < 4 * n_qm31; i++) st32(buf + 32 + 4 * i, q[i]);
+    fo_blake2s256(buf, len, d);
+    free(buf);
+    channel_update_digest(c, d);
+}
+void fo_channel_draw_random_bytes(fo_channel* c, uint8_t out[32]) {
+    uint8_t buf[64];
+    memcpy(buf, c->digest, 32);
+    memset(buf + 32, 0, 32);
+    for (int i = 0; i < 8; i++) buf[32 + i] = (uint8_t)(c->n_sent >> (8 * i)); /* n_sent.to_le_bytes(), padded */
+    c->n_sent += 1;
+    fo_blake2s256(buf, 64, out);
+}
+void fo_channel_draw_felt(fo_channel* c, uint32_t out[4]) {
+    /* draw_base_felts: retry until all eight u32 < 2P, then reduce; the first four form the QM31 */
+    for (;;) {
+        uint8_t b[32];
+        uint32_t w[8];
+        int ok = 1;
+        fo_channel_draw_random_bytes(c, b);
+        for (int i = 0; i < 8; i++) {
+            w[i] = ld32(b + 4 * i);
+            if (w[i] >= 2u * P) ok = 0;
+        }
+        if (!ok) continue;
+        for (int i = 0; i < 4; i++) out[i] = m31_reduce(w[i]);
+        return;
+    }
+}
+uint32_t fo_channel_trailing_zeros(const fo_channel* c) {
+    /* u128::from_le_bytes(digest[0..16]).trailing_zeros() */
+    uint32_t tz = 0;
+    for (int i = 0; i < 16; i++) {
+        uint8_t b = c->digest[i];
+        if (b == 0) {
+            tz += 8;
+            continue;
+        }
+        while (!(b & 1)) {
+            tz++;
+            b >>= 1;
+        }
+        return tz;
+    }
+    return 128;
+}
+uint64_t fo_grind(const fo_channel* c, uint32_t pow_bits) {
+    /* CpuBackend::grind: sequential scan from 0 */
+    for (uint64_t nonce = 0;; nonce++) {
+        fo_channel t = *c;
+        fo_channel_mix_u64(&t, nonce);
+        if (fo_channel_trailing_zeros(&t) >= pow_bits) return nonce;
+    }
+}
+
+static int cmp_u32(const void* a, const void* b) {
+    uint32_t x = *(const uint32_t*)a, y = *(const uint32_t*)b;
+    return x < y ? -1 : x > y;
+}
+size_t fo_queries_generate(fo_channel* c, uint32_t log_domain_size, size_t n_queries, uint32_t* out) {
+    /* Queries::generate: 8 LE u32 per draw, masked to the domain, until n_queries drawn; BTreeSet */
+    size_t cnt = 0;
+    uint32_t mask = (log_domain_size >= 32) ? 0xFFFFFFFFu : ((1u << log_domain_size) - 1);
+    while (cnt < n_queries) {
+        uint8_t b[32];
+        fo_channel_draw_random_bytes(c, b);
+        for (int i = 0; i < 8 && cnt < n_queries; i++) out[cnt++] = ld32(b + 4 * i) & mask;
+    }
+    qsort(out, cnt, sizeof(uint32_t), cmp_u32);
+    size_t u = 0;
+    for (size_t i = 0; i < cnt; i++)
+        if (u == 0 || out[u - 1] != out[i]) out[u++] = out[i];
+    return u;
+}
+/* Queries::fold: positions >> n_folds, consecutive dedup */
+static size_t queries_fold(const uint32_t* in, size_t n, uint32_t n_folds, uint32_t* out) {
+    size_t u = 0;
+    for (size_t i = 0; i < n; i++) {
+        uint32_t q = in[i] >> n_folds;
+        if (u == 0 || out[u - 1] != q) out[u++] = q;
+    }
+    return u;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * growable buffers
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+    uint8_t* p;
+    size_t len, cap;
+} bytebuf;
+static void bb_push(bytebuf* b, const void* src, size_t n) {
+    if (b->len + n > b->cap) {
+        size_t nc = b->cap ? b->cap * 2 : 256;
+        while (nc < b->len + n) nc *= 2;
+        b->p = (uint8_t*)realloc(b->p, nc);
+        b->cap = nc;
+    }
+    memcpy(b->p + b->len, src, n);
+    b->len += n;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * Decommitment (stwo core/fri.rs::compute_decommitment_positions_and_witness_evals,
+ *               core/vcs/prover.rs::MerkleProver::decommit)
+ * ---------------------------------------------------------------------------------------------- */
+/* returns decommitment positions (malloc'd) and appends witness evals; fold_step = 1 */
+static uint32_t* decommit_positions_and_witness(const uint32_t* const col[4], const uint32_t* queries, size_t nq,
+                                                size_t* n_pos_out, bytebuf* witness) {
+    uint32_t* pos = (uint32_t*)malloc(sizeof(uint32_t) * 2 * (nq ? nq : 1));
+    size_t np = 0, i = 0;
+    while (i < nq) {
+        size_t j = i;
+        while (j < nq && (queries[j] >> 1) == (queries[i] >> 1)) j++; /* chunk_by folding coset */
+        uint32_t start = (queries[i] >> 1) << 1;
+        size_t k = i;
+        for (uint32_t position = start; position < start + 2; position++) {
+            pos[np++] = position;
+            if (k < j && queries[k] == position) {
+                k++;
+                continue; /* the verifier can compute this one */
+            }
+            uint32_t v[4];
+            qm_to(col_at(col, position), v);
+            bb_push(witness, v, 16);
+        }
+        i = j;
+    }
+    *n_pos_out = np;
+    return pos;
+}
+
+/* MerkleProver::decommit for a tree whose only columns sit on the leaf layer.
+ * layers: leaves-first buffer (fo_merkle_commit). queried leaf values go to the caller implicitly
+ * (they are the decommitment positions' column values), so only hash_witness is produced here;
+ * column_witness stays empty for this shape. */
+static void merkle_decommit(const uint8_t* layers, uint32_t log_size, const uint32_t* positions, size_t n_pos,
+                            bytebuf* hash_witness) {
+    uint32_t* last = NULL;
+    size_t n_last = 0;
+    for (int layer_log = (int)log_size; layer_log >= 0; layer_log--) {
+        const uint8_t* prev_hashes = (layer_log < (int)log_size) ? layers + fo_merkle_layer_offset(log_size, (uint32_t)layer_log + 1) : NULL;
+        const uint32_t* colq = (layer_log == (int)log_size) ? positions : NULL;
+        size_t n_colq = (layer_log == (int)log_size) ? n_pos : 0;
+        uint32_t* total = (uint32_t*)malloc(sizeof(uint32_t) * (n_last + n_colq + 1));
+        size_t n_total = 0, pi = 0, ci = 0;
+        while (pi < n_last || ci < n_colq) {
+            /* next_decommitment_node: min(prev.peek()/2, col.peek()) */
+            uint32_t node;
+            if (pi < n_last && ci < n_colq) {
+                uint32_t a = last[pi] / 2, b = colq[ci];
+                node = a < b ? a : b;
+            } else if (pi < n_last)
+                node = last[pi] / 2;
+            else
+                node = colq[ci];
+            if (prev_hashes) {
+                if (pi < n_last && last[pi] == 2 * node)
+                    pi++;
+                else
+                    bb_push(hash_witness, prev_hashes + 32 * (size_t)(2 * node), 32);
+                if (pi < n_last && last[pi] == 2 * node + 1)
+                    pi++;
+                else
+                    bb_push(hash_witness, prev_hashes + 32 * (size_t)(2 * node + 1), 32);
+            }
+            if (ci < n_colq && colq[ci] == node) ci++; /* queried values returned, not witnessed */
+            total[n_total++] = node;
+        }
+        free(last);
+        last = total;
+        n_last = n_total;
+    }
+    free(last);
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * Last layer (stwo core/poly/line.rs::{LineEvaluation::interpolate, line_ifft, LinePoly})
+ * ---------------------------------------------------------------------------------------------- */
+static void bit_reverse_qm(qm31* v, uint32_t log_size) {
+    uint32_t n = 1u << log_size;
+    for (uint32_t i = 0; i < n; i++) {
+        uint32_t j = brev(i, log_size);
+        if (i < j) {
+            qm31 t = v[i];
+            v[i] = v[j];
+            v[j] = t;
+        }
+    }
+}
+/* in: evaluations in bit-reversed order on LineDomain(c); out: coefficients in LinePoly's internal
+ * (bit-reversed) order */
+static void line_interpolate(qm31* v, coset c) {
+    uint32_t log_size = c.log_size;
+    size_t n = (size_t)1 << log_size;
+    bit_reverse_qm(v, log_size);
+    coset d = c;
+    while (d.log_size > 0) {
+        size_t sz = (size_t)1 << d.log_size;
+        for (size_t base = 0; base < n; base += sz) {
+            qm31 *l = v + base, *r = v + base + sz / 2;
+            for (size_t i = 0; i < sz / 2; i++) {
+                uint32_t x = coset_at(d, (uint32_t)i).x;
+                ibutterfly_q(&l[i], &r[i], m31_inv(x));
+            }
+        }
+        d = coset_double(d);
+    }
+    uint32_t len_inv = m31_inv((uint32_t)n);
+    for (size_t i = 0; i < n; i++) v[i] = qm_scale(v[i], len_inv);
+}
+/* LinePoly::eval_at_point with coeffs in internal (bit-reversed) order */
+static qm31 fold_rec(const qm31* values, size_t n, const qm31* factors) {
+    if (n == 1) return values[0];
+    qm31 l = fold_rec(values, n / 2, factors + 1), r = fold_rec(values + n / 2, n / 2, factors + 1);
+    return qm_add(l, qm_mul(r, factors[0]));
+}
+static qm31 line_poly_eval(const qm31* coeffs, uint32_t log_size, uint32_t x) {
+    qm31 dbl[32];
+    qm31 xx = {{x, 0}, {0, 0}};
+    const qm31 one = {{1, 0}, {0, 0}};
+    for (uint32_t i = 0; i < log_size; i++) {
+        dbl[i] = xx;
+        qm31 sq = qm_mul(xx, xx);
+        xx = qm_sub(qm_add(sq, sq), one); /* CirclePoint::double_x */
+    }
+    return fold_rec(coeffs, (size_t)1 << log_size, dbl);
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * API: commit (src/commit.rs:11-22)
+ * ---------------------------------------------------------------------------------------------- */
+int fo_commit(const uint8_t* data, size_t len, uint32_t B, uint8_t root[32]) {
+    size_t fp = fo_padded_len(fo_felt_count(len));
+    uint32_t* coef = (uint32_t*)malloc(fp * sizeof(uint32_t));
+    uint32_t L;
+    fo_polynomial_from_bytes(data, len, coef, &L);
+    if (L + B < 1 || L + B > 30) {
+        free(coef);
+        return FO_ERR_INVARIANT; /* Coset::half_odds(L + B - 1) under/overflow panics upstream */
+    }
+    uint32_t n = L + B;
+    size_t N = (size_t)1 << n;
+    uint32_t* tw = (uint32_t*)malloc((N / 2 ? N / 2 : 1) * sizeof(uint32_t));
+    uint32_t* itw = (uint32_t*)malloc((N / 2 ? N / 2 : 1) * sizeof(uint32_t));
+    fo_precompute_twiddles(n, tw, itw); /* src/commit.rs:15 — recomputed on every call */
+    uint32_t* ev = (uint32_t*)malloc(4 * N * sizeof(uint32_t));
+    const uint32_t* cols[4];
+    for (int c = 0; c < 4; c++) {
+        fo_circle_evaluate(coef + ((size_t)c << L), L, n, tw, ev + c * N);
+        cols[c] = ev + c * N;
+    }
+    uint8_t* layers = (uint8_t*)malloc(64 * N);
+    fo_merkle_commit(cols, 4, n, layers);
+    memcpy(root, layers + fo_merkle_layer_offset(n, 0), 32);
+    free(layers);
+    free(ev);
+    free(itw);
+    free(tw);
+    free(coef);
+    return FO_OK;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * API: commit_and_generate_proof (src/proof.rs:32-77; stwo core/fri.rs::FriProver)
+ * ---------------------------------------------------------------------------------------------- */
+static __thread fo_trace g_trace;
+const fo_trace* fo_last_trace(void) { return &g_trace; }
+
+static void layer_proof_take(fo_layer_proof* lp, bytebuf* fw, bytebuf* hw, const uint8_t* root) {
+    lp->fri_witness = (uint32_t*)fw->p;
+    lp->n_fri_witness = fw->len / 16;
+    lp->hash_witness = hw->p;
+    lp->n_hash_witness = hw->len / 32;
+    lp->column_witness = NULL;
+    lp->n_column_witness = 0;
+    memcpy(lp->commitment, root, 32);
+}
+
+typedef struct {
+    uint32_t* vals; /* 4 columns of 2^log */
+    uint8_t* tree;  /* leaves-first layers */
+    uint32_t log;
+} fri_layer;
+
+int fo_commit_and_generate_proof(const uint8_t* data, size_t len, const uint64_t* seed, fo_pcs_config cfg,
+                                 uint8_t commitment[32], fo_proof** out) {
+    uint32_t B = cfg.log_blowup_factor, last = cfg.log_last_layer_degree_bound;
+    size_t fp = fo_padded_len(fo_felt_count(len));
+    uint32_t* coef = (uint32_t*)malloc(fp * sizeof(uint32_t));
+    uint32_t L;
+    fo_polynomial_from_bytes(data, len, coef, &L);
+    /* invariants the reference enforces by panicking: half_odds underflow; FriProver::commit_last_layer's
+     * assert_eq!(evaluation.len(), last_layer_domain_size) needs L - 1 >= last */
+    if (L + B < 2 || L + B > 30 || L < 1 + last) {
+        free(coef);
+        return FO_ERR_INVARIANT;
+    }
+    uint32_t n = L + B;
+    size_t N = (size_t)1 << n;
+    memset(&g_trace, 0, sizeof g_trace);
+
+    fo_channel ch;
+    fo_channel_init(&ch);
+    if (seed) fo_channel_mix_u64(&ch, *seed); /* src/proof.rs:40-42 */
+
+    uint32_t* tw = (uint32_t*)malloc((N / 2) * sizeof(uint32_t));
+    uint32_t* itw = (uint32_t*)malloc((N / 2) * sizeof(uint32_t));
+    fo_precompute_twiddles(n, tw, itw);
+    uint32_t* ev = (uint32_t*)malloc(4 * N * sizeof(uint32_t));
+    const uint32_t* cols[4];
+    for (int c = 0; c < 4; c++) {
+        fo_circle_evaluate(coef + ((size_t)c << L), L, n, tw, ev + c * N);
+        cols[c] = ev + c * N;
+    }
+
+    /* FriProver::commit_first_layer */
+    uint8_t* tree0 = (uint8_t*)malloc(64 * N);
+    fo_merkle_commit(cols, 4, n, tree0);
+    const uint8_t* root0 = tree0 + fo_merkle_layer_offset(n, 0);
+    fo_channel_mix_root(&ch, root0);
+    memcpy(g_trace.roots[0], root0, 32);
+
+    /* FriProver::commit_inner_layers */
+    uint32_t n_inner_max = n;
+    fri_layer* inner = (fri_layer*)calloc(n_inner_max, sizeof(fri_layer));
+    size_t n_inner = 0;
+    uint32_t alpha[4];
+    fo_channel_draw_felt(&ch, alpha);
+    memcpy(g_trace.alphas[0], alpha, 16);
+    uint32_t cur_log = n - 1;
+    uint32_t* cur = (uint32_t*)calloc(4 * ((size_t)1 << cur_log), sizeof(uint32_t)); /* LineEvaluation::new_zero */
+    {
+        uint32_t* d[4];
+        for (int c = 0; c < 4; c++) d[c] = cur + ((size_t)c << cur_log);
+        fo_fold_circle_into_line(d, cols, n, alpha);
+    }
+    uint32_t last_log = last + B; /* FriConfig::last_layer_domain_size */
+    while (cur_log > last_log) {
+        const uint32_t* lc[4];
+        for (int c = 0; c < 4; c++) lc[c] = cur + ((size_t)c << cur_log);
+        uint8_t* tree = (uint8_t*)malloc((size_t)64 << cur_log);
+        fo_merkle_commit(lc, 4, cur_log, tree);
+        const uint8_t* root = tree + fo_merkle_layer_offset(cur_log, 0);
+        fo_channel_mix_root(&ch, root);
+        fo_channel_draw_felt(&ch, alpha);
+        if (n_inner + 1 < 64) {
+            memcpy(g_trace.roots[n_inner + 1], root, 32);
+            memcpy(g_trace.alphas[n_inner + 1], alpha, 16);
+        }
+        uint32_t* nxt = (uint32_t*)malloc(4 * sizeof(uint32_t) * ((size_t)1 << (cur_log - 1)));
+        uint32_t* d[4];
+        for (int c = 0; c < 4; c++) d[c] = nxt + ((size_t)c << (cur_log - 1));
+        fo_fold_line(lc, cur_log, n, alpha, d);
+        inner[n_inner].vals = cur;
+        inner[n_inner].tree = tree;
+        inner[n_inner].log = cur_log;
+        n_inner++;
+        cur = nxt;
+        cur_log--;
+    }
+    g_trace.n_layers = (uint32_t)(1 + n_inner);
+
+    /* FriProver::commit_last_layer */
+    int rc = FO_OK;
+    size_t n_last_dom = (size_t)1 << cur_log;
+    qm31* lastv = (qm31*)malloc(n_last_dom * sizeof(qm31));
+    {
+        const uint32_t* lc[4];
+        for (int c = 0; c < 4; c++) lc[c] = cur + ((size_t)c << cur_log);
+        for (size_t i = 0; i < n_last_dom; i++) lastv[i] = col_at(lc, i);
+    }
+    line_interpolate(lastv, line_coset(n, cur_log));
+    bit_reverse_qm(lastv, cur_log); /* into_ordered_coefficients */
+    size_t n_poly = (size_t)1 << last;
+    for (size_t i = n_poly; i < n_last_dom; i++)
+        if (!qm_is_zero(lastv[i])) rc = FO_ERR_INVARIANT; /* assert!(zeros.all(is_zero), "invalid degree") */
+    bit_reverse_qm(lastv, last); /* LinePoly::from_ordered_coefficients */
+    uint32_t* last_poly = (uint32_t*)malloc(16 * n_poly);
+    for (size_t i = 0; i < n_poly; i++) qm_to(lastv[i], last_poly + 4 * i);
+    free(lastv);
+    fo_channel_mix_felts(&ch, last_poly, n_poly);
+
+    fo_proof* pr = (fo_proof*)calloc(1, sizeof(fo_proof));
+    pr->last_layer_poly = last_poly;
+    pr->n_last_layer_poly = n_poly;
+    pr->pcs_config = cfg;
+    pr->log_size_bound = L; /* polynomial.log_size(), src/proof.rs:73 */
+
+    if (rc == FO_OK) {
+        /* src/proof.rs:58-60 */
+        memcpy(g_trace.digest_before_grind, ch.digest, 32);
+        pr->proof_of_work = fo_grind(&ch, cfg.pow_bits);
+        fo_channel_mix_u64(&ch, pr->proof_of_work);
+
+        /* FriProver::decommit */
+        uint32_t* q = (uint32_t*)malloc(sizeof(uint32_t) * (cfg.n_queries ? cfg.n_queries : 1));
+        size_t nq = fo_queries_generate(&ch, n, cfg.n_queries, q);
+
+        /* src/proof.rs:62-66: evaluations at the (sorted, deduplicated) query positions */
+        pr->evaluations = (uint32_t*)malloc(16 * (nq ? nq : 1));
+        pr->n_evaluations = nq;
+        for (size_t i = 0; i < nq; i++) qm_to(col_at(cols, q[i]), pr->evaluations + 4 * i);
+
+        /* first layer */
+        {
+            bytebuf fw = {0}, hw = {0};
+            size_t np;
+            uint32_t* pos = decommit_positions_and_witness(cols, q, nq, &np, &fw);
+            merkle_decommit(tree0, n, pos, np, &hw);
+            free(pos);
+            layer_proof_take(&pr->first_layer, &fw, &hw, root0);
+        }
+        /* inner layers: queries.fold(1), then fold(1) per layer */
+        pr->inner_layers = (fo_layer_proof*)calloc(n_inner ? n_inner : 1, sizeof(fo_layer_proof));
+        pr->n_inner_layers = n_inner;
+        uint32_t* lq = (uint32_t*)malloc(sizeof(uint32_t) * (nq ? nq : 1));
+        size_t nlq = queries_fold(q, nq, 1, lq);
+        for (size_t k = 0; k < n_inner; k++) {
+            const uint32_t* lc[4];
+            for (int c = 0; c < 4; c++) lc[c] = inner[k].vals + ((size_t)c << inner[k].log);
+            bytebuf fw = {0}, hw = {0};
+            size_t np;
+            uint32_t* pos = decommit_positions_and_witness(lc, lq, nlq, &np, &fw);
+            merkle_decommit(inner[k].tree, inner[k].log, pos, np, &hw);
+            free(pos);
+            layer_proof_take(&pr->inner_layers[k], &fw, &hw, inner[k].tree + fo_merkle_layer_offset(inner[k].log, 0));
+            nlq = queries_fold(lq, nlq, 1, lq);
+        }
+        free(lq);
+        free(q);
+        memcpy(commitment, root0, 32);
+    }
+
+    for (size_t k = 0; k < n_inner; k++) {
+        free(inner[k].vals);
+        free(inner[k].tree);
+    }
+    free(inner);
+    free(cur);
+    free(tree0);
+    free(ev);
+    free(itw);
+    free(tw);
+    free(coef);
+    if (rc != FO_OK) {
+        fo_proof_free(pr);
+        return rc;
+    }
+    *out = pr;
+    return FO_OK;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * API: verify_proof (src/proof.rs:79-101; stwo core/fri.rs::FriVerifier, core/vcs/verifier.rs)
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+    uint32_t* positions; /* decommitment positions */
+    size_t n_positions;
+    qm31* subset_evals; /* 2 per subset */
+    uint32_t* subset_start;
+    size_t n_subsets;
+} sparse_eval;
+
+/* compute_decommitment_positions_and_rebuild_evals, fold_step = 1.
+ * returns 0 ok, 1 insufficient witness, 2 query_evals exhausted (reference: unwrap panic) */
+static int rebuild_evals(const uint32_t* queries, size_t nq, const qm31* query_evals, size_t n_query_evals,
+                         const qm31* witness, size_t n_witness, size_t* witness_used, sparse_eval* se) {
+    se->positions = (uint32_t*)malloc(sizeof(uint32_t) * 2 * (nq ? nq : 1));
+    se->subset_evals = (qm31*)malloc(sizeof(qm31) * 2 * (nq ? nq : 1));
+    se->subset_start = (uint32_t*)malloc(sizeof(uint32_t) * (nq ? nq : 1));
+    se->n_positions = se->n_subsets = 0;
+    size_t qi = 0, wi = 0, i = 0;
+    while (i < nq) {
+        size_t j = i;
+        while (j < nq && (queries[j] >> 1) == (queries[i] >> 1)) j++;
+        uint32_t start = (queries[i] >> 1) << 1;
+        size_t k = i;
+        for (uint32_t position = start; position < start + 2; position++) {
+            se->positions[se->n_positions++] = position;
+            qm31 v;
+            if (k < j && queries[k] == position) {
+                k++;
+                if (qi >= n_query_evals) return 2;
+                v = query_evals[qi++];
+            } else {
+                if (wi >= n_witness) return 1;
+                v = witness[wi++];
+            }
+            se->subset_evals[2 * se->n_subsets + (position - start)] = v;
+        }
+        se->subset_start[se->n_subsets++] = start;
+        i = j;
+    }
+    *witness_used = wi;
+    return 0;
+}
+static void sparse_free(sparse_eval* se) {
+    free(se->positions);
+    free(se->subset_evals);
+    free(se->subset_start);
+}
+
+/* MerkleVerifier::verify for columns only on the leaf layer (4 columns). 0 = ok. */
+static int merkle_verify(const uint8_t root[32], uint32_t log_size, const uint32_t* positions, size_t n_pos,
+                         const uint32_t* queried_values, size_t n_values, const fo_layer_proof* lp) {
+    size_t hw = 0, vi = 0;
+    uint32_t* last_idx = NULL;
+    uint8_t* last_hash = NULL;
+    size_t n_last = 0;
+    int rc = 0;
+    for (int layer_log = (int)log_size; layer_log >= 0 && !rc; layer_log--) {
+        int have_prev = layer_log < (int)log_size;
+        uint32_t ncols = have_prev ? 0 : 4;
+        const uint32_t* colq = have_prev ? NULL : positions;
+        size_t n_colq = have_prev ? 0 : n_pos;
+        uint32_t* tot_idx = (uint32_t*)malloc(sizeof(uint32_t) * (n_last + n_colq + 1));
+        uint8_t* tot_hash = (uint8_t*)malloc(32 * (n_last + n_colq + 1));
+        size_t n_tot = 0, pi = 0, ci = 0;
+        while ((pi < n_last || ci < n_colq) && !rc) {
+            uint32_t node;
+            if (pi < n_last && ci < n_colq) {
+                uint32_t a = last_idx[pi] / 2, b = colq[ci];
+                node = a < b ? a : b;
+            } else if (pi < n_last)
+                node = last_idx[pi] / 2;
+            else
+                node = colq[ci];
+            const uint8_t *lh = NULL, *rh = NULL;
+            if (have_prev) {
+                if (pi < n_last && last_idx[pi] == 2 * node)
+                    lh = last_hash + 32 * pi++;
+                else if (hw < lp->n_hash_witness)
+                    lh = lp->hash_witness + 32 * hw++;
+                else
+                    rc = 1; /* WitnessTooShort */
+                if (!rc) {
+                    if (pi < n_last && last_idx[pi] == 2 * node + 1)
+                        rh = last_hash + 32 * pi++;
+                    else if (hw < lp->n_hash_witness)
+                        rh = lp->hash_witness + 32 * hw++;
+                    else
+                        rc = 1;
+                }
+                if (rc) break;
+            }
+            uint32_t vals[4];
+            if (ci < n_colq && colq[ci] == node) {
+                ci++;
+                if (vi + ncols > n_values) {
+                    rc = 2; /* TooFewQueriedValues */
+                    break;
+                }
+                for (uint32_t c = 0; c < ncols; c++) vals[c] = queried_values[vi++];
+            } else if (ncols) {
+                rc = 1; /* column_witness is empty for this shape */
+                break;
+            }
+            tot_idx[n_tot] = node;
+            hash_node(lh, rh, vals, ncols, tot_hash + 32 * n_tot);
+            n_tot++;
+        }
+        free(last_idx);
+        free(last_hash);
+        last_idx = tot_idx;
+        last_hash = tot_hash;
+        n_last = n_tot;
+    }
+    if (!rc && hw != lp->n_hash_witness) rc = 3;     /* WitnessTooLong */
+    if (!rc && vi != n_values) rc = 4;               /* TooManyQueriedValues */
+    if (!rc && lp->n_column_witness != 0) rc = 3;    /* WitnessTooLong */
+    if (!rc && (n_last != 1 || memcmp(last_hash, root, 32) != 0)) rc = 5; /* RootMismatch */
+    free(last_idx);
+    free(last_hash);
+    return rc;
+}
+
+int fo_verify(const fo_proof* proof, const uint64_t* seed, int* ok) {
+    *ok = 0;
+    const fo_pcs_config cfg = proof->pcs_config;
+    uint32_t B = cfg.log_blowup_factor, last = cfg.log_last_layer_degree_bound, L = proof->log_size_bound;
+    if (L + B < 2 || L + B > 30 || L < 1) return FO_ERR_INVARIANT;
+    uint32_t n = L + B;
+    fo_channel ch;
+    fo_channel_init(&ch);
+    if (seed) fo_channel_mix_u64(&ch, *seed);
+
+    /* FriVerifier::commit */
+    qm31 alphas[64];
+    uint32_t a4[4];
+    fo_channel_mix_root(&ch, proof->first_layer.commitment);
+    fo_channel_draw_felt(&ch, a4);
+    alphas[0] = qm_from(a4);
+    uint32_t layer_bound = L - 1; /* CirclePolyDegreeBound::fold_to_line */
+    if (proof->n_inner_layers >= 63) return FO_OK;
+    for (size_t k = 0; k < proof->n_inner_layers; k++) {
+        fo_channel_mix_root(&ch, proof->inner_layers[k].commitment);
+        fo_channel_draw_felt(&ch, a4);
+        alphas[k + 1] = qm_from(a4);
+        if (layer_bound < 1) return FO_OK; /* InvalidNumFriLayers => false */
+        layer_bound -= 1;
+    }
+    if (layer_bound != last) return FO_OK; /* InvalidNumFriLayers */
+    if (proof->n_last_layer_poly > ((size_t)1 << last)) return FO_OK; /* LastLayerDegreeInvalid */
+    fo_channel_mix_felts(&ch, proof->last_layer_poly, proof->n_last_layer_poly);
+
+    /* src/proof.rs:92-95 */
+    fo_channel_mix_u64(&ch, proof->proof_of_work);
+    if (fo_channel_trailing_zeros(&ch) < cfg.pow_bits) return FO_OK;
+
+    /* sample_query_positions */
+    uint32_t* q = (uint32_t*)malloc(sizeof(uint32_t) * (cfg.n_queries ? cfg.n_queries : 1));
+    size_t nq = fo_queries_generate(&ch, n, cfg.n_queries, q);
+
+    int rc = FO_OK, good = 1;
+    /* decommit_first_layer */
+    const qm31* evals = (const qm31*)proof->evaluations; /* 4 x u32 each, same layout */
+    sparse_eval se;
+    size_t wused = 0;
+    int r = rebuild_evals(q, nq, evals, proof->n_evaluations, (const qm31*)proof->first_layer.fri_witness,
+                          proof->first_layer.n_fri_witness, &wused, &se);
+    if (r == 2) {
+        rc = FO_ERR_INVARIANT; /* query_evals.next().unwrap() panics (src/proof.rs:166-173) */
+        good = 0;
+    } else if (r == 1 || wused != proof->first_layer.n_fri_witness) {
+        good = 0; /* FirstLayerEvaluationsInvalid */
+    }
+    uint32_t* lq = (uint32_t*)malloc(sizeof(uint32_t) * (nq ? nq : 1));
+    size_t nlq = 0;
+    qm31* layer_evals = NULL;
+    if (good) {
+        if (merkle_verify(proof->first_layer.commitment, n, se.positions, se.n_positions, (const uint32_t*)se.subset_evals,
+                          4 * se.n_positions, &proof->first_layer) != 0)
+            good = 0; /* FirstLayerCommitmentInvalid */
+    }
+    if (good) {
+        /* decommit_inner_layers: fold the circle sparse evals with alpha_0 into the first line layer */
+        nlq = queries_fold(q, nq, 1, lq);
+        layer_evals = (qm31*)malloc(sizeof(qm31) * (nlq ? nlq : 1));
+        if (proof->n_inner_layers == 0) {
+            rc = FO_ERR_INVARIANT; /* assert!(first_layer_columns.is_empty()) fails upstream */
+            good = 0;
+        }
+    }
+    if (good) {
+        for (size_t s = 0; s < se.n_subsets; s++) {
+            /* SparseEvaluation::fold_circle: fold at p = domain.at(bit_reverse(subset_start)) */
+            cpoint p = cp_from_index(circle_domain_index_at(n, brev(se.subset_start[s], n)));
+            qm31 f0 = se.subset_evals[2 * s], f1 = se.subset_evals[2 * s + 1];
+            ibutterfly_q(&f0, &f1, m31_inv(p.y));
+            /* accumulate_line onto zero: 0 * alpha^2 + (alpha f1 + f0) */
+            layer_evals[s] = qm_add(qm_mul(alphas[0], f1), f0);
+        }
+    }
+    sparse_free(&se);
+    uint32_t cur_log = n - 1;
+    for (size_t k = 0; good && k < proof->n_inner_layers; k++) {
+        const fo_layer_proof* lp = &proof->inner_layers[k];
+        sparse_eval s2;
+        size_t wu = 0;
+        int r2 = rebuild_evals(lq, nlq, layer_evals, nlq, (const qm31*)lp->fri_witness, lp->n_fri_witness, &wu, &s2);
+        if (r2 != 0 || wu != lp->n_fri_witness) good = 0; /* InnerLayerEvaluationsInvalid */
+        if (good && merkle_verify(lp->commitment, cur_log, s2.positions, s2.n_positions, (const uint32_t*)s2.subset_evals,
+                                  4 * s2.n_positions, lp) != 0)
+            good = 0; /* InnerLayerCommitmentInvalid */
+        if (good) {
+            coset c = line_coset(n, cur_log);
+            for (size_t s = 0; s < s2.n_subsets; s++) {
+                uint32_t x = coset_at(c, brev(s2.subset_start[s], cur_log)).x;
+                qm31 f0 = s2.subset_evals[2 * s], f1 = s2.subset_evals[2 * s + 1];
+                ibutterfly_q(&f0, &f1, m31_inv(x));
+                layer_evals[s] = qm_add(f0, qm_mul(alphas[k + 1], f1));
+            }
+            nlq = queries_fold(lq, nlq, 1, lq);
+            cur_log--;
+        }
+        sparse_free(&s2);
+    }
+    /* decommit_last_layer */
+    if (good) {
+        coset c = line_coset(n, cur_log);
+        uint32_t plog = 0;
+        while (((size_t)1 << plog) < proof->n_last_layer_poly) plog++;
+        if (((size_t)1 << plog) != proof->n_last_layer_poly) {
+            good = 0;
+        } else {
+            const qm31* coeffs = (const qm31*)proof->last_layer_poly;
+            for (size_t i = 0; i < nlq && good; i++) {
+                uint32_t x = coset_at(c, brev(lq[i], cur_log)).x;
+                if (!qm_eq(layer_evals[i], line_poly_eval(coeffs, plog, x))) good = 0; /* LastLayerEvaluationsInvalid */
+            }
+        }
+    }
+    free(layer_evals);
+    free(lq);
+    free(q);
+    *ok = (rc == FO_OK) && good;
+    return rc;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * proof housekeeping + canonical wire image
+ * ---------------------------------------------------------------------------------------------- */
+static void layer_free(fo_layer_proof* lp) {
+    free(lp->fri_witness);
+    free(lp->hash_witness);
+    free(lp->column_witness);
+}
+void fo_proof_free(fo_proof* p) {
+    if (!p) return;
+    layer_free(&p->first_layer);
+    for (size_t i = 0; i < p->n_inner_layers; i++) layer_free(&p->inner_layers[i]);
+    free(p->inner_layers);
+    free(p->last_layer_poly);
+    free(p->evaluations);
+    free(p);
+}
+static void* dup_mem(const void* src, size_t n) {
+    void* d = malloc(n ? n : 1);
+    if (n) memcpy(d, src, n);
+    return d;
+}
+static void layer_clone(fo_layer_proof* d, const fo_layer_proof* s) {
+    *d = *s;
+    d->fri_witness = (uint32_t*)dup_mem(s->fri_witness, 16 * s->n_fri_witness);
+    d->hash_witness = (uint8_t*)dup_mem(s->hash_witness, 32 * s->n_hash_witness);
+    d->column_witness = (uint32_t*)dup_mem(s->column_witness, 4 * s->n_column_witness);
+}
+fo_proof* fo_proof_clone(const fo_proof* p) {
+    fo_proof* c = (fo_proof*)calloc(1, sizeof *c);
+    *c = *p;
+    layer_clone(&c->first_layer, &p->first_layer);
+    c->inner_layers = (fo_layer_proof*)calloc(p->n_inner_layers ? p->n_inner_layers : 1, sizeof(fo_layer_proof));
+    for (size_t i = 0; i < p->n_inner_layers; i++) layer_clone(&c->inner_layers[i], &p->inner_layers[i]);
+    c->last_layer_poly = (uint32_t*)dup_mem(p->last_layer_poly, 16 * p->n_last_layer_poly);
+    c->evaluations = (uint32_t*)dup_mem(p->evaluations, 16 * p->n_evaluations);
+    return c;
+}
+
+static void ser_u32(bytebuf* b, uint32_t v) {
+    uint8_t t[4];
+    st32(t, v);
+    bb_push(b, t, 4);
+}
+static void ser_words(bytebuf* b, const uint32_t* w, size_t n) {
+    for (size_t i = 0; i < n; i++) ser_u32(b, w[i]);
+}
+static void ser_layer(bytebuf* b, const fo_layer_proof* lp) {
+    bb_push(b, lp->commitment, 32);
+    ser_u32(b, (uint32_t)lp->n_fri_witness);
+    ser_words(b, lp->fri_witness, 4 * lp->n_fri_witness);
+    ser_u32(b, (uint32_t)lp->n_hash_witness);
+    bb_push(b, lp->hash_witness, 32 * lp->n_hash_witness);
+    ser_u32(b, (uint32_t)lp->n_column_witness);
+    ser_words(b, lp->column_witness, lp->n_column_witness);
+}
+size_t fo_proof_serialize(const fo_proof* p, uint8_t* buf, size_t cap) {
+    bytebuf b = {0};
+    ser_u32(&b, 0x41445246u); /* "FRDA" */
+    ser_u32(&b, 1);
+    ser_u32(&b, p->pcs_config.pow_bits);
+    ser_u32(&b, p->pcs_config.log_blowup_factor);
+    ser_u32(&b, p->pcs_config.log_last_layer_degree_bound);
+    ser_u32(&b, p->pcs_config.n_queries);
+    ser_u32(&b, p->log_size_bound);
+    ser_u32(&b, (uint32_t)p->proof_of_work);
+    ser_u32(&b, (uint32_t)(p->proof_of_work >> 32));
+    ser_u32(&b, (uint32_t)p->n_evaluations);
+    ser_words(&b, p->evaluations, 4 * p->n_evaluations);
+    ser_layer(&b, &p->first_layer);
+    ser_u32(&b, (uint32_t)p->n_inner_layers);
+    for (size_t i = 0; i < p->n_inner_layers; i++) ser_layer(&b, &p->inner_layers[i]);
+    ser_u32(&b, (uint32_t)p->n_last_layer_poly);
+    ser_words(&b, p->last_layer_poly, 4 * p->n_last_layer_poly);
+    size_t n = b.len;
+    if (buf && cap >= n) memcpy(buf, b.p, n);
+    free(b.p);
+    return n;
+}
