@@ -1,0 +1,254 @@
+#!/usr/bin/env python3
+"""bench.py — FRI-DAS commit/prove throughput on MI355X (BASELINE.json metric).
+
+A "step" is one pass of the hot path over one synthetic blob per GPU: `commit_and_generate_proof`
+(/root/reference/src/proof.rs:32-77, the benches/proof.rs:30-44 workload) on a device-resident blob whose felts
+exactly fill a 2^n domain at log_blowup_factor 4 (default n = 24 = BASELINE.json configs[4], the largest single-GPU
+configuration): unpack -> 4 x circle NTT -> first Merkle tree -> every FRI fold + per-layer Merkle tree -> last-layer
+interpolation -> grind (pow_bits 20) -> 20 query openings.  value = M31 field elements committed per second =
+n_gpus * 4 * 2^n * steps / wall time, inputs already resident in HBM when the timed region starts.
+
+Multi-GPU: one process per GPU (torch.distributed, backend nccl = RCCL), independent blobs sharded one per rank (weak
+scaling); the only collective is an all_gather of the 32-byte commitment roots per step.
+
+The JSON line also carries
+  roofline     — the dominant kernel family (by summed HIP-event time on the kernels' own stream, instrumented replay of
+                 the same K steps): achieved = algorithmic bytes / time against the 8 TB/s HBM peak;
+  cpu_baseline — the CPU oracle (oracle/, a restated port of the reference's single-threaded CPU path) timed on this
+                 host on a bounded sample (rank 0, N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def splitmix64_bytes(seed, n):
+    cnt = (n + 7) // 8
+    z = (np.uint64(seed) + np.uint64(0x9E3779B97F4A7C15) * np.arange(1, cnt + 1, dtype=np.uint64)).astype(np.uint64)
+    z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+    z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+    z = z ^ (z >> np.uint64(31))
+    return z.view(np.uint8)[:n].copy()
+
+
+def blob_len_for(log_domain, log_blowup=4):
+    return (4 << (log_domain - log_blowup)) * 30 // 8
+
+
+def algorithmic_bytes(n, workload, log_blowup=4, log_last=0):
+    """SURVEY.md §8d byte model: every logical stage reads its input once and writes its output once."""
+    N = float(1 << n)
+    enc = 16.0 * N * (1.0 + 2.0 ** (-log_blowup))
+    tree = lambda m: 144.0 * m  # noqa: E731
+    total = enc + tree(N)
+    if workload == "prove":
+        total += 24.0 * N  # fold_circle_into_line
+        m = N / 2
+        last = float(1 << (log_last + log_blowup))
+        while m > last:
+            total += tree(m) + 24.0 * m  # per inner layer: tree + fold_line
+            m /= 2
+    return total
+
+
+def cpu_baseline(sample_log, workload, calls):
+    from oracle import oracle as O
+
+    O.build()
+    data = splitmix64_bytes(100, blob_len_for(sample_log))
+    cfg = O.make_config(20, 4, 0, 20)
+    t0 = time.perf_counter()
+    for _ in range(calls):
+        if workload == "prove":
+            O.commit_and_generate_proof(data, data.size, cfg)
+        else:
+            O.commit(data, 4)
+    dt = time.perf_counter() - t0
+    return {
+        "value": 4.0 * (1 << sample_log) * calls / dt,
+        "unit": "M31 field-elems/s",
+        "cores": 1,
+        "kind": "port",
+        "sample": f"{calls} x {'commit_and_generate_proof' if workload == 'prove' else 'commit'} on a 2^{sample_log} domain "
+        f"(same generator and config as the GPU workload), {dt:.1f} s of single-thread CPU on a {os.cpu_count()}-core host; "
+        "restated CPU path (oracle/), not the upstream Rust binary",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--log-domain", type=int, default=24)
+    ap.add_argument("--workload", choices=["prove", "commit"], default="prove")
+    ap.add_argument("--cpu-sample-log", type=int, default=22)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-twiddle-cache", action="store_true", help="regenerate twiddles every call, as the reference does")
+    args = ap.parse_args()
+
+    import torch
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    import frieda_amd
+
+    n = args.log_domain
+    blob_len = blob_len_for(n)
+    blob = torch.from_numpy(splitmix64_bytes(100 + rank, blob_len)).cuda()
+    stream = torch.cuda.Stream()
+    ctx = frieda_amd.Context(local_rank, stream.cuda_stream)
+    if args.no_twiddle_cache:
+        ctx.set_twiddle_cache(False)
+    cfg = frieda_amd.PcsConfig(frieda_amd.FriConfig(4, 0, 20), 20)  # benches/proof.rs:5-12
+    seed = blob_len  # benches/proof.rs:23: Some(data.len())
+    roots_dev = torch.zeros(32, dtype=torch.uint8, device="cuda")
+    gathered = torch.zeros(32 * world, dtype=torch.uint8, device="cuda")
+
+    def step():
+        if args.workload == "prove":
+            root, proof = ctx.commit_and_generate_proof_device(blob.data_ptr(), blob_len, seed, cfg)
+            if world > 1:
+                roots_dev.copy_(torch.frombuffer(bytearray(root), dtype=torch.uint8))
+            return root, proof
+        ctx.commit_device(blob.data_ptr(), blob_len, 4, roots_dev.data_ptr())
+        if world > 1:
+            ctx.synchronize()
+        return None, None
+
+    def gather_roots():
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, roots_dev)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    torch.cuda.synchronize()
+    last = (None, None)
+    for _ in range(args.warmup):
+        last = step()
+        gather_roots()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        last = step()
+        gather_roots()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # correctness gate on what was just timed: the proof verifies and its first root equals commit()'s
+    if args.workload == "prove":
+        root, proof = last
+        assert frieda_amd.verify(proof, seed), "timed proof does not verify"
+        ctx.commit_device(blob.data_ptr(), blob_len, 4, roots_dev.data_ptr())
+        ctx.synchronize()
+        assert bytes(roots_dev.cpu().numpy()) == root, "first FRI root != commit() root"
+    else:
+        ctx.synchronize()
+        root = bytes(roots_dev.cpu().numpy())
+
+    elems = 4.0 * (1 << n)
+    value = world * elems * args.steps / dt
+
+    # ---- instrumented replay: per-kernel HIP-event durations on the kernels' own stream ----
+    ctx.set_kernel_timing(True)
+    for _ in range(args.steps):
+        step()
+    kern = ctx.kernel_timing_report(reset=True)
+    ctx.set_kernel_timing(False)
+    kern.sort(key=lambda k: -k["total_ms"])
+    roofline = None
+    if kern:
+        dom = kern[0]
+        ach = dom["alg_bytes"] / (dom["total_ms"] * 1e-3) / 1e9 if dom["total_ms"] > 0 else 0.0
+        roofline = {
+            "bound": "hbm",
+            "kernel": dom["name"],
+            "achieved": ach,
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": ach / HBM_PEAK_GBS,
+            "traffic": None,
+            "avg_launch_us": 1e3 * dom["total_ms"] / max(dom["launches"], 1),
+            "launches_per_step": dom["launches"] / args.steps,
+            "alg_bytes_per_launch": dom["alg_bytes"] / max(dom["launches"], 1),
+            "measured": "HIP events on the ctx stream, instrumented replay of the timed K steps",
+        }
+    path_bytes = algorithmic_bytes(n, args.workload)
+    gpu_ms = sum(k["total_ms"] for k in kern) / args.steps
+
+    out = {
+        "metric": "M31 field-elems/s committed (NTT+FRI+Merkle)",
+        "value": value,
+        "unit": "M31 field-elems/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": 1e3 * dt / args.steps,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "u32",
+        "data": "synthetic",
+        "config": {
+            "workload": f"commit_and_generate_proof, 2^{n} domain" if args.workload == "prove" else f"commit, 2^{n} domain",
+            "log_domain": n,
+            "log_blowup_factor": 4,
+            "blob_bytes": blob_len,
+            "pcs_config": {"pow_bits": 20, "log_last_layer_degree_bound": 0, "n_queries": 20},
+            "parallelism": f"{world} independent blobs, one per GPU; all_gather of 32-byte roots",
+            "twiddles": "regenerated per call" if args.no_twiddle_cache else "cached per context",
+        },
+        "roofline": roofline,
+        "path": {
+            "algorithmic_bytes_per_step": path_bytes,
+            "achieved_GBps_wall": path_bytes / (dt / args.steps) / 1e9,
+            "frac_of_hbm_peak_wall": path_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS,
+            "gpu_kernel_ms_per_step": gpu_ms,
+            "frac_of_hbm_peak_kernels": (path_bytes / (gpu_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if gpu_ms > 0 else None,
+            "kernels": [
+                {"name": k["name"], "ms_per_step": k["total_ms"] / args.steps, "launches_per_step": k["launches"] / args.steps} for k in kern
+            ],
+        },
+        "root": root.hex() if root else None,
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args.cpu_sample_log, args.workload, 2 if args.cpu_sample_log <= 22 else 1)
+    elif rank == 0:
+        out["cpu_baseline"] = None
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

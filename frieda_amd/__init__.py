@@ -1,0 +1,32 @@
+"""frieda_amd — MI355X-native FRI-DAS commit / prove hot path behind frieda's commit()/generate_proof()/verify() API.
+
+The package holds only what that path needs: `csrc/` (hand-written gfx950 kernels + the C-ABI host runtime,
+built into `lib/libfrieda_hip.so`) and this thin host-side mirror of the reference interface.
+"""
+from .api import (  # noqa: F401
+    Context,
+    FriConfig,
+    FriedaError,
+    FriedaPanic,
+    PcsConfig,
+    Proof,
+    commit,
+    commit_and_generate_proof,
+    default_context,
+    generate_proof,
+    verify,
+)
+
+__all__ = [
+    "Context",
+    "FriConfig",
+    "FriedaError",
+    "FriedaPanic",
+    "PcsConfig",
+    "Proof",
+    "commit",
+    "commit_and_generate_proof",
+    "default_context",
+    "generate_proof",
+    "verify",
+]

@@ -1,0 +1,271 @@
+"""Host-side mirror of frieda's public API over the C ABI (include/frieda_hip.h).
+
+Same names, argument meaning and error behaviour as /root/reference/src/lib.rs:22-44:
+
+    commit(data, log_blowup_factor) -> bytes[32]
+    generate_proof(data, seed, pcs_config) -> Proof
+    commit_and_generate_proof(data, seed, pcs_config) -> (bytes[32], Proof)      (src/proof.rs:32)
+    verify(proof, seed) -> bool
+
+Where the reference panics (assert!/unwrap, e.g. src/proof.rs:166-173) `FriedaPanic` is raised; verifier
+rejections return False.  Every call runs on the MI355X through libfrieda_hip.so; there is no CPU path.
+"""
+import ctypes as C
+import threading
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import _lib
+
+
+class FriedaError(RuntimeError):
+    def __init__(self, status, detail=""):
+        self.status = status
+        msg = _lib.lib().frieda_status_string(status).decode()
+        super().__init__(f"frieda_hip status {status} ({msg}){': ' + detail if detail else ''}")
+
+
+class FriedaPanic(FriedaError):
+    """The reference implementation panics on this input (FRIEDA_ERR_INVARIANT)."""
+
+
+def _check(status, ctx=None):
+    if status == _lib.OK:
+        return
+    detail = ""
+    if ctx is not None:
+        detail = _lib.lib().frieda_last_error(ctx).decode(errors="replace")
+    raise (FriedaPanic if status == _lib.ERR_INVARIANT else FriedaError)(status, detail)
+
+
+@dataclass(frozen=True)
+class FriConfig:
+    """stwo FriConfig as constructed at src/proof.rs:110-114."""
+
+    log_blowup_factor: int = 4
+    log_last_layer_degree_bound: int = 0
+    n_queries: int = 20
+
+
+@dataclass(frozen=True)
+class PcsConfig:
+    """stwo PcsConfig as constructed at src/proof.rs:109-116, benches/proof.rs:5-12."""
+
+    fri_config: FriConfig = FriConfig()
+    pow_bits: int = 20
+
+    def _c(self):
+        f = self.fri_config
+        return _lib.PcsConfigC(self.pow_bits, f.log_blowup_factor, f.log_last_layer_degree_bound, f.n_queries)
+
+
+def _seed_ptr(seed):
+    return C.byref(C.c_uint64(seed)) if seed is not None else None
+
+
+def _as_bytes(data):
+    if isinstance(data, np.ndarray):
+        return np.ascontiguousarray(data, dtype=np.uint8)
+    return np.frombuffer(bytes(data), dtype=np.uint8)
+
+
+class Context:
+    """One device + one stream + twiddle cache + workspace (frieda_ctx).  Not thread-safe; use one per GPU/thread."""
+
+    def __init__(self, device=0, stream=None):
+        self._h = C.c_void_p()
+        self._L = _lib.lib()
+        _check(self._L.frieda_ctx_create(device, C.c_void_p(stream) if stream else None, C.byref(self._h)))
+        self.device = device
+
+    def close(self):
+        if self._h:
+            self._L.frieda_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def synchronize(self):
+        _check(self._L.frieda_ctx_synchronize(self._h), self._h)
+
+    def set_twiddle_cache(self, enabled):
+        _check(self._L.frieda_ctx_set_twiddle_cache(self._h, int(bool(enabled))), self._h)
+
+    def set_kernel_timing(self, enabled):
+        _check(self._L.frieda_ctx_set_kernel_timing(self._h, int(bool(enabled))), self._h)
+
+    def kernel_timing_report(self, reset=True):
+        """Per-kernel HIP-event timings accumulated since the last reset: list of dicts."""
+        import json
+
+        n = self._L.frieda_ctx_kernel_timing_report(self._h, None, 0, 0)
+        buf = C.create_string_buffer(n + 16)
+        self._L.frieda_ctx_kernel_timing_report(self._h, buf, n + 16, int(bool(reset)))
+        return json.loads(buf.value.decode())["kernels"]
+
+    # ---- Level A ----
+    def commit(self, data, log_blowup_factor):
+        a = _as_bytes(data)
+        root = (C.c_uint8 * 32)()
+        _check(self._L.frieda_commit(self._h, a.ctypes.data if a.size else None, a.size, log_blowup_factor, root), self._h)
+        return bytes(root)
+
+    def commit_device(self, d_ptr, length, log_blowup_factor, d_root_ptr):
+        """Blob and 32-byte root both in device memory; asynchronous on the context stream."""
+        _check(self._L.frieda_commit_device(self._h, d_ptr, length, log_blowup_factor, d_root_ptr), self._h)
+
+    def commit_and_generate_proof(self, data, seed, pcs_config):
+        a = _as_bytes(data)
+        root = (C.c_uint8 * 32)()
+        out = C.c_void_p()
+        _check(
+            self._L.frieda_commit_and_generate_proof(
+                self._h, a.ctypes.data if a.size else None, a.size, _seed_ptr(seed), pcs_config._c(), root, C.byref(out)
+            ),
+            self._h,
+        )
+        return bytes(root), Proof(out)
+
+    def commit_and_generate_proof_device(self, d_ptr, length, seed, pcs_config):
+        root = (C.c_uint8 * 32)()
+        out = C.c_void_p()
+        _check(
+            self._L.frieda_commit_and_generate_proof_device(self._h, d_ptr, length, _seed_ptr(seed), pcs_config._c(), root, C.byref(out)),
+            self._h,
+        )
+        return bytes(root), Proof(out)
+
+    def generate_proof(self, data, seed, pcs_config):
+        return self.commit_and_generate_proof(data, seed, pcs_config)[1]
+
+
+class Proof:
+    """frieda::proof::Proof (src/proof.rs:19-26).  Fields are public upstream, so they are readable and writable here."""
+
+    def __init__(self, handle):
+        self._h = handle
+        self._L = _lib.lib()
+
+    def __del__(self):
+        try:
+            if self._h:
+                self._L.frieda_proof_free(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def clone(self):
+        out = C.c_void_p()
+        _check(self._L.frieda_proof_clone(self._h, C.byref(out)))
+        return Proof(out)
+
+    @property
+    def proof_of_work(self):
+        return self._L.frieda_proof_proof_of_work(self._h)
+
+    @proof_of_work.setter
+    def proof_of_work(self, v):
+        self._L.frieda_proof_set_proof_of_work(self._h, v)
+
+    @property
+    def pcs_config(self):
+        c = self._L.frieda_proof_pcs_config(self._h)
+        return PcsConfig(FriConfig(c.log_blowup_factor, c.log_last_layer_degree_bound, c.n_queries), c.pow_bits)
+
+    @property
+    def log_size_bound(self):
+        return self._L.frieda_proof_log_size_bound(self._h)
+
+    @property
+    def evaluations(self):
+        """uint32[n, 4] copy of Vec<QM31>."""
+        n = self._L.frieda_proof_n_evaluations(self._h)
+        if n == 0:
+            return np.zeros((0, 4), dtype=np.uint32)
+        p = self._L.frieda_proof_evaluations(self._h)
+        return np.ctypeslib.as_array(p, shape=(n, 4)).copy()
+
+    @evaluations.setter
+    def evaluations(self, arr):
+        arr = np.ascontiguousarray(arr, dtype=np.uint32).reshape(-1, 4)
+        _check(self._L.frieda_proof_resize_evaluations(self._h, arr.shape[0]))
+        if arr.shape[0]:
+            p = self._L.frieda_proof_evaluations(self._h)
+            C.memmove(p, arr.ctypes.data, arr.nbytes)
+
+    @property
+    def n_inner_layers(self):
+        return self._L.frieda_proof_n_inner_layers(self._h)
+
+    def layer(self, i):
+        """Layer 0 = first_layer, 1.. = inner_layers[i-1] -> dict(commitment, fri_witness, hash_witness, column_witness)."""
+        n = C.c_size_t()
+        com = bytes(self._L.frieda_proof_layer_commitment(self._h, i)[:32])
+        p = self._L.frieda_proof_layer_fri_witness(self._h, i, C.byref(n))
+        fw = np.ctypeslib.as_array(p, shape=(n.value, 4)).copy() if n.value else np.zeros((0, 4), np.uint32)
+        p = self._L.frieda_proof_layer_hash_witness(self._h, i, C.byref(n))
+        hw = [bytes(p[32 * j : 32 * j + 32]) for j in range(n.value)]
+        p = self._L.frieda_proof_layer_column_witness(self._h, i, C.byref(n))
+        cw = np.ctypeslib.as_array(p, shape=(n.value,)).copy() if n.value else np.zeros((0,), np.uint32)
+        return {"commitment": com, "fri_witness": fw, "hash_witness": hw, "column_witness": cw}
+
+    @property
+    def commitment(self):
+        return bytes(self._L.frieda_proof_layer_commitment(self._h, 0)[:32])
+
+    @property
+    def last_layer_poly(self):
+        n = C.c_size_t()
+        p = self._L.frieda_proof_last_layer_poly(self._h, C.byref(n))
+        return np.ctypeslib.as_array(p, shape=(n.value, 4)).copy() if n.value else np.zeros((0, 4), np.uint32)
+
+    def serialize(self):
+        n = self._L.frieda_proof_serialize(self._h, None, 0)
+        buf = (C.c_uint8 * n)()
+        self._L.frieda_proof_serialize(self._h, buf, n)
+        return bytes(buf)
+
+    @staticmethod
+    def deserialize(blob):
+        a = np.frombuffer(bytes(blob), dtype=np.uint8)
+        out = C.c_void_p()
+        _check(_lib.lib().frieda_proof_deserialize(a.ctypes.data, a.size, C.byref(out)))
+        return Proof(out)
+
+
+# ---- module-level API with an implicit per-thread default context (frieda's free functions) ----
+_tls = threading.local()
+
+
+def default_context():
+    ctx = getattr(_tls, "ctx", None)
+    if ctx is None:
+        ctx = _tls.ctx = Context(0)
+    return ctx
+
+
+def commit(data, log_blowup_factor):
+    """api::commit (src/lib.rs:31)."""
+    return default_context().commit(data, log_blowup_factor)
+
+
+def generate_proof(data, seed, pcs_config):
+    """api::generate_proof (src/lib.rs:36)."""
+    return default_context().generate_proof(data, seed, pcs_config)
+
+
+def commit_and_generate_proof(data, seed, pcs_config):
+    """proof::commit_and_generate_proof (src/proof.rs:32)."""
+    return default_context().commit_and_generate_proof(data, seed, pcs_config)
+
+
+def verify(proof, seed):
+    """api::verify (src/lib.rs:41): bool; raises FriedaPanic where the reference panics.  Host-only."""
+    ok = C.c_int(0)
+    _check(_lib.lib().frieda_verify(proof._h, _seed_ptr(seed), C.byref(ok)))
+    return bool(ok.value)

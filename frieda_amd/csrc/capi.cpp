@@ -1,0 +1,429 @@
+// capi.cpp — the extern "C" shell of libfrieda_hip.so (declarations and reference citations: include/frieda_hip.h).
+// No exception leaves this file: every entry point catches and maps to a status code.
+#include <string.h>
+
+#include <new>
+
+#include "host.h"
+
+using namespace frieda;
+
+#define FR_GUARD_BEGIN try {
+#define FR_GUARD_END(ctxptr)                                          \
+    }                                                                 \
+    catch (const std::bad_alloc&) {                                   \
+        if (ctxptr) (ctxptr)->c.err = "host allocation failed";       \
+        return FRIEDA_ERR_NOMEM;                                      \
+    }                                                                 \
+    catch (const std::exception& e) {                                 \
+        if (ctxptr) (ctxptr)->c.err = e.what();                       \
+        return FRIEDA_ERR_INVARIANT;                                  \
+    }
+
+extern "C" {
+
+uint32_t frieda_abi_version(void) { return FRIEDA_ABI_VERSION; }
+
+const char* frieda_status_string(int status) {
+    switch (status) {
+        case FRIEDA_OK: return "ok";
+        case FRIEDA_ERR_ARG: return "invalid argument";
+        case FRIEDA_ERR_HIP: return "HIP runtime error";
+        case FRIEDA_ERR_INVARIANT: return "invariant violated (the reference panics here)";
+        case FRIEDA_ERR_NOMEM: return "out of memory";
+        case FRIEDA_ERR_FORMAT: return "malformed proof image";
+        default: return "unknown status";
+    }
+}
+
+const char* frieda_last_error(const frieda_ctx* ctx) { return ctx ? ctx->c.err.c_str() : "null context"; }
+
+int frieda_ctx_create(int device, void* stream, frieda_ctx** out) {
+    if (!out) return FRIEDA_ERR_ARG;
+    *out = nullptr;
+    frieda_ctx* ctx = new (std::nothrow) frieda_ctx();
+    if (!ctx) return FRIEDA_ERR_NOMEM;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || device < 0 || device >= ndev) {
+        delete ctx;
+        return e != hipSuccess ? FRIEDA_ERR_HIP : FRIEDA_ERR_ARG;
+    }
+    ctx->c.device = device;
+    if (hipSetDevice(device) != hipSuccess) {
+        delete ctx;
+        return FRIEDA_ERR_HIP;
+    }
+    if (stream) {
+        ctx->c.stream = reinterpret_cast<hipStream_t>(stream);
+        ctx->c.own_stream = false;
+    } else {
+        if (hipStreamCreateWithFlags(&ctx->c.stream, hipStreamNonBlocking) != hipSuccess) {
+            delete ctx;
+            return FRIEDA_ERR_HIP;
+        }
+        ctx->c.own_stream = true;
+    }
+    *out = ctx;
+    return FRIEDA_OK;
+}
+
+int frieda_ctx_destroy(frieda_ctx* ctx) {
+    if (!ctx) return FRIEDA_ERR_ARG;
+    delete ctx;
+    return FRIEDA_OK;
+}
+
+int frieda_ctx_synchronize(frieda_ctx* ctx) {
+    if (!ctx) return FRIEDA_ERR_ARG;
+    FR_HIP(&ctx->c, hipSetDevice(ctx->c.device));
+    FR_HIP(&ctx->c, hipStreamSynchronize(ctx->c.stream));
+    return FRIEDA_OK;
+}
+
+int frieda_ctx_set_twiddle_cache(frieda_ctx* ctx, int enabled) {
+    if (!ctx) return FRIEDA_ERR_ARG;
+    ctx->c.cache_twiddles = enabled != 0;
+    return FRIEDA_OK;
+}
+
+int frieda_ctx_set_kernel_timing(frieda_ctx* ctx, int enabled) {
+    if (!ctx) return FRIEDA_ERR_ARG;
+    FR_GUARD_BEGIN
+    FR_HIP(&ctx->c, hipSetDevice(ctx->c.device));
+    return ctx->c.set_kernel_timing(enabled != 0);
+    FR_GUARD_END(ctx)
+}
+
+size_t frieda_ctx_kernel_timing_report(frieda_ctx* ctx, char* buf, size_t cap, int reset) {
+    if (!ctx) return 0;
+    try {
+        (void)hipSetDevice(ctx->c.device);
+        std::string r = ctx->c.kernel_timing_report(reset != 0);
+        if (buf && cap > r.size()) memcpy(buf, r.c_str(), r.size() + 1);
+        return r.size() + 1;
+    } catch (...) {
+        return 0;
+    }
+}
+
+// ---- Level A ----
+int frieda_commit(frieda_ctx* ctx, const uint8_t* data, size_t len, uint32_t log_blowup_factor, uint8_t out_root[32]) {
+    if (!ctx || !out_root || (!data && len)) return FRIEDA_ERR_ARG;
+    FR_GUARD_BEGIN
+    return commit_host(&ctx->c, data, len, log_blowup_factor, out_root);
+    FR_GUARD_END(ctx)
+}
+
+int frieda_commit_device(frieda_ctx* ctx, const void* d_data, size_t len, uint32_t log_blowup_factor, void* d_out_root) {
+    if (!ctx || !d_out_root || (!d_data && len)) return FRIEDA_ERR_ARG;
+    FR_GUARD_BEGIN
+    return commit_device(&ctx->c, static_cast<const uint8_t*>(d_data), len, log_blowup_factor, static_cast<uint8_t*>(d_out_root), false);
+    FR_GUARD_END(ctx)
+}
+
+static int prove_common(frieda_ctx* ctx, const void* data, size_t len, bool on_device, const uint64_t* seed, frieda_pcs_config cfg,
+                        uint8_t* out_commitment, frieda_proof** out) {
+    if (!ctx || !out || (!data && len)) return FRIEDA_ERR_ARG;
+    *out = nullptr;
+    FR_GUARD_BEGIN
+    frieda_proof* p = new frieda_proof();
+    uint8_t root[32];
+    int rc = prove(&ctx->c, static_cast<const uint8_t*>(data), len, on_device, seed, cfg, root, p->p);
+    if (rc != FRIEDA_OK) {
+        delete p;
+        return rc;
+    }
+    if (out_commitment) memcpy(out_commitment, root, 32);
+    *out = p;
+    return FRIEDA_OK;
+    FR_GUARD_END(ctx)
+}
+
+int frieda_commit_and_generate_proof(frieda_ctx* ctx, const uint8_t* data, size_t len, const uint64_t* seed, frieda_pcs_config cfg,
+                                     uint8_t out_commitment[32], frieda_proof** out) {
+    return prove_common(ctx, data, len, false, seed, cfg, out_commitment, out);
+}
+int frieda_commit_and_generate_proof_device(frieda_ctx* ctx, const void* d_data, size_t len, const uint64_t* seed,
+                                            frieda_pcs_config cfg, uint8_t out_commitment[32], frieda_proof** out) {
+    return prove_common(ctx, d_data, len, true, seed, cfg, out_commitment, out);
+}
+int frieda_generate_proof(frieda_ctx* ctx, const uint8_t* data, size_t len, const uint64_t* seed, frieda_pcs_config cfg,
+                          frieda_proof** out) {
+    return prove_common(ctx, data, len, false, seed, cfg, nullptr, out);
+}
+
+int frieda_verify(const frieda_proof* proof, const uint64_t* seed, int* ok) {
+    if (!proof || !ok) return FRIEDA_ERR_ARG;
+    frieda_ctx* none = nullptr;
+    FR_GUARD_BEGIN
+    return verify(proof->p, seed, ok);
+    FR_GUARD_END(none)
+}
+
+// ---- Proof accessors ----
+void frieda_proof_free(frieda_proof* p) { delete p; }
+
+int frieda_proof_clone(const frieda_proof* p, frieda_proof** out) {
+    if (!p || !out) return FRIEDA_ERR_ARG;
+    frieda_ctx* none = nullptr;
+    FR_GUARD_BEGIN
+    *out = new frieda_proof(*p);
+    return FRIEDA_OK;
+    FR_GUARD_END(none)
+}
+uint64_t frieda_proof_proof_of_work(const frieda_proof* p) { return p->p.proof_of_work; }
+void frieda_proof_set_proof_of_work(frieda_proof* p, uint64_t nonce) { p->p.proof_of_work = nonce; }
+frieda_pcs_config frieda_proof_pcs_config(const frieda_proof* p) { return p->p.pcs_config; }
+uint32_t frieda_proof_log_size_bound(const frieda_proof* p) { return p->p.log_size_bound; }
+size_t frieda_proof_n_evaluations(const frieda_proof* p) { return p->p.evaluations.size(); }
+uint32_t* frieda_proof_evaluations(frieda_proof* p) { return reinterpret_cast<uint32_t*>(p->p.evaluations.data()); }
+int frieda_proof_resize_evaluations(frieda_proof* p, size_t n) {
+    if (!p) return FRIEDA_ERR_ARG;
+    frieda_ctx* none = nullptr;
+    FR_GUARD_BEGIN
+    p->p.evaluations.resize(n, QM31{0, 0, 0, 0});
+    return FRIEDA_OK;
+    FR_GUARD_END(none)
+}
+size_t frieda_proof_n_inner_layers(const frieda_proof* p) { return p->p.inner_layers.size(); }
+static const LayerProof* layer_of(const frieda_proof* p, size_t layer) {
+    if (layer == 0) return &p->p.first_layer;
+    if (layer - 1 < p->p.inner_layers.size()) return &p->p.inner_layers[layer - 1];
+    return nullptr;
+}
+const uint8_t* frieda_proof_layer_commitment(const frieda_proof* p, size_t layer) {
+    const LayerProof* l = layer_of(p, layer);
+    return l ? l->commitment.data() : nullptr;
+}
+const uint32_t* frieda_proof_layer_fri_witness(const frieda_proof* p, size_t layer, size_t* n_qm31) {
+    const LayerProof* l = layer_of(p, layer);
+    if (n_qm31) *n_qm31 = l ? l->fri_witness.size() : 0;
+    return l ? reinterpret_cast<const uint32_t*>(l->fri_witness.data()) : nullptr;
+}
+const uint8_t* frieda_proof_layer_hash_witness(const frieda_proof* p, size_t layer, size_t* n_hashes) {
+    const LayerProof* l = layer_of(p, layer);
+    if (n_hashes) *n_hashes = l ? l->hash_witness.size() : 0;
+    return l ? reinterpret_cast<const uint8_t*>(l->hash_witness.data()) : nullptr;
+}
+const uint32_t* frieda_proof_layer_column_witness(const frieda_proof* p, size_t layer, size_t* n_m31) {
+    const LayerProof* l = layer_of(p, layer);
+    if (n_m31) *n_m31 = l ? l->column_witness.size() : 0;
+    return l ? l->column_witness.data() : nullptr;
+}
+const uint32_t* frieda_proof_last_layer_poly(const frieda_proof* p, size_t* n_qm31) {
+    if (n_qm31) *n_qm31 = p->p.last_layer_poly.size();
+    return reinterpret_cast<const uint32_t*>(p->p.last_layer_poly.data());
+}
+size_t frieda_proof_serialize(const frieda_proof* p, uint8_t* buf, size_t cap) {
+    if (!p) return 0;
+    try {
+        std::vector<uint8_t> b = serialize_proof(p->p);
+        if (buf && cap >= b.size()) memcpy(buf, b.data(), b.size());
+        return b.size();
+    } catch (...) {
+        return 0;
+    }
+}
+int frieda_proof_deserialize(const uint8_t* buf, size_t len, frieda_proof** out) {
+    if (!buf || !out) return FRIEDA_ERR_ARG;
+    *out = nullptr;
+    frieda_ctx* none = nullptr;
+    FR_GUARD_BEGIN
+    frieda_proof* p = new frieda_proof();
+    if (!deserialize_proof(buf, len, p->p)) {
+        delete p;
+        return FRIEDA_ERR_FORMAT;
+    }
+    *out = p;
+    return FRIEDA_OK;
+    FR_GUARD_END(none)
+}
+
+// ---- Level B ----
+int frieda_dev_alloc(frieda_ctx* ctx, size_t bytes, void** d_out) {
+    if (!ctx || !d_out) return FRIEDA_ERR_ARG;
+    FR_HIP(&ctx->c, hipSetDevice(ctx->c.device));
+    hipError_t e = hipMalloc(d_out, bytes ? bytes : 1);
+    if (e != hipSuccess) {
+        ctx->c.err = std::string("hipMalloc: ") + hipGetErrorString(e);
+        return FRIEDA_ERR_NOMEM;
+    }
+    return FRIEDA_OK;
+}
+int frieda_dev_free(frieda_ctx* ctx, void* d) {
+    if (!ctx) return FRIEDA_ERR_ARG;
+    FR_HIP(&ctx->c, hipSetDevice(ctx->c.device));
+    FR_HIP(&ctx->c, hipStreamSynchronize(ctx->c.stream));
+    FR_HIP(&ctx->c, hipFree(d));
+    return FRIEDA_OK;
+}
+int frieda_dev_upload(frieda_ctx* ctx, void* d_dst, const void* h_src, size_t bytes) {
+    if (!ctx || (bytes && (!d_dst || !h_src))) return FRIEDA_ERR_ARG;
+    FR_HIP(&ctx->c, hipSetDevice(ctx->c.device));
+    if (bytes) FR_HIP(&ctx->c, hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, ctx->c.stream));
+    FR_HIP(&ctx->c, hipStreamSynchronize(ctx->c.stream));
+    return FRIEDA_OK;
+}
+int frieda_dev_download(frieda_ctx* ctx, void* h_dst, const void* d_src, size_t bytes) {
+    if (!ctx || (bytes && (!h_dst || !d_src))) return FRIEDA_ERR_ARG;
+    FR_HIP(&ctx->c, hipSetDevice(ctx->c.device));
+    if (bytes) FR_HIP(&ctx->c, hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->c.stream));
+    FR_HIP(&ctx->c, hipStreamSynchronize(ctx->c.stream));
+    return FRIEDA_OK;
+}
+
+int frieda_codec_shape(size_t len, size_t* n_felts, size_t* n_padded, uint32_t* log_size) {
+    CodecShape s = codec_shape(len);
+    if (n_felts) *n_felts = s.n_felts;
+    if (n_padded) *n_padded = s.n_padded;
+    if (log_size) *log_size = s.log_size;
+    return FRIEDA_OK;
+}
+
+int frieda_unpack30(frieda_ctx* ctx, const void* d_bytes, size_t len, uint32_t* d_coef, size_t n_out) {
+    if (!ctx || !d_coef || (!d_bytes && len)) return FRIEDA_ERR_ARG;
+    if (n_out < (8 * len + 29) / 30) return ctx->c.fail(FRIEDA_ERR_ARG, "n_out smaller than the felt count");
+    FR_HIP(&ctx->c, hipSetDevice(ctx->c.device));
+    k::unpack30(ctx->c.launch(), static_cast<const uint8_t*>(d_bytes), len, d_coef, n_out);
+    FR_HIP(&ctx->c, hipGetLastError());
+    return FRIEDA_OK;
+}
+
+int frieda_precompute_twiddles(frieda_ctx* ctx, uint32_t log_domain, const uint32_t** d_twiddles, const uint32_t** d_inv_twiddles) {
+    if (!ctx || log_domain < 1 || log_domain > FRIEDA_MAX_LOG_DOMAIN) return FRIEDA_ERR_ARG;
+    FR_GUARD_BEGIN
+    FR_HIP(&ctx->c, hipSetDevice(ctx->c.device));
+    TwiddleSet ts;
+    int rc = ctx->c.get_twiddles(log_domain, ts);
+    if (rc) return rc;
+    if (d_twiddles) *d_twiddles = ts.d_tw;
+    if (d_inv_twiddles) *d_inv_twiddles = ts.d_itw;
+    return FRIEDA_OK;
+    FR_GUARD_END(ctx)
+}
+
+int frieda_circle_evaluate(frieda_ctx* ctx, const uint32_t* d_coef, uint32_t ncols, uint32_t log_coef, uint32_t log_domain,
+                           uint32_t* d_out) {
+    if (!ctx || !d_coef || !d_out || ncols == 0 || ncols > 65535) return FRIEDA_ERR_ARG;
+    if (log_domain < 1 || log_domain > FRIEDA_MAX_LOG_DOMAIN || log_coef > log_domain) return FRIEDA_ERR_ARG;
+    FR_GUARD_BEGIN
+    FR_HIP(&ctx->c, hipSetDevice(ctx->c.device));
+    TwiddleSet ts;
+    int rc = ctx->c.get_twiddles(log_domain, ts);
+    if (rc) return rc;
+    k::circle_evaluate(ctx->c.launch(), d_coef, (size_t)1 << log_coef, ncols, log_coef, log_domain, ts.d_tw, ts.ds, d_out,
+                       (size_t)1 << log_domain);
+    FR_HIP(&ctx->c, hipGetLastError());
+    return FRIEDA_OK;
+    FR_GUARD_END(ctx)
+}
+
+int frieda_merkle_commit_layer(frieda_ctx* ctx, uint32_t log_size, const void* d_prev, const uint32_t* const* d_cols, uint32_t ncols,
+                               void* d_out) {
+    if (!ctx || !d_out || log_size > FRIEDA_MAX_LOG_DOMAIN || (ncols && !d_cols) || ncols > 1024) return FRIEDA_ERR_ARG;
+    FR_GUARD_BEGIN
+    FR_HIP(&ctx->c, hipSetDevice(ctx->c.device));
+    hipStream_t s = ctx->c.stream;
+    const size_t n = (size_t)1 << log_size;
+    uint8_t* out = static_cast<uint8_t*>(d_out);
+    const uint8_t* prev = static_cast<const uint8_t*>(d_prev);
+    if (!prev && ncols == 4) {
+        k::merkle_leaf4(ctx->c.launch(), d_cols[0], d_cols[1], d_cols[2], d_cols[3], n, out);
+    } else if (prev && ncols == 0) {
+        k::merkle_node(ctx->c.launch(), prev, n, out);
+    } else {
+        // general shape: the column pointer table goes through the workspace arena
+        int rc = ctx->c.ensure_arena(sizeof(void*) * (ncols ? ncols : 1));
+        if (rc) return rc;
+        if (ncols) FR_HIP(&ctx->c, hipMemcpyAsync(ctx->c.arena, d_cols, sizeof(void*) * ncols, hipMemcpyHostToDevice, s));
+        k::merkle_layer_generic(ctx->c.launch(), prev, reinterpret_cast<const uint32_t* const*>(ctx->c.arena), ncols, n, out);
+        FR_HIP(&ctx->c, hipStreamSynchronize(s));  // d_cols is caller memory; the arena slot is reused by the next call
+    }
+    FR_HIP(&ctx->c, hipGetLastError());
+    return FRIEDA_OK;
+    FR_GUARD_END(ctx)
+}
+
+size_t frieda_merkle_layer_offset(uint32_t log_size, uint32_t layer_log) { return k::merkle_layer_offset(log_size, layer_log); }
+
+int frieda_merkle_commit(frieda_ctx* ctx, const uint32_t* d_cols, uint32_t log_size, void* d_layers) {
+    if (!ctx || !d_cols || !d_layers || log_size > FRIEDA_MAX_LOG_DOMAIN) return FRIEDA_ERR_ARG;
+    FR_HIP(&ctx->c, hipSetDevice(ctx->c.device));
+    const size_t n = (size_t)1 << log_size;
+    k::merkle_tree4(ctx->c.launch(), d_cols, d_cols + n, d_cols + 2 * n, d_cols + 3 * n, log_size, static_cast<uint8_t*>(d_layers));
+    FR_HIP(&ctx->c, hipGetLastError());
+    return FRIEDA_OK;
+}
+
+int frieda_merkle_root(frieda_ctx* ctx, const uint32_t* d_cols, uint32_t log_size, void* d_root) {
+    if (!ctx || !d_cols || !d_root || log_size > FRIEDA_MAX_LOG_DOMAIN) return FRIEDA_ERR_ARG;
+    FR_GUARD_BEGIN
+    FR_HIP(&ctx->c, hipSetDevice(ctx->c.device));
+    int rc = ctx->c.ensure_arena(k::merkle_root_scratch_bytes(log_size));
+    if (rc) return rc;
+    const size_t n = (size_t)1 << log_size;
+    k::merkle_root4(ctx->c.launch(), d_cols, d_cols + n, d_cols + 2 * n, d_cols + 3 * n, log_size, ctx->c.arena, static_cast<uint8_t*>(d_root));
+    FR_HIP(&ctx->c, hipGetLastError());
+    return FRIEDA_OK;
+    FR_GUARD_END(ctx)
+}
+
+int frieda_fold_circle_into_line(frieda_ctx* ctx, uint32_t* d_dst, const uint32_t* d_src, uint32_t log_domain, const uint32_t alpha[4]) {
+    if (!ctx || !d_dst || !d_src || !alpha || log_domain < 1 || log_domain > FRIEDA_MAX_LOG_DOMAIN) return FRIEDA_ERR_ARG;
+    FR_GUARD_BEGIN
+    FR_HIP(&ctx->c, hipSetDevice(ctx->c.device));
+    TwiddleSet ts;
+    int rc = ctx->c.get_twiddles(log_domain, ts);
+    if (rc) return rc;
+    k::fold_circle_into_line(ctx->c.launch(), d_dst, (size_t)1 << (log_domain - 1), d_src, (size_t)1 << log_domain, log_domain, ts.d_itw,
+                             ts.ds, k::Alpha{{alpha[0], alpha[1], alpha[2], alpha[3]}});
+    FR_HIP(&ctx->c, hipGetLastError());
+    return FRIEDA_OK;
+    FR_GUARD_END(ctx)
+}
+
+int frieda_fold_line(frieda_ctx* ctx, const uint32_t* d_src, uint32_t line_log, uint32_t log_domain, const uint32_t alpha[4],
+                     uint32_t* d_dst) {
+    if (!ctx || !d_dst || !d_src || !alpha || line_log < 1 || log_domain < 2 || line_log > log_domain - 1 ||
+        log_domain > FRIEDA_MAX_LOG_DOMAIN)
+        return FRIEDA_ERR_ARG;
+    FR_GUARD_BEGIN
+    FR_HIP(&ctx->c, hipSetDevice(ctx->c.device));
+    TwiddleSet ts;
+    int rc = ctx->c.get_twiddles(log_domain, ts);
+    if (rc) return rc;
+    k::fold_line(ctx->c.launch(), d_src, (size_t)1 << line_log, line_log, log_domain, ts.d_itw, ts.ds,
+                 k::Alpha{{alpha[0], alpha[1], alpha[2], alpha[3]}}, d_dst, (size_t)1 << (line_log - 1));
+    FR_HIP(&ctx->c, hipGetLastError());
+    return FRIEDA_OK;
+    FR_GUARD_END(ctx)
+}
+
+int frieda_grind(frieda_ctx* ctx, const uint8_t digest[32], uint32_t pow_bits, uint64_t* nonce) {
+    if (!ctx || !digest || !nonce || pow_bits > 48) return FRIEDA_ERR_ARG;
+    FR_GUARD_BEGIN
+    FR_HIP(&ctx->c, hipSetDevice(ctx->c.device));
+    int rc = ctx->c.ensure_arena(256);
+    if (rc) return rc;
+    hipStream_t s = ctx->c.stream;
+    uint32_t dw[8];
+    for (int i = 0; i < 8; i++)
+        dw[i] = (uint32_t)digest[4 * i] | ((uint32_t)digest[4 * i + 1] << 8) | ((uint32_t)digest[4 * i + 2] << 16) | ((uint32_t)digest[4 * i + 3] << 24);
+    unsigned long long* d_res = reinterpret_cast<unsigned long long*>(ctx->c.arena);
+    FR_HIP(&ctx->c, hipMemsetAsync(d_res, 0xFF, 8, s));
+    uint64_t base = 0, chunk = (uint64_t)1 << 22, found = ~0ull;
+    for (;;) {
+        k::grind_scan(ctx->c.launch(), dw, pow_bits, base, chunk, d_res);
+        FR_HIP(&ctx->c, hipMemcpyAsync(&found, d_res, 8, hipMemcpyDeviceToHost, s));
+        FR_HIP(&ctx->c, hipStreamSynchronize(s));
+        if (found != ~0ull) break;
+        base += chunk;
+        if (chunk < ((uint64_t)1 << 28)) chunk <<= 1;
+    }
+    *nonce = found;
+    return FRIEDA_OK;
+    FR_GUARD_END(ctx)
+}
+
+}  // extern "C"

@@ -1,0 +1,95 @@
+// codec.hip — byte stream -> M31 coefficient unpacker (gfx950).
+//
+// Replaces `bytes_to_felt_le` + the zero padding of `polynomial_from_bytes`
+// (/root/reference/src/utils.rs:10-24): the input is an LSB-first bit stream cut into 30-bit chunks,
+// the last chunk zero-extended, then zeros up to the padded power-of-two length.
+//
+// Layout: four felts are exactly 120 bits = 15 bytes, so thread t owns bytes [15t, 15t+15) and writes
+// felts 4t..4t+3 as one 16-byte store.  It reads the five aligned dwords that cover its 15 bytes (the
+// neighbouring threads' dwords overlap by one, served from L1) and funnel-shifts.  HBM-bound:
+// 3.75 B read + 4 B written per felt.
+#include <hip/hip_runtime.h>
+
+#include "kernels.h"
+
+namespace frieda {
+namespace k {
+
+namespace {
+
+// aligned dword `d` of the byte stream, zero beyond `len`
+__device__ __forceinline__ uint32_t load_dword_guarded(const uint8_t* in, size_t len, size_t d) {
+    size_t b = d * 4;
+    if (b + 4 <= len) return *reinterpret_cast<const uint32_t*>(in + b);
+    uint32_t v = 0;
+    for (int i = 0; i < 4; i++)
+        if (b + i < len) v |= (uint32_t)in[b + i] << (8 * i);
+    return v;
+}
+
+template <int O>  // O = bit offset of the thread's first byte inside its first dword
+__device__ __forceinline__ uint4 extract4(const uint32_t (&w)[5]) {
+    uint32_t f[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int pos = O + 30 * j, q = pos >> 5, r = pos & 31;
+        uint64_t pair = ((uint64_t)w[q + 1] << 32) | w[q];  // q + 1 <= 4 for every (O, j)
+        f[j] = (uint32_t)(pair >> r) & 0x3fffffffu;
+    }
+    return make_uint4(f[0], f[1], f[2], f[3]);
+}
+
+__global__ __launch_bounds__(256) void unpack30_aligned_kernel(const uint8_t* __restrict__ in, size_t len,
+                                                               uint32_t* __restrict__ out, size_t n_quads) {
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_quads) return;
+    size_t byte0 = 15 * t;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (byte0 < len) {
+        size_t d0 = byte0 >> 2;
+        uint32_t w[5];
+#pragma unroll
+        for (int i = 0; i < 5; i++) w[i] = load_dword_guarded(in, len, d0 + i);
+        switch (byte0 & 3) {
+            case 0: v = extract4<0>(w); break;
+            case 1: v = extract4<8>(w); break;
+            case 2: v = extract4<16>(w); break;
+            default: v = extract4<24>(w); break;
+        }
+    }
+    reinterpret_cast<uint4*>(out)[t] = v;
+}
+
+// any alignment: one felt per thread from byte loads
+__global__ __launch_bounds__(256) void unpack30_bytes_kernel(const uint8_t* __restrict__ in, size_t len,
+                                                             uint32_t* __restrict__ out, size_t n_out) {
+    size_t kf = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (kf >= n_out) return;
+    size_t bit0 = 30 * kf, byte0 = bit0 >> 3;
+    uint32_t sh = (uint32_t)(bit0 & 7);
+    uint64_t acc = 0;
+    for (int i = 0; i < 5; i++)
+        if (byte0 + i < len) acc |= (uint64_t)in[byte0 + i] << (8 * i);
+    out[kf] = (uint32_t)(acc >> sh) & 0x3fffffffu;
+}
+
+}  // namespace
+
+void unpack30(const Launch& L, const uint8_t* d_bytes, size_t len, uint32_t* d_out, size_t n_out) {
+    if (n_out == 0) return;
+    hipStream_t s = L.stream;
+    Scope scope(L, "unpack30", (double)len + 4.0 * (double)n_out);
+    bool aligned = ((reinterpret_cast<uintptr_t>(d_bytes) & 3) == 0) && ((reinterpret_cast<uintptr_t>(d_out) & 15) == 0) &&
+                   (n_out % 4 == 0);
+    if (aligned) {
+        size_t quads = n_out / 4;
+        unsigned grid = (unsigned)((quads + 255) / 256);
+        unpack30_aligned_kernel<<<grid, 256, 0, s>>>(d_bytes, len, d_out, quads);
+    } else {
+        unsigned grid = (unsigned)((n_out + 255) / 256);
+        unpack30_bytes_kernel<<<grid, 256, 0, s>>>(d_bytes, len, d_out, n_out);
+    }
+}
+
+}  // namespace k
+}  // namespace frieda

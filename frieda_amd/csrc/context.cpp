@@ -1,0 +1,227 @@
+// context.cpp — device context: stream, workspace arena, per-domain twiddle cache; host circle-group helpers.
+#include <string.h>
+
+#include <cstdio>
+
+#include "host.h"
+
+namespace frieda {
+
+// ---- circle group on the host ------------------------------------------------------------------
+static constexpr uint32_t IDX_MASK = 0x7fffffffu;
+
+CPoint point_from_index(uint32_t index) {
+    // CirclePointIndex::to_point: scalar multiple of the order-2^31 generator
+    CPoint res{1, 0}, cur{CIRCLE_GEN_X, CIRCLE_GEN_Y};
+    index &= IDX_MASK;
+    while (index) {
+        if (index & 1u) res = cp_add(res, cur);
+        cur = cp_double(cur);
+        index >>= 1;
+    }
+    return res;
+}
+
+Coset Coset::half_odds(uint32_t log_size) {
+    // Coset::new(subgroup_gen(log_size + 2), log_size); subgroup_gen(k) = 2^(31-k)
+    Coset c;
+    c.initial = 1u << (31 - (log_size + 2));
+    c.step = log_size == 0 ? 0u : (1u << (31 - log_size));
+    c.log_size = log_size;
+    return c;
+}
+Coset Coset::doubled() const { return Coset{(initial * 2u) & IDX_MASK, (step * 2u) & IDX_MASK, log_size - 1}; }
+uint32_t Coset::index_at(uint32_t i) const { return (initial + (uint32_t)((uint64_t)step * i)) & IDX_MASK; }
+CPoint Coset::at(uint32_t i) const { return point_from_index(index_at(i)); }
+
+Coset line_coset(uint32_t n, uint32_t m) {
+    Coset c = Coset::half_odds(n - 1);
+    while (c.log_size > m) c = c.doubled();
+    return c;
+}
+
+CodecShape codec_shape(size_t len) {
+    // src/utils.rs:10-33.  F = ceil(8 len / 30); F' = 2^max(ceil(log2 F), 2) (the reference computes the
+    // exponent in f64; identical for every F < 2^52); L = log2(F') - 2.
+    CodecShape s;
+    s.n_felts = (8 * len + 29) / 30;
+    uint32_t e = 2;
+    while (((size_t)1 << e) < s.n_felts) e++;
+    s.n_padded = (size_t)1 << e;
+    s.log_size = e - 2;
+    return s;
+}
+
+// ---- kernel timer ------------------------------------------------------------------------------
+struct KernelTimerImpl {
+    struct Span {
+        const char* name;
+        double alg_bytes;
+        hipEvent_t start, stop;
+    };
+    std::vector<Span> spans;
+    std::vector<hipEvent_t> pool;
+    size_t used = 0;
+    hipEvent_t next() {
+        if (used == pool.size()) {
+            hipEvent_t e;
+            (void)hipEventCreate(&e);
+            pool.push_back(e);
+        }
+        return pool[used++];
+    }
+    ~KernelTimerImpl() {
+        for (auto e : pool) (void)hipEventDestroy(e);
+    }
+};
+
+namespace k {
+void timer_begin(KernelTimer* t, hipStream_t s, const char* name, double alg_bytes) {
+    auto* ti = reinterpret_cast<KernelTimerImpl*>(t);
+    KernelTimerImpl::Span sp{name, alg_bytes, ti->next(), ti->next()};
+    (void)hipEventRecord(sp.start, s);
+    ti->spans.push_back(sp);
+}
+void timer_end(KernelTimer* t, hipStream_t s) {
+    auto* ti = reinterpret_cast<KernelTimerImpl*>(t);
+    (void)hipEventRecord(ti->spans.back().stop, s);
+}
+}  // namespace k
+
+k::Launch Ctx::launch() const { return k::Launch{stream, reinterpret_cast<k::KernelTimer*>(timer)}; }
+
+int Ctx::set_kernel_timing(bool enabled) {
+    if (enabled && !timer) timer = new KernelTimerImpl();
+    if (!enabled && timer) {
+        (void)hipStreamSynchronize(stream);
+        delete timer;
+        timer = nullptr;
+    }
+    return FRIEDA_OK;
+}
+
+std::string Ctx::kernel_timing_report(bool reset) {
+    std::string out = "{\"kernels\": [";
+    if (timer) {
+        (void)hipStreamSynchronize(stream);
+        struct Agg {
+            const char* name;
+            size_t launches;
+            double ms, bytes;
+        };
+        std::vector<Agg> agg;
+        for (auto& sp : timer->spans) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, sp.start, sp.stop) != hipSuccess) continue;
+            Agg* a = nullptr;
+            for (auto& x : agg)
+                if (strcmp(x.name, sp.name) == 0) a = &x;
+            if (!a) {
+                agg.push_back(Agg{sp.name, 0, 0.0, 0.0});
+                a = &agg.back();
+            }
+            a->launches++;
+            a->ms += ms;
+            a->bytes += sp.alg_bytes;
+        }
+        bool first = true;
+        for (auto& a : agg) {
+            char buf[256];
+            snprintf(buf, sizeof buf, "%s{\"name\": \"%s\", \"launches\": %zu, \"total_ms\": %.6f, \"alg_bytes\": %.1f}", first ? "" : ", ",
+                     a.name, a.launches, a.ms, a.bytes);
+            out += buf;
+            first = false;
+        }
+        if (reset) {
+            timer->spans.clear();
+            timer->used = 0;
+        }
+    }
+    out += "]}";
+    return out;
+}
+
+// ---- Ctx ---------------------------------------------------------------------------------------
+int Ctx::fail(int code, const std::string& what) {
+    err = what;
+    return code;
+}
+int Ctx::hip_fail(hipError_t e, const char* what) {
+    err = std::string(what) + ": " + hipGetErrorString(e);
+    return FRIEDA_ERR_HIP;
+}
+
+int Ctx::ensure_arena(size_t bytes) {
+    if (bytes <= arena_bytes) return FRIEDA_OK;
+    if (arena) {
+        FR_HIP(this, hipStreamSynchronize(stream));
+        FR_HIP(this, hipFree(arena));
+        arena = nullptr;
+        arena_bytes = 0;
+    }
+    size_t want = (bytes + ((size_t)1 << 20) - 1) & ~(((size_t)1 << 20) - 1);
+    hipError_t e = hipMalloc((void**)&arena, want);
+    if (e != hipSuccess) {
+        err = std::string("hipMalloc(workspace ") + std::to_string(want) + " B): " + hipGetErrorString(e);
+        return FRIEDA_ERR_NOMEM;
+    }
+    arena_bytes = want;
+    return FRIEDA_OK;
+}
+
+void Ctx::drop_twiddles() {
+    for (auto& kv : twiddles) {
+        if (kv.second.d_tw) (void)hipFree(kv.second.d_tw);
+        if (kv.second.d_itw) (void)hipFree(kv.second.d_itw);
+    }
+    twiddles.clear();
+}
+
+int Ctx::get_twiddles(uint32_t n, TwiddleSet& out) {
+    auto it = twiddles.find(n);
+    if (it != twiddles.end() && cache_twiddles) {
+        out = it->second;
+        return FRIEDA_OK;
+    }
+    TwiddleSet ts;
+    if (it != twiddles.end()) {
+        ts = it->second;  // regenerate into the existing buffers (reference behaviour: recomputed per call)
+    } else {
+        size_t bytes = sizeof(uint32_t) << (n - 1);
+        FR_HIP(this, hipMalloc((void**)&ts.d_tw, bytes));
+        FR_HIP(this, hipMalloc((void**)&ts.d_itw, bytes));
+    }
+    // seeds: initial point of half_odds(n-1) and the step multiples the kernel combines
+    Coset h = Coset::half_odds(n - 1);
+    k::TwiddleSeeds seeds;
+    memset(&seeds, 0, sizeof seeds);
+    seeds.p0 = point_from_index(h.initial);
+    if (n >= 3) {
+        CPoint sp = point_from_index(h.step);
+        for (uint32_t b = 0; b + 2 < n; b++) {
+            seeds.step[b] = sp;
+            sp = cp_double(sp);
+        }
+    }
+    ts.ds.init_x = seeds.p0.x;
+    ts.ds.init_y = seeds.p0.y;
+    ts.ds.inv_init_x = m31_inv(seeds.p0.x);
+    ts.ds.inv_init_y = m31_inv(seeds.p0.y);
+    k::gen_twiddles(launch(), n, seeds, ts.d_tw, ts.d_itw);
+    FR_HIP(this, hipGetLastError());
+    twiddles[n] = ts;
+    out = ts;
+    return FRIEDA_OK;
+}
+
+Ctx::~Ctx() {
+    (void)hipSetDevice(device);
+    if (stream) (void)hipStreamSynchronize(stream);
+    drop_twiddles();
+    delete timer;
+    if (arena) (void)hipFree(arena);
+    if (pinned) (void)hipHostFree(pinned);
+    if (own_stream && stream) (void)hipStreamDestroy(stream);
+}
+
+}  // namespace frieda

@@ -1,0 +1,138 @@
+// host.h — host-side data structures of libfrieda_hip: context, proof container, prover / verifier entry points.
+// C++ mirror of the Rust types frieda exposes (/root/reference/src/proof.rs:19-26, src/lib.rs:22-44); the C ABI in
+// include/frieda_hip.h is a thin shell over these.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <array>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/frieda_hip.h"
+#include "channel.h"
+#include "field.h"
+#include "kernels.h"
+
+namespace frieda {
+
+using Hash32 = std::array<uint8_t, 32>;
+
+// stwo FriLayerProof { fri_witness, decommitment: MerkleDecommitment { hash_witness, column_witness }, commitment }
+struct LayerProof {
+    std::vector<QM31> fri_witness;
+    std::vector<Hash32> hash_witness;
+    std::vector<uint32_t> column_witness;
+    Hash32 commitment{};
+};
+
+// frieda::proof::Proof (src/proof.rs:19-26) with stwo's FriProof flattened in
+struct ProofData {
+    LayerProof first_layer;
+    std::vector<LayerProof> inner_layers;
+    std::vector<QM31> last_layer_poly;  // LinePoly coefficients in stwo's internal (bit-reversed) order
+    uint64_t proof_of_work = 0;
+    frieda_pcs_config pcs_config{};
+    uint32_t log_size_bound = 0;
+    std::vector<QM31> evaluations;
+};
+
+std::vector<uint8_t> serialize_proof(const ProofData& p);
+bool deserialize_proof(const uint8_t* buf, size_t len, ProofData& out);
+
+// ---- circle-group helpers on the host (index arithmetic mod 2^31, stwo core/circle.rs) ----
+struct Coset {
+    uint32_t initial, step, log_size;
+    static Coset half_odds(uint32_t log_size);
+    Coset doubled() const;
+    uint32_t index_at(uint32_t i) const;
+    CPoint at(uint32_t i) const;
+};
+CPoint point_from_index(uint32_t index);
+// coset of the FRI line layer of log size m inside the circle domain of log size n
+Coset line_coset(uint32_t n, uint32_t m);
+
+// shape of polynomial_from_bytes (src/utils.rs:21-33) by integer arithmetic
+struct CodecShape {
+    size_t n_felts, n_padded;
+    uint32_t log_size;  // L: per-column log size
+};
+CodecShape codec_shape(size_t len);
+
+// ---- device context ----
+struct TwiddleSet {
+    uint32_t* d_tw = nullptr;
+    uint32_t* d_itw = nullptr;
+    k::DomainScalars ds{};
+};
+
+// per-kernel HIP-event timer: events are recorded on the ctx stream around each launch; durations are read back
+// (after a stream synchronise) by report()
+struct KernelTimerImpl;
+
+struct Ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    bool cache_twiddles = true;
+    std::map<uint32_t, TwiddleSet> twiddles;
+    uint8_t* arena = nullptr;
+    size_t arena_bytes = 0;
+    void* pinned = nullptr;  // small pinned staging block for D2H of roots / nonces
+    size_t pinned_bytes = 0;
+    std::string err;
+    KernelTimerImpl* timer = nullptr;  // non-null while kernel timing is enabled
+
+    k::Launch launch() const;
+    int set_kernel_timing(bool enabled);
+    std::string kernel_timing_report(bool reset);  // JSON; synchronises the stream
+
+    int fail(int code, const std::string& what);
+    int hip_fail(hipError_t e, const char* what);
+    int ensure_arena(size_t bytes);
+    int get_twiddles(uint32_t n, TwiddleSet& out);
+    void drop_twiddles();
+    ~Ctx();
+};
+
+#define FR_HIP(ctx, expr)                                            \
+    do {                                                             \
+        hipError_t e__ = (expr);                                     \
+        if (e__ != hipSuccess) return (ctx)->hip_fail(e__, #expr);   \
+    } while (0)
+
+// bump allocator over the ctx arena (sizes are planned before ensure_arena)
+struct ArenaPlan {
+    size_t off = 0;
+    size_t take(size_t bytes) {
+        size_t o = off;
+        off = (off + bytes + 255) & ~(size_t)255;
+        return o;
+    }
+};
+
+// ---- prover / verifier ----
+int commit_device(Ctx* ctx, const uint8_t* d_data, size_t len, uint32_t log_blowup, uint8_t* d_root, bool data_in_arena);
+int commit_host(Ctx* ctx, const uint8_t* data, size_t len, uint32_t log_blowup, uint8_t out_root[32]);
+int prove(Ctx* ctx, const uint8_t* data, size_t len, bool data_on_device, const uint64_t* seed, frieda_pcs_config cfg,
+          uint8_t out_commitment[32], ProofData& out);
+// returns FRIEDA_OK with *ok set, or FRIEDA_ERR_INVARIANT where the reference panics
+int verify(const ProofData& proof, const uint64_t* seed, int* ok);
+
+// transcript pieces shared by prover and verifier (transcript.cpp)
+void channel_mix_felts(Channel& ch, const std::vector<QM31>& felts);
+std::vector<uint32_t> generate_queries(Channel& ch, uint32_t log_domain_size, uint32_t n_queries);
+std::vector<uint32_t> fold_queries(const std::vector<uint32_t>& q, uint32_t n_folds);
+
+// host Merkle node hash (verifier)
+Hash32 hash_node_host(const uint8_t* left, const uint8_t* right, const uint32_t* values, size_t n_values);
+
+}  // namespace frieda
+
+struct frieda_ctx {
+    frieda::Ctx c;
+};
+struct frieda_proof {
+    frieda::ProofData p;
+};

@@ -1,0 +1,101 @@
+// kernels.h — host-side launchers of the gfx950 kernels (one translation unit per kernel family).
+// Every launcher is asynchronous on the given stream and performs no allocation or synchronisation.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "field.h"
+
+namespace frieda {
+namespace k {
+
+// offset of line-twiddle level `lv` in a twiddle table for a circle domain of log size n
+inline size_t tw_level_offset(uint32_t n, uint32_t lv) { return ((size_t)1 << (n - 1)) - ((size_t)1 << (n - 1 - lv)); }
+__device__ __forceinline__ size_t tw_level_offset_dev(uint32_t n, uint32_t lv) {
+    return ((size_t)1 << (n - 1)) - ((size_t)1 << (n - 1 - lv));
+}
+
+// Launch context: the stream plus an optional per-kernel timer (HIP events recorded on that same stream around
+// every launch; off unless frieda_ctx_set_kernel_timing enabled it).  alg_bytes = the algorithmic (compulsory)
+// HBM bytes of the launch by the byte model of SURVEY.md §8d / DESIGN.md §5.
+struct KernelTimer;
+struct Launch {
+    hipStream_t stream;
+    KernelTimer* timer;
+};
+void timer_begin(KernelTimer* t, hipStream_t s, const char* name, double alg_bytes);
+void timer_end(KernelTimer* t, hipStream_t s);
+struct Scope {
+    const Launch& l;
+    Scope(const Launch& l_, const char* name, double alg_bytes) : l(l_) {
+        if (l.timer) timer_begin(l.timer, l.stream, name, alg_bytes);
+    }
+    ~Scope() {
+        if (l.timer) timer_end(l.timer, l.stream);
+    }
+};
+
+// scalars describing the domain that the tiny-domain (n < 3) paths need in place of table lookups
+struct DomainScalars {
+    uint32_t init_x, init_y;          // half_odds(n-1).initial point
+    uint32_t inv_init_x, inv_init_y;  // their inverses
+};
+
+// ---- codec.hip ----
+// src/utils.rs:10-33: bytes -> 30-bit felts, zero padded up to n_out (multiple of 4)
+void unpack30(const Launch& L, const uint8_t* d_bytes, size_t len, uint32_t* d_out, size_t n_out);
+
+// ---- twiddle.hip ----
+struct TwiddleSeeds {
+    CPoint p0;        // point(initial index of half_odds(n-1))
+    CPoint step[32];  // point(step << k)
+};
+// fills d_tw / d_itw (2^(n-1) words each) for the circle domain of log size n >= 1
+void gen_twiddles(const Launch& L, uint32_t n, const TwiddleSeeds& seeds, uint32_t* d_tw, uint32_t* d_itw);
+
+// ---- ntt.hip ----
+// d_coef[ncols][coef_stride] (2^L live words per column) -> d_out[ncols][out_stride] (2^n per column)
+void circle_evaluate(const Launch& L_, const uint32_t* d_coef, size_t coef_stride, uint32_t ncols, uint32_t L, uint32_t n,
+                     const uint32_t* d_tw, DomainScalars ds, uint32_t* d_out, size_t out_stride);
+
+// ---- merkle.hip ----
+// leaves of 4 SoA columns: out[i] = H(c0[i], c1[i], c2[i], c3[i], 0 x 12)
+void merkle_leaf4(const Launch& L, const uint32_t* c0, const uint32_t* c1, const uint32_t* c2, const uint32_t* c3, size_t n,
+                  uint8_t* d_out);
+// inner nodes without column values: out[i] = H(prev[2i] || prev[2i+1])
+void merkle_node(const Launch& L, const uint8_t* d_prev, size_t n, uint8_t* d_out);
+// general commit_on_layer (any ncols, optional prev); d_col_ptrs is a device array of ncols column pointers
+void merkle_layer_generic(const Launch& L, const uint8_t* d_prev, const uint32_t* const* d_col_ptrs, uint32_t ncols, size_t n,
+                          uint8_t* d_out);
+// all layers of a tree over 4 columns of 2^m (leaves-first layout as frieda_merkle_layer_offset)
+void merkle_tree4(const Launch& L, const uint32_t* c0, const uint32_t* c1, const uint32_t* c2, const uint32_t* c3, uint32_t m,
+                  uint8_t* d_layers);
+// root only; d_scratch must hold merkle_root_scratch_bytes(m)
+size_t merkle_root_scratch_bytes(uint32_t m);
+void merkle_root4(const Launch& L, const uint32_t* c0, const uint32_t* c1, const uint32_t* c2, const uint32_t* c3, uint32_t m,
+                  uint8_t* d_scratch, uint8_t* d_root);
+inline size_t merkle_layer_offset(uint32_t log_size, uint32_t layer_log) {
+    // leaves first: sum_{l = layer_log+1 .. log_size} 32 * 2^l
+    return ((size_t)64 << log_size) - ((size_t)64 << layer_log);
+}
+
+// ---- fri.hip ----
+struct Alpha {
+    uint32_t v[4];
+};
+// dst[4][N/2] = dst * alpha^2 + (f0 + alpha f1); src[4][N]
+void fold_circle_into_line(const Launch& L, uint32_t* d_dst, size_t dst_stride, const uint32_t* d_src, size_t src_stride,
+                           uint32_t n, const uint32_t* d_itw, DomainScalars ds, Alpha alpha);
+// src[4][2^m] on the line domain of log size m inside a circle domain of log size n -> dst[4][2^(m-1)]
+void fold_line(const Launch& L, const uint32_t* d_src, size_t src_stride, uint32_t m, uint32_t n, const uint32_t* d_itw,
+               DomainScalars ds, Alpha alpha, uint32_t* d_dst, size_t dst_stride);
+// out_words[i] = base_words[word_idx[i]];  out_hashes[i] = 32 bytes at base + 32 * hash_idx[i]
+void gather(const Launch& L, const uint32_t* d_base, const uint64_t* d_word_idx, size_t n_words, uint32_t* d_out_words,
+            const uint64_t* d_hash_idx, size_t n_hashes, uint8_t* d_out_hashes);
+// scans nonces [base, base + count) for trailing_zeros(compress(digest, nonce)) >= pow_bits; atomicMin into *d_result
+void grind_scan(const Launch& L, const uint32_t digest[8], uint32_t pow_bits, uint64_t base, uint64_t count,
+                unsigned long long* d_result);
+
+}  // namespace k
+}  // namespace frieda

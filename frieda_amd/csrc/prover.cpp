@@ -1,0 +1,436 @@
+// prover.cpp — commit() and commit_and_generate_proof() on the device.
+//
+// Orchestrates the gfx950 kernels in the order of the reference call stack:
+//   commit   (/root/reference/src/commit.rs:11-22): codec -> twiddles -> 4 x circle FFT -> Merkle root
+//   prove    (/root/reference/src/proof.rs:32-77; stwo core/fri.rs FriProver::{commit, decommit}):
+//            codec -> FFT -> first tree -> [mix root, draw alpha, fold, tree]* -> last layer interpolate ->
+//            grind -> queries -> decommit (one gather launch) -> Proof
+// The blob enters as raw bytes (3.75 B per felt over PCIe) and is unpacked on the device; after that nothing but
+// 32-byte roots, the final 16/32-point layer, the nonce and the gathered openings ever cross PCIe.
+// The Fiat–Shamir channel is evaluated on the host between layers (one 32-byte D2H per layer).
+#include <string.h>
+
+#include <algorithm>
+
+#include "host.h"
+
+namespace frieda {
+
+namespace {
+
+void hash_to_words(const uint8_t* h, uint32_t (&w)[8]) {
+    for (int i = 0; i < 8; i++)
+        w[i] = (uint32_t)h[4 * i] | ((uint32_t)h[4 * i + 1] << 8) | ((uint32_t)h[4 * i + 2] << 16) | ((uint32_t)h[4 * i + 3] << 24);
+}
+
+int ensure_pinned(Ctx* ctx, size_t bytes) {
+    if (ctx->pinned_bytes >= bytes) return FRIEDA_OK;
+    if (ctx->pinned) FR_HIP(ctx, hipHostFree(ctx->pinned));
+    ctx->pinned = nullptr;
+    ctx->pinned_bytes = 0;
+    FR_HIP(ctx, hipHostMalloc(&ctx->pinned, bytes, hipHostMallocDefault));
+    ctx->pinned_bytes = bytes;
+    return FRIEDA_OK;
+}
+
+// validated domain shape shared by commit and prove
+struct Shape {
+    CodecShape cs;
+    uint32_t L, B, n;
+    size_t N;
+};
+
+int make_shape(Ctx* ctx, size_t len, uint32_t B, Shape& sh) {
+    sh.cs = codec_shape(len);
+    sh.L = sh.cs.log_size;
+    sh.B = B;
+    // Coset::half_odds(L + B - 1) panics for L + B == 0 (u32 underflow)
+    if (sh.L + B < 1) return ctx->fail(FRIEDA_ERR_INVARIANT, "log_size + log_blowup_factor must be >= 1");
+    if (sh.L + B > FRIEDA_MAX_LOG_DOMAIN) return ctx->fail(FRIEDA_ERR_ARG, "domain larger than FRIEDA_MAX_LOG_DOMAIN");
+    sh.n = sh.L + B;
+    sh.N = (size_t)1 << sh.n;
+    return FRIEDA_OK;
+}
+
+// LineEvaluation::interpolate for the last FRI layer (stwo core/poly/line.rs), host side: <= 2^14 points.
+// `v`: evaluations in bit-reversed order on LineDomain(c); returns coefficients in LinePoly's internal order.
+void line_interpolate(std::vector<QM31>& v, Coset c) {
+    const uint32_t lg = c.log_size;
+    const size_t n = v.size();
+    for (uint32_t i = 0; i < n; i++) {
+        uint32_t j = bit_reverse(i, lg);
+        if (i < j) std::swap(v[i], v[j]);
+    }
+    for (Coset d = c; d.log_size > 0; d = d.doubled()) {
+        const size_t sz = (size_t)1 << d.log_size, half = sz / 2;
+        std::vector<uint32_t> ix(half);
+        CPoint p = point_from_index(d.initial), st = point_from_index(d.step);
+        for (size_t i = 0; i < half; i++) {
+            ix[i] = m31_inv(p.x);
+            p = cp_add(p, st);
+        }
+        for (size_t base = 0; base < n; base += sz)
+            for (size_t i = 0; i < half; i++) {
+                QM31 a = v[base + i], b = v[base + half + i];
+                v[base + i] = qm_add(a, b);
+                v[base + half + i] = qm_scale(qm_sub(a, b), ix[i]);
+            }
+    }
+    uint32_t len_inv = m31_inv((uint32_t)n);
+    for (auto& q : v) q = qm_scale(q, len_inv);
+}
+
+void bit_reverse_vec(std::vector<QM31>& v, size_t count, uint32_t lg) {
+    for (uint32_t i = 0; i < count; i++) {
+        uint32_t j = bit_reverse(i, lg);
+        if (i < j) std::swap(v[i], v[j]);
+    }
+}
+
+}  // namespace
+
+// -------------------------------------------------------------------------------------------------
+// commit
+// -------------------------------------------------------------------------------------------------
+int commit_device(Ctx* ctx, const uint8_t* d_data, size_t len, uint32_t log_blowup, uint8_t* d_root, bool data_in_arena) {
+    Shape sh;
+    int rc = make_shape(ctx, len, log_blowup, sh);
+    if (rc) return rc;
+    FR_HIP(ctx, hipSetDevice(ctx->device));
+
+    ArenaPlan plan;
+    size_t o_data = plan.take(data_in_arena ? len : 0);
+    size_t o_coef = plan.take(sizeof(uint32_t) * sh.cs.n_padded);
+    size_t o_eval = plan.take(sizeof(uint32_t) * 4 * sh.N);
+    size_t o_scr = plan.take(k::merkle_root_scratch_bytes(sh.n));
+    (void)o_data;
+    if (!data_in_arena) {
+        rc = ctx->ensure_arena(plan.off);
+        if (rc) return rc;
+    } else if (plan.off > ctx->arena_bytes) {
+        return ctx->fail(FRIEDA_ERR_ARG, "internal: arena not sized by caller");
+    }
+    TwiddleSet tw;
+    rc = ctx->get_twiddles(sh.n, tw);
+    if (rc) return rc;
+
+    uint32_t* coef = reinterpret_cast<uint32_t*>(ctx->arena + o_coef);
+    uint32_t* eval = reinterpret_cast<uint32_t*>(ctx->arena + o_eval);
+    k::unpack30(ctx->launch(), d_data, len, coef, sh.cs.n_padded);
+    k::circle_evaluate(ctx->launch(), coef, (size_t)1 << sh.L, 4, sh.L, sh.n, tw.d_tw, tw.ds, eval, sh.N);
+    k::merkle_root4(ctx->launch(), eval, eval + sh.N, eval + 2 * sh.N, eval + 3 * sh.N, sh.n, ctx->arena + o_scr, d_root);
+    FR_HIP(ctx, hipGetLastError());
+    return FRIEDA_OK;
+}
+
+int commit_host(Ctx* ctx, const uint8_t* data, size_t len, uint32_t log_blowup, uint8_t out_root[32]) {
+    Shape sh;
+    int rc = make_shape(ctx, len, log_blowup, sh);
+    if (rc) return rc;
+    FR_HIP(ctx, hipSetDevice(ctx->device));
+    // same plan as commit_device(data_in_arena = true), plus 32 bytes for the root
+    ArenaPlan plan;
+    size_t o_data = plan.take(len);
+    plan.take(sizeof(uint32_t) * sh.cs.n_padded);
+    plan.take(sizeof(uint32_t) * 4 * sh.N);
+    plan.take(k::merkle_root_scratch_bytes(sh.n));
+    size_t o_root = plan.take(32);
+    rc = ctx->ensure_arena(plan.off);
+    if (rc) return rc;
+    rc = ensure_pinned(ctx, 4096);
+    if (rc) return rc;
+    if (len) FR_HIP(ctx, hipMemcpyAsync(ctx->arena + o_data, data, len, hipMemcpyHostToDevice, ctx->stream));
+    rc = commit_device(ctx, ctx->arena + o_data, len, log_blowup, ctx->arena + o_root, true);
+    if (rc) return rc;
+    FR_HIP(ctx, hipMemcpyAsync(ctx->pinned, ctx->arena + o_root, 32, hipMemcpyDeviceToHost, ctx->stream));
+    FR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    memcpy(out_root, ctx->pinned, 32);
+    return FRIEDA_OK;
+}
+
+// -------------------------------------------------------------------------------------------------
+// commit_and_generate_proof
+// -------------------------------------------------------------------------------------------------
+namespace {
+
+struct FriLayerDev {
+    size_t o_vals;   // 4 columns of 2^log words
+    size_t o_tree;   // leaves-first layers
+    uint32_t log;
+};
+
+// Collects the device reads of one layer's decommitment in proof order
+struct GatherPlan {
+    std::vector<uint64_t> word_idx;  // u32 index from the arena base
+    std::vector<uint64_t> hash_idx;  // 32-byte index from the arena base
+};
+
+// compute_decommitment_positions_and_witness_evals (fold_step = 1): positions + requests for the witness values
+std::vector<uint32_t> plan_witness(const std::vector<uint32_t>& queries, const FriLayerDev& lay, GatherPlan& g, size_t& n_witness) {
+    std::vector<uint32_t> pos;
+    n_witness = 0;
+    const size_t stride = (size_t)1 << lay.log;
+    for (size_t i = 0; i < queries.size();) {
+        size_t j = i;
+        while (j < queries.size() && (queries[j] >> 1) == (queries[i] >> 1)) j++;
+        uint32_t start = (queries[i] >> 1) << 1;
+        size_t kq = i;
+        for (uint32_t p = start; p < start + 2; p++) {
+            pos.push_back(p);
+            if (kq < j && queries[kq] == p) {
+                kq++;
+                continue;
+            }
+            for (int c = 0; c < 4; c++) g.word_idx.push_back(lay.o_vals / 4 + (size_t)c * stride + p);
+            n_witness++;
+        }
+        i = j;
+    }
+    return pos;
+}
+
+// MerkleProver::decommit for a tree with its columns on the leaf layer only: requests for the sibling hashes
+size_t plan_merkle_decommit(const std::vector<uint32_t>& positions, const FriLayerDev& lay, GatherPlan& g) {
+    size_t n_hashes = 0;
+    std::vector<uint32_t> last;
+    for (int layer = (int)lay.log; layer >= 0; layer--) {
+        const bool leaf = layer == (int)lay.log;
+        std::vector<uint32_t> cur;
+        const size_t prev_base = leaf ? 0 : (lay.o_tree + k::merkle_layer_offset(lay.log, (uint32_t)layer + 1)) / 32;
+        size_t pi = 0, ci = 0;
+        const size_t n_col = leaf ? positions.size() : 0;
+        while (pi < last.size() || ci < n_col) {
+            uint32_t node;
+            if (pi < last.size() && ci < n_col)
+                node = std::min(last[pi] / 2, positions[ci]);
+            else if (pi < last.size())
+                node = last[pi] / 2;
+            else
+                node = positions[ci];
+            if (!leaf) {
+                if (pi < last.size() && last[pi] == 2 * node)
+                    pi++;
+                else {
+                    g.hash_idx.push_back(prev_base + 2 * (size_t)node);
+                    n_hashes++;
+                }
+                if (pi < last.size() && last[pi] == 2 * node + 1)
+                    pi++;
+                else {
+                    g.hash_idx.push_back(prev_base + 2 * (size_t)node + 1);
+                    n_hashes++;
+                }
+            }
+            if (ci < n_col && positions[ci] == node) ci++;
+            cur.push_back(node);
+        }
+        last.swap(cur);
+    }
+    return n_hashes;
+}
+
+}  // namespace
+
+int prove(Ctx* ctx, const uint8_t* data, size_t len, bool data_on_device, const uint64_t* seed, frieda_pcs_config cfg,
+          uint8_t out_commitment[32], ProofData& out) {
+    const uint32_t B = cfg.log_blowup_factor, last = cfg.log_last_layer_degree_bound;
+    Shape sh;
+    int rc = make_shape(ctx, len, B, sh);
+    if (rc) return rc;
+    // FriProver::commit_last_layer asserts evaluation.len() == last_layer_domain_size: needs L - 1 >= last;
+    // the line domain half_odds(n - 1) needs n >= 2
+    if (sh.n < 2 || sh.L < 1 + last) return ctx->fail(FRIEDA_ERR_INVARIANT, "polynomial too small for the FRI configuration");
+    if (last > 10) return ctx->fail(FRIEDA_ERR_ARG, "log_last_layer_degree_bound > 10");
+    if (cfg.n_queries == 0 || cfg.n_queries > 4096) return ctx->fail(FRIEDA_ERR_ARG, "n_queries out of range");
+    if (cfg.pow_bits > 48) return ctx->fail(FRIEDA_ERR_ARG, "pow_bits > 48");
+    FR_HIP(ctx, hipSetDevice(ctx->device));
+    const uint32_t n = sh.n, last_log = last + B;
+    const size_t N = sh.N;
+    const uint32_t n_inner = (n - 1) - last_log;
+
+    // ---- workspace plan ----
+    ArenaPlan plan;
+    size_t o_data = plan.take(data_on_device ? 0 : len);
+    size_t o_coef = plan.take(sizeof(uint32_t) * sh.cs.n_padded);
+    FriLayerDev first{plan.take(sizeof(uint32_t) * 4 * N), 0, n};
+    first.o_tree = plan.take(k::merkle_layer_offset(n, 0) + 32);
+    std::vector<FriLayerDev> inner(n_inner);
+    for (uint32_t kx = 0; kx < n_inner; kx++) {
+        uint32_t lg = n - 1 - kx;
+        inner[kx].log = lg;
+        inner[kx].o_vals = plan.take(sizeof(uint32_t) * 4 << lg);
+        inner[kx].o_tree = plan.take(k::merkle_layer_offset(lg, 0) + 32);
+    }
+    size_t o_lastv = plan.take(sizeof(uint32_t) * 4 << last_log);
+    size_t o_nonce = plan.take(8);
+    // decommit gather: per layer <= 2 positions per query; hashes <= 2 * queries * log per layer
+    const size_t max_words = (size_t)cfg.n_queries * 4 * (1 + (n_inner + 1));
+    const size_t max_hashes = (size_t)cfg.n_queries * 2 * (size_t)(n + 1) * (n_inner + 1);
+    size_t o_widx = plan.take(8 * max_words), o_hidx = plan.take(8 * max_hashes);
+    size_t o_wout = plan.take(4 * max_words), o_hout = plan.take(32 * max_hashes);
+    rc = ctx->ensure_arena(plan.off);
+    if (rc) return rc;
+    const size_t pinned_need = std::max<size_t>(std::max<size_t>(4096, (sizeof(uint32_t) * 4) << last_log), 4 * max_words + 32 * max_hashes);
+    rc = ensure_pinned(ctx, pinned_need);
+    if (rc) return rc;
+    TwiddleSet tw;
+    rc = ctx->get_twiddles(n, tw);
+    if (rc) return rc;
+    hipStream_t s = ctx->stream;
+    const k::Launch LN = ctx->launch();
+    uint8_t* A = ctx->arena;
+
+    // ---- encode (src/proof.rs:38,44-50) ----
+    const uint8_t* d_data = data;
+    if (!data_on_device) {
+        if (len) FR_HIP(ctx, hipMemcpyAsync(A + o_data, data, len, hipMemcpyHostToDevice, s));
+        d_data = A + o_data;
+    }
+    uint32_t* coef = reinterpret_cast<uint32_t*>(A + o_coef);
+    uint32_t* eval = reinterpret_cast<uint32_t*>(A + first.o_vals);
+    k::unpack30(LN, d_data, len, coef, sh.cs.n_padded);
+    k::circle_evaluate(LN, coef, (size_t)1 << sh.L, 4, sh.L, n, tw.d_tw, tw.ds, eval, N);
+
+    Channel ch;
+    ch.init();
+    if (seed) ch.mix_u64(*seed);  // src/proof.rs:40-42
+
+    auto fetch_root = [&](const FriLayerDev& lay, Hash32& root) -> int {
+        FR_HIP(ctx, hipMemcpyAsync(ctx->pinned, A + lay.o_tree + k::merkle_layer_offset(lay.log, 0), 32, hipMemcpyDeviceToHost, s));
+        FR_HIP(ctx, hipStreamSynchronize(s));
+        memcpy(root.data(), ctx->pinned, 32);
+        return FRIEDA_OK;
+    };
+    auto cols = [&](const FriLayerDev& lay, int c) { return reinterpret_cast<uint32_t*>(A + lay.o_vals) + ((size_t)c << lay.log); };
+
+    // ---- FriProver::commit_first_layer ----
+    k::merkle_tree4(LN, cols(first, 0), cols(first, 1), cols(first, 2), cols(first, 3), n, A + first.o_tree);
+    std::vector<Hash32> roots(1 + n_inner);
+    rc = fetch_root(first, roots[0]);
+    if (rc) return rc;
+    uint32_t rw[8];
+    hash_to_words(roots[0].data(), rw);
+    ch.mix_root(rw);
+
+    // ---- FriProver::commit_inner_layers ----
+    QM31 alpha = ch.draw_felt();
+    {
+        // LineEvaluation::new_zero then fold_circle_into_line
+        uint32_t* dst = (n_inner > 0) ? cols(inner[0], 0) : reinterpret_cast<uint32_t*>(A + o_lastv);
+        FR_HIP(ctx, hipMemsetAsync(dst, 0, sizeof(uint32_t) * 4 << (n - 1), s));
+        k::fold_circle_into_line(LN, dst, (size_t)1 << (n - 1), eval, N, n, tw.d_itw, tw.ds, k::Alpha{{alpha.a, alpha.b, alpha.c, alpha.d}});
+    }
+    for (uint32_t kx = 0; kx < n_inner; kx++) {
+        const FriLayerDev& lay = inner[kx];
+        k::merkle_tree4(LN, cols(lay, 0), cols(lay, 1), cols(lay, 2), cols(lay, 3), lay.log, A + lay.o_tree);
+        rc = fetch_root(lay, roots[kx + 1]);
+        if (rc) return rc;
+        hash_to_words(roots[kx + 1].data(), rw);
+        ch.mix_root(rw);
+        alpha = ch.draw_felt();
+        uint32_t* dst = (kx + 1 < n_inner) ? cols(inner[kx + 1], 0) : reinterpret_cast<uint32_t*>(A + o_lastv);
+        k::fold_line(LN, cols(lay, 0), (size_t)1 << lay.log, lay.log, n, tw.d_itw, tw.ds, k::Alpha{{alpha.a, alpha.b, alpha.c, alpha.d}}, dst,
+                     (size_t)1 << (lay.log - 1));
+    }
+
+    // ---- FriProver::commit_last_layer ----
+    const size_t n_lastdom = (size_t)1 << last_log;
+    FR_HIP(ctx, hipMemcpyAsync(ctx->pinned, A + o_lastv, sizeof(uint32_t) * 4 * n_lastdom, hipMemcpyDeviceToHost, s));
+    FR_HIP(ctx, hipStreamSynchronize(s));
+    std::vector<QM31> lastv(n_lastdom);
+    {
+        const uint32_t* h = reinterpret_cast<const uint32_t*>(ctx->pinned);
+        for (size_t i = 0; i < n_lastdom; i++) lastv[i] = {h[i], h[n_lastdom + i], h[2 * n_lastdom + i], h[3 * n_lastdom + i]};
+    }
+    line_interpolate(lastv, line_coset(n, last_log));
+    bit_reverse_vec(lastv, n_lastdom, last_log);  // into_ordered_coefficients
+    const size_t n_poly = (size_t)1 << last;
+    for (size_t i = n_poly; i < n_lastdom; i++)
+        if (!qm_is_zero(lastv[i])) return ctx->fail(FRIEDA_ERR_INVARIANT, "invalid degree");  // assert! upstream
+    lastv.resize(n_poly);
+    bit_reverse_vec(lastv, n_poly, last);  // LinePoly::from_ordered_coefficients
+    channel_mix_felts(ch, lastv);
+
+    // ---- grind (src/proof.rs:58-59) ----
+    unsigned long long* d_nonce = reinterpret_cast<unsigned long long*>(A + o_nonce);
+    uint64_t nonce = ~0ull;
+    {
+        FR_HIP(ctx, hipMemsetAsync(d_nonce, 0xFF, 8, s));
+        uint64_t base = 0, chunk = (uint64_t)1 << 22;
+        for (;;) {
+            k::grind_scan(LN, ch.digest, cfg.pow_bits, base, chunk, d_nonce);
+            FR_HIP(ctx, hipMemcpyAsync(ctx->pinned, d_nonce, 8, hipMemcpyDeviceToHost, s));
+            FR_HIP(ctx, hipStreamSynchronize(s));
+            memcpy(&nonce, ctx->pinned, 8);
+            if (nonce != ~0ull) break;
+            base += chunk;
+            if (chunk < ((uint64_t)1 << 28)) chunk <<= 1;
+        }
+    }
+    ch.mix_u64(nonce);
+
+    // ---- FriProver::decommit ----
+    std::vector<uint32_t> queries = generate_queries(ch, n, cfg.n_queries);
+    GatherPlan g;
+    // Proof.evaluations (src/proof.rs:62-66)
+    for (uint32_t q : queries)
+        for (int c = 0; c < 4; c++) g.word_idx.push_back(first.o_vals / 4 + (size_t)c * N + q);
+    struct LayerCounts {
+        size_t n_witness, n_hashes;
+    };
+    std::vector<LayerCounts> counts(1 + n_inner);
+    {
+        std::vector<uint32_t> pos = plan_witness(queries, first, g, counts[0].n_witness);
+        counts[0].n_hashes = plan_merkle_decommit(pos, first, g);
+    }
+    std::vector<uint32_t> lq = fold_queries(queries, 1);
+    for (uint32_t kx = 0; kx < n_inner; kx++) {
+        std::vector<uint32_t> pos = plan_witness(lq, inner[kx], g, counts[kx + 1].n_witness);
+        counts[kx + 1].n_hashes = plan_merkle_decommit(pos, inner[kx], g);
+        lq = fold_queries(lq, 1);
+    }
+    if (g.word_idx.size() > max_words || g.hash_idx.size() > max_hashes) return ctx->fail(FRIEDA_ERR_INVARIANT, "internal: gather plan overflow");
+    FR_HIP(ctx, hipMemcpyAsync(A + o_widx, g.word_idx.data(), 8 * g.word_idx.size(), hipMemcpyHostToDevice, s));
+    if (!g.hash_idx.empty()) FR_HIP(ctx, hipMemcpyAsync(A + o_hidx, g.hash_idx.data(), 8 * g.hash_idx.size(), hipMemcpyHostToDevice, s));
+    k::gather(LN, reinterpret_cast<const uint32_t*>(A), reinterpret_cast<const uint64_t*>(A + o_widx), g.word_idx.size(),
+              reinterpret_cast<uint32_t*>(A + o_wout), reinterpret_cast<const uint64_t*>(A + o_hidx), g.hash_idx.size(), A + o_hout);
+    uint8_t* hp = reinterpret_cast<uint8_t*>(ctx->pinned);
+    const size_t wbytes = 4 * g.word_idx.size();
+    FR_HIP(ctx, hipMemcpyAsync(hp, A + o_wout, wbytes, hipMemcpyDeviceToHost, s));
+    if (!g.hash_idx.empty()) FR_HIP(ctx, hipMemcpyAsync(hp + wbytes, A + o_hout, 32 * g.hash_idx.size(), hipMemcpyDeviceToHost, s));
+    FR_HIP(ctx, hipStreamSynchronize(s));
+    FR_HIP(ctx, hipGetLastError());
+
+    // ---- assemble Proof (src/proof.rs:67-76) ----
+    const uint32_t* wv = reinterpret_cast<const uint32_t*>(hp);
+    const uint8_t* hv = hp + wbytes;
+    size_t wi = 0, hi = 0;
+    auto take_qm = [&]() {
+        QM31 q{wv[wi], wv[wi + 1], wv[wi + 2], wv[wi + 3]};
+        wi += 4;
+        return q;
+    };
+    out = ProofData{};
+    out.pcs_config = cfg;
+    out.log_size_bound = sh.L;
+    out.proof_of_work = nonce;
+    out.last_layer_poly = lastv;
+    out.evaluations.resize(queries.size());
+    for (auto& q : out.evaluations) q = take_qm();
+    out.inner_layers.resize(n_inner);
+    for (uint32_t li = 0; li <= n_inner; li++) {
+        LayerProof& lp = li == 0 ? out.first_layer : out.inner_layers[li - 1];
+        lp.commitment = roots[li];
+        lp.fri_witness.resize(counts[li].n_witness);
+        for (auto& q : lp.fri_witness) q = take_qm();
+        lp.hash_witness.resize(counts[li].n_hashes);
+        for (auto& h : lp.hash_witness) {
+            memcpy(h.data(), hv + 32 * hi, 32);
+            hi++;
+        }
+    }
+    memcpy(out_commitment, roots[0].data(), 32);
+    return FRIEDA_OK;
+}
+
+}  // namespace frieda

@@ -1,0 +1,167 @@
+/*
+ * frieda_hip.h — C ABI of the MI355X-native FRI-DAS commit / prove path (libfrieda_hip.so).
+ *
+ * This is the drop-in boundary: the entry points a Rust `extern "C"` block in a frieda fork (Level A) or
+ * an stwo `HipBackend` (Level B) would bind.  Plain pointers and sizes only; no C++/torch types; no
+ * exceptions or unwinding cross it.  Every function returns an int status (FRIEDA_OK == 0).  Where the
+ * reference panics (assert!/unwrap) the status is FRIEDA_ERR_INVARIANT and a Rust shim re-raises with
+ * panic!; verifier rejections are reported through *ok, exactly like the reference's `bool`.
+ *
+ * Reference interfaces replaced (paths under /root/reference):
+ *   Level A  src/lib.rs:31-43  api::{commit, generate_proof, verify}
+ *            src/proof.rs:32-36 commit_and_generate_proof; src/proof.rs:19-26 struct Proof
+ *   Level B  the stwo backend traits frieda instantiates with `CpuBackend`
+ *            (src/commit.rs:15,17; src/proof.rs:47,48,52,58; src/utils.rs:21,28):
+ *            PolyOps::{precompute_twiddles, evaluate}, MerkleOps::commit_on_layer,
+ *            FriOps::{fold_circle_into_line, fold_line}, GrindOps::grind, plus the codec of
+ *            src/utils.rs:10-33.
+ *
+ * Threading: a frieda_ctx owns one device, one stream, its twiddle cache and workspace.  A ctx is not
+ * thread-safe; distinct ctxs are independent (one per GPU / host thread).  No global mutable state.
+ */
+#ifndef FRIEDA_HIP_H
+#define FRIEDA_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FRIEDA_OK 0
+#define FRIEDA_ERR_ARG 1       /* null pointer / size out of the supported range */
+#define FRIEDA_ERR_HIP 2       /* a HIP runtime call failed (see frieda_last_error) */
+#define FRIEDA_ERR_INVARIANT 3 /* the reference would panic here */
+#define FRIEDA_ERR_NOMEM 4
+#define FRIEDA_ERR_FORMAT 5    /* malformed proof image */
+
+#define FRIEDA_ABI_VERSION 1
+#define FRIEDA_MAX_LOG_DOMAIN 28
+
+typedef struct frieda_ctx frieda_ctx;
+typedef struct frieda_proof frieda_proof;
+
+/* stwo PcsConfig { pow_bits, fri_config: FriConfig { log_blowup_factor, log_last_layer_degree_bound,
+ * n_queries } } as passed at src/lib.rs:36, src/proof.rs:109-116, benches/proof.rs:5-12 */
+typedef struct {
+    uint32_t pow_bits;
+    uint32_t log_blowup_factor;
+    uint32_t log_last_layer_degree_bound;
+    uint32_t n_queries;
+} frieda_pcs_config;
+
+uint32_t frieda_abi_version(void);
+const char* frieda_status_string(int status);
+/* detail of the last failure on this ctx (valid until the next call on it) */
+const char* frieda_last_error(const frieda_ctx* ctx);
+
+/* ---- context -------------------------------------------------------------------------------- */
+/* stream: a hipStream_t to run on (e.g. torch's current stream), or NULL to create a private one */
+int frieda_ctx_create(int device, void* stream, frieda_ctx** out);
+int frieda_ctx_destroy(frieda_ctx* ctx);
+int frieda_ctx_synchronize(frieda_ctx* ctx);
+/* twiddle policy: 1 (default) keep the per-domain twiddle tables in the ctx across calls; 0 regenerate
+ * them on every call as the reference does (src/commit.rs:15) */
+int frieda_ctx_set_twiddle_cache(frieda_ctx* ctx, int enabled);
+
+/* measurement aid: when enabled, HIP events are recorded on the ctx stream around every kernel launch.
+ * frieda_ctx_kernel_timing_report synchronises the stream and writes a JSON object
+ * {"kernels": [{"name", "launches", "total_ms", "alg_bytes"}]} (alg_bytes = algorithmic HBM bytes by the byte model
+ * of DESIGN.md §5); returns the bytes needed including the NUL; reset != 0 clears the accumulated spans. */
+int frieda_ctx_set_kernel_timing(frieda_ctx* ctx, int enabled);
+size_t frieda_ctx_kernel_timing_report(frieda_ctx* ctx, char* buf, size_t cap, int reset);
+
+/* ---- Level A: frieda's public API ------------------------------------------------------------- */
+/* api::commit(data, log_blowup_factor) -> [u8; 32]   (src/lib.rs:31, src/commit.rs:11-22) */
+int frieda_commit(frieda_ctx* ctx, const uint8_t* data, size_t len, uint32_t log_blowup_factor, uint8_t out_root[32]);
+/* same with the blob already resident in device memory; the root is written to device memory
+ * (d_out_root, 32 B) asynchronously on the ctx stream — no host synchronisation */
+int frieda_commit_device(frieda_ctx* ctx, const void* d_data, size_t len, uint32_t log_blowup_factor, void* d_out_root);
+
+/* proof::commit_and_generate_proof(data, seed, cfg) -> (Commitment, Proof)   (src/proof.rs:32-77);
+ * seed == NULL is Option::None */
+int frieda_commit_and_generate_proof(frieda_ctx* ctx, const uint8_t* data, size_t len, const uint64_t* seed,
+                                     frieda_pcs_config cfg, uint8_t out_commitment[32], frieda_proof** out);
+int frieda_commit_and_generate_proof_device(frieda_ctx* ctx, const void* d_data, size_t len, const uint64_t* seed,
+                                            frieda_pcs_config cfg, uint8_t out_commitment[32], frieda_proof** out);
+/* api::generate_proof (src/lib.rs:36) */
+int frieda_generate_proof(frieda_ctx* ctx, const uint8_t* data, size_t len, const uint64_t* seed, frieda_pcs_config cfg,
+                          frieda_proof** out);
+/* api::verify(proof, seed) -> bool  (src/lib.rs:41, src/proof.rs:79-101).  Host-only (the reference's
+ * verifier is O(n_queries * log N) hashes).  *ok receives the bool; FRIEDA_ERR_INVARIANT where the
+ * reference panics (src/proof.rs:166-173). */
+int frieda_verify(const frieda_proof* proof, const uint64_t* seed, int* ok);
+
+/* ---- struct Proof (src/proof.rs:19-26) accessors; fields are `pub` upstream, hence the setters --- */
+void frieda_proof_free(frieda_proof* p);
+int frieda_proof_clone(const frieda_proof* p, frieda_proof** out);
+uint64_t frieda_proof_proof_of_work(const frieda_proof* p);
+void frieda_proof_set_proof_of_work(frieda_proof* p, uint64_t nonce);
+frieda_pcs_config frieda_proof_pcs_config(const frieda_proof* p);
+uint32_t frieda_proof_log_size_bound(const frieda_proof* p);
+/* evaluations: Vec<QM31>, 4 little-endian u32 coordinates each; pointer stays valid until the next
+ * resize/free */
+size_t frieda_proof_n_evaluations(const frieda_proof* p);
+uint32_t* frieda_proof_evaluations(frieda_proof* p);
+int frieda_proof_resize_evaluations(frieda_proof* p, size_t n);
+/* FriProof: layer 0 = first_layer, 1..n_inner = inner_layers */
+size_t frieda_proof_n_inner_layers(const frieda_proof* p);
+const uint8_t* frieda_proof_layer_commitment(const frieda_proof* p, size_t layer);
+const uint32_t* frieda_proof_layer_fri_witness(const frieda_proof* p, size_t layer, size_t* n_qm31);
+const uint8_t* frieda_proof_layer_hash_witness(const frieda_proof* p, size_t layer, size_t* n_hashes);
+const uint32_t* frieda_proof_layer_column_witness(const frieda_proof* p, size_t layer, size_t* n_m31);
+const uint32_t* frieda_proof_last_layer_poly(const frieda_proof* p, size_t* n_qm31);
+/* canonical little-endian wire image (layout in DESIGN.md §6).  buf == NULL returns the size needed. */
+size_t frieda_proof_serialize(const frieda_proof* p, uint8_t* buf, size_t cap);
+int frieda_proof_deserialize(const uint8_t* buf, size_t len, frieda_proof** out);
+
+/* ---- Level B: backend-trait granular operations on device buffers ------------------------------- */
+/* Column<T> storage */
+int frieda_dev_alloc(frieda_ctx* ctx, size_t bytes, void** d_out);
+int frieda_dev_free(frieda_ctx* ctx, void* d);
+int frieda_dev_upload(frieda_ctx* ctx, void* d_dst, const void* h_src, size_t bytes);
+int frieda_dev_download(frieda_ctx* ctx, void* h_dst, const void* d_src, size_t bytes);
+
+/* codec, src/utils.rs:10-33: d_bytes[len] -> d_coef[n_out] felts (30-bit LSB-first chunks), zero padded
+ * to n_out words.  frieda_codec_shape gives F (felts), F' (padded) and L (per-column log size). */
+int frieda_codec_shape(size_t len, size_t* n_felts, size_t* n_padded, uint32_t* log_size);
+int frieda_unpack30(frieda_ctx* ctx, const void* d_bytes, size_t len, uint32_t* d_coef, size_t n_out);
+
+/* PolyOps::precompute_twiddles(Coset::half_odds(log_domain - 1)): device tables of 2^(log_domain-1) words
+ * each (levels N/4, N/8, ..., 1, pad 1) owned by the ctx */
+int frieda_precompute_twiddles(frieda_ctx* ctx, uint32_t log_domain, const uint32_t** d_twiddles,
+                               const uint32_t** d_inv_twiddles);
+/* PolyOps::evaluate on CircleDomain of log size log_domain for ncols polynomials of 2^log_coef coefficients
+ * each: d_coef[ncols][2^log_coef] -> d_out[ncols][2^log_domain], bit-reversed order */
+int frieda_circle_evaluate(frieda_ctx* ctx, const uint32_t* d_coef, uint32_t ncols, uint32_t log_coef,
+                           uint32_t log_domain, uint32_t* d_out);
+
+/* MerkleOps::commit_on_layer(log_size, prev_layer, columns): d_prev is NULL or 2^(log_size+1) hashes;
+ * d_cols is a host array of ncols device column pointers (2^log_size words each); d_out gets 2^log_size
+ * 32-byte hashes */
+int frieda_merkle_commit_layer(frieda_ctx* ctx, uint32_t log_size, const void* d_prev, const uint32_t* const* d_cols,
+                               uint32_t ncols, void* d_out);
+/* MerkleProver::commit over 4 equal-length columns d_cols[4][2^log_size]: all layers, leaves first
+ * (layer log_size at offset 0, ..., root last; offsets from frieda_merkle_layer_offset), 32*(2^(log_size+1)-1)
+ * bytes */
+int frieda_merkle_commit(frieda_ctx* ctx, const uint32_t* d_cols, uint32_t log_size, void* d_layers);
+size_t frieda_merkle_layer_offset(uint32_t log_size, uint32_t layer_log);
+/* root only (no layer is stored): the commit() shape */
+int frieda_merkle_root(frieda_ctx* ctx, const uint32_t* d_cols, uint32_t log_size, void* d_root);
+
+/* FriOps::fold_circle_into_line: d_dst[4][N/2] (accumulated: dst*alpha^2 + f') from d_src[4][N] */
+int frieda_fold_circle_into_line(frieda_ctx* ctx, uint32_t* d_dst, const uint32_t* d_src, uint32_t log_domain,
+                                 const uint32_t alpha[4]);
+/* FriOps::fold_line: d_src[4][2^line_log] on the line domain reached from half_odds(log_domain-1) by
+ * doubling -> d_dst[4][2^(line_log-1)] */
+int frieda_fold_line(frieda_ctx* ctx, const uint32_t* d_src, uint32_t line_log, uint32_t log_domain,
+                     const uint32_t alpha[4], uint32_t* d_dst);
+
+/* GrindOps::grind: smallest nonce with trailing_zeros(mix_u64(digest, nonce)) >= pow_bits */
+int frieda_grind(frieda_ctx* ctx, const uint8_t digest[32], uint32_t pow_bits, uint64_t* nonce);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,338 @@
+"""GPU: the HIP path, called through the C ABI, against the oracle on the same seeded inputs — bit-exact.
+
+Level B (one backend operation at a time) first, then Level A (commit / generate_proof / verify), then the
+size-independent properties at BASELINE.json's full sizes where the oracle would take minutes.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import pattern_bytes, splitmix64_bytes
+from util import DevBuf, blob_len_for, load_vectors, resolve_input
+
+pytestmark = pytest.mark.gpu
+
+P = 2**31 - 1
+
+
+def _check(ctx, rc):
+    from frieda_amd.api import _check as chk
+
+    chk(rc, ctx._h)
+
+
+def rand_m31(rng, shape):
+    return rng.integers(0, P, shape, dtype=np.uint32)
+
+
+# ------------------------------------------------------------------------------------------------
+# Level B
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n_bytes", [0, 1, 3, 4, 14, 15, 16, 29, 30, 31, 58, 60, 61, 119, 1000, 1024, 4097, 65536, 262146])
+def test_unpack30(gpu_ctx, oracle, n_bytes):
+    data = splitmix64_bytes(11, n_bytes)
+    coef, L = oracle.polynomial_from_bytes(data)
+    n_out = coef.size
+    d_in = DevBuf.from_array(gpu_ctx, data if n_bytes else np.zeros(4, np.uint8))
+    d_out = DevBuf(gpu_ctx, 4 * n_out)
+    _check(gpu_ctx, gpu_ctx._L.frieda_unpack30(gpu_ctx._h, d_in.ptr, n_bytes, d_out.ptr, n_out))
+    got = d_out.to_array(np.uint32, (n_out,))
+    assert np.array_equal(got, coef.ravel())
+    # shape helper agrees with the reference's f64 rule
+    nf, npad, lg = C.c_size_t(), C.c_size_t(), C.c_uint32()
+    gpu_ctx._L.frieda_codec_shape(n_bytes, C.byref(nf), C.byref(npad), C.byref(lg))
+    assert (npad.value, lg.value) == (n_out, L)
+
+
+def test_unpack30_unaligned_pointer(gpu_ctx, oracle):
+    data = splitmix64_bytes(12, 1001)
+    coef, _ = oracle.polynomial_from_bytes(data[1:])
+    d_in = DevBuf.from_array(gpu_ctx, data)
+    d_out = DevBuf(gpu_ctx, 4 * coef.size)
+    _check(gpu_ctx, gpu_ctx._L.frieda_unpack30(gpu_ctx._h, C.c_void_p(d_in.ptr.value + 1), 1000, d_out.ptr, coef.size))
+    assert np.array_equal(d_out.to_array(np.uint32, (coef.size,)), coef.ravel())
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 4, 5, 8, 11, 14, 17])
+def test_twiddles(gpu_ctx, oracle, n):
+    tw, itw = oracle.precompute_twiddles(n)
+    p_tw, p_itw = C.c_void_p(), C.c_void_p()
+    _check(gpu_ctx, gpu_ctx._L.frieda_precompute_twiddles(gpu_ctx._h, n, C.byref(p_tw), C.byref(p_itw)))
+    got = np.zeros(tw.size, np.uint32)
+    goti = np.zeros(tw.size, np.uint32)
+    _check(gpu_ctx, gpu_ctx._L.frieda_dev_download(gpu_ctx._h, got.ctypes.data, p_tw, got.nbytes))
+    _check(gpu_ctx, gpu_ctx._L.frieda_dev_download(gpu_ctx._h, goti.ctypes.data, p_itw, goti.nbytes))
+    assert np.array_equal(got, tw)
+    assert np.array_equal(goti, itw)
+
+
+@pytest.mark.parametrize(
+    "L,n", [(0, 1), (1, 1), (0, 2), (1, 2), (2, 2), (0, 4), (2, 6), (7, 11), (9, 13), (12, 16), (13, 17), (14, 15), (16, 20), (18, 18), (5, 5)]
+)
+def test_circle_evaluate(gpu_ctx, oracle, L, n):
+    rng = np.random.default_rng(100 + n)
+    ncols = 4 if n < 20 else 2
+    coef = rand_m31(rng, (ncols, 1 << L))
+    exp = oracle.circle_evaluate(coef, n)
+    d_c = DevBuf.from_array(gpu_ctx, coef)
+    d_o = DevBuf(gpu_ctx, 4 * ncols << n)
+    _check(gpu_ctx, gpu_ctx._L.frieda_circle_evaluate(gpu_ctx._h, d_c.ptr, ncols, L, n, d_o.ptr))
+    got = d_o.to_array(np.uint32, (ncols, 1 << n))
+    assert np.array_equal(got, exp)
+
+
+@pytest.mark.parametrize("m", [0, 1, 2, 5, 10, 11, 12, 16])
+def test_merkle_commit_all_layers(gpu_ctx, oracle, m):
+    rng = np.random.default_rng(200 + m)
+    cols = rand_m31(rng, (4, 1 << m))
+    layers = oracle.merkle_commit(cols)
+    d_c = DevBuf.from_array(gpu_ctx, cols)
+    total = 32 * ((2 << m) - 1)
+    d_l = DevBuf(gpu_ctx, total)
+    _check(gpu_ctx, gpu_ctx._L.frieda_merkle_commit(gpu_ctx._h, d_c.ptr, m, d_l.ptr))
+    buf = d_l.to_array(np.uint8, (total,))
+    for l in range(m + 1):
+        off = gpu_ctx._L.frieda_merkle_layer_offset(m, l)
+        assert off == oracle.lib().fo_merkle_layer_offset(m, l)
+        assert np.array_equal(buf[off : off + (32 << l)].reshape(-1, 32), layers[l]), f"layer {l}"
+    d_r = DevBuf(gpu_ctx, 32)
+    _check(gpu_ctx, gpu_ctx._L.frieda_merkle_root(gpu_ctx._h, d_c.ptr, m, d_r.ptr))
+    assert bytes(d_r.to_array(np.uint8, (32,))) == bytes(layers[0][0])
+
+
+@pytest.mark.parametrize("ncols,with_prev", [(4, False), (0, True), (1, False), (3, True), (16, False), (17, True), (40, True)])
+def test_merkle_commit_layer_general_shapes(gpu_ctx, oracle, ncols, with_prev):
+    """MerkleOps::commit_on_layer for arbitrary column counts (the trait surface, not only frieda's two shapes)."""
+    log_size = 7
+    rng = np.random.default_rng(300 + ncols)
+    cols = rand_m31(rng, (ncols, 1 << log_size)) if ncols else None
+    prev = rng.integers(0, 256, (2 << log_size, 32), dtype=np.uint8) if with_prev else None
+    exp = oracle.merkle_commit_layer(log_size, prev, cols)
+    d_prev = DevBuf.from_array(gpu_ctx, prev) if with_prev else None
+    d_cols = [DevBuf.from_array(gpu_ctx, cols[i]) for i in range(ncols)]
+    ptrs = (C.c_void_p * max(ncols, 1))(*[b.ptr for b in d_cols])
+    d_out = DevBuf(gpu_ctx, 32 << log_size)
+    _check(gpu_ctx, gpu_ctx._L.frieda_merkle_commit_layer(gpu_ctx._h, log_size, d_prev.ptr if d_prev else None, ptrs, ncols, d_out.ptr))
+    assert np.array_equal(d_out.to_array(np.uint8, (1 << log_size, 32)), exp)
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 6, 12, 16])
+def test_fold_circle_into_line(gpu_ctx, oracle, n):
+    rng = np.random.default_rng(400 + n)
+    src = rand_m31(rng, (4, 1 << n))
+    alpha = rand_m31(rng, (4,))
+    for dst0 in (np.zeros((4, 1 << (n - 1)), np.uint32), rand_m31(rng, (4, 1 << (n - 1)))):
+        exp = oracle.fold_circle_into_line(src, alpha, dst0.copy())
+        d_s, d_d = DevBuf.from_array(gpu_ctx, src), DevBuf.from_array(gpu_ctx, dst0)
+        _check(gpu_ctx, gpu_ctx._L.frieda_fold_circle_into_line(gpu_ctx._h, d_d.ptr, d_s.ptr, n, alpha.ctypes.data))
+        assert np.array_equal(d_d.to_array(np.uint32, (4, 1 << (n - 1))), exp)
+
+
+@pytest.mark.parametrize("n,m", [(2, 1), (3, 2), (6, 5), (6, 1), (12, 11), (12, 7), (16, 15), (16, 9)])
+def test_fold_line(gpu_ctx, oracle, n, m):
+    rng = np.random.default_rng(500 + 31 * n + m)
+    src = rand_m31(rng, (4, 1 << m))
+    alpha = rand_m31(rng, (4,))
+    exp = oracle.fold_line(src, n, alpha)
+    d_s, d_d = DevBuf.from_array(gpu_ctx, src), DevBuf(gpu_ctx, 16 << (m - 1))
+    _check(gpu_ctx, gpu_ctx._L.frieda_fold_line(gpu_ctx._h, d_s.ptr, m, n, alpha.ctypes.data, d_d.ptr))
+    assert np.array_equal(d_d.to_array(np.uint32, (4, 1 << (m - 1))), exp)
+
+
+@pytest.mark.parametrize("pow_bits,seed", [(0, 1), (5, 2), (12, 3), (20, 4), (22, 5)])
+def test_grind_returns_minimum_nonce(gpu_ctx, oracle, pow_bits, seed):
+    ch = oracle.Channel()
+    oracle.lib().fo_channel_init(C.byref(ch))
+    oracle.lib().fo_channel_mix_u64(C.byref(ch), seed)
+    exp = oracle.lib().fo_grind(C.byref(ch), pow_bits)
+    got = C.c_uint64()
+    _check(gpu_ctx, gpu_ctx._L.frieda_grind(gpu_ctx._h, bytes(ch.digest), pow_bits, C.byref(got)))
+    assert got.value == exp
+
+
+def test_config2_ntt_plus_fold_round(gpu_ctx, oracle):
+    """BASELINE.json configs[1]: 2^20-element NTT + fold_circle_into_line + one fold_line, all three buffers bit-exact."""
+    n, L = 20, 16
+    data = splitmix64_bytes(1, blob_len_for(n))
+    coef, lg = oracle.polynomial_from_bytes(data)
+    assert lg == L
+    alphas = (splitmix64_bytes(2, 32).view(np.uint32) % P).astype(np.uint32).reshape(2, 4)
+    ev = oracle.circle_evaluate(coef, n)
+    l1 = oracle.fold_circle_into_line(ev, alphas[0])
+    l2 = oracle.fold_line(l1, n, alphas[1])
+    d_c, d_e = DevBuf.from_array(gpu_ctx, coef), DevBuf(gpu_ctx, 16 << n)
+    d_1, d_2 = DevBuf.from_array(gpu_ctx, np.zeros((4, 1 << (n - 1)), np.uint32)), DevBuf(gpu_ctx, 16 << (n - 2))
+    L_ = gpu_ctx._L
+    _check(gpu_ctx, L_.frieda_circle_evaluate(gpu_ctx._h, d_c.ptr, 4, L, n, d_e.ptr))
+    _check(gpu_ctx, L_.frieda_fold_circle_into_line(gpu_ctx._h, d_1.ptr, d_e.ptr, n, alphas[0].ctypes.data))
+    _check(gpu_ctx, L_.frieda_fold_line(gpu_ctx._h, d_1.ptr, n - 1, n, alphas[1].ctypes.data, d_2.ptr))
+    assert np.array_equal(d_e.to_array(np.uint32, (4, 1 << n)), ev)
+    assert np.array_equal(d_1.to_array(np.uint32, (4, 1 << (n - 1))), l1)
+    assert np.array_equal(d_2.to_array(np.uint32, (4, 1 << (n - 2))), l2)
+
+
+# ------------------------------------------------------------------------------------------------
+# Level A
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("vec", load_vectors()["commit"], ids=lambda v: v["input"][:24])
+def test_commit_known_answers(gpu_ctx, blob, vec):
+    """src/commit.rs:28-38 (golden root) and the secondary vectors, on the GPU."""
+    data = resolve_input(vec["input"], blob)
+    assert gpu_ctx.commit(data, vec["log_blowup_factor"]).hex() == vec["root"]
+
+
+@pytest.mark.parametrize("n_bytes", [0, 1, 15, 16, 17, 58, 119, 120, 121, 300, 1023, 5000, 70001])
+@pytest.mark.parametrize("B", [1, 2, 4])
+def test_commit_matches_oracle_ragged(gpu_ctx, oracle, n_bytes, B):
+    data = splitmix64_bytes(21 + B, n_bytes).tobytes()
+    assert gpu_ctx.commit(data, B) == oracle.commit(data, B)
+
+
+def test_commit_without_twiddle_cache(gpu_ctx, oracle):
+    data = pattern_bytes(4096).tobytes()
+    gpu_ctx.set_twiddle_cache(False)
+    try:
+        assert gpu_ctx.commit(data, 4) == oracle.commit(data, 4)
+        assert gpu_ctx.commit(data, 4) == oracle.commit(data, 4)
+    finally:
+        gpu_ctx.set_twiddle_cache(True)
+
+
+def test_commit_device_resident(gpu_ctx, oracle):
+    import torch
+
+    data = splitmix64_bytes(5, blob_len_for(16))
+    t = torch.from_numpy(data).cuda()
+    root = torch.zeros(32, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    gpu_ctx.commit_device(t.data_ptr(), t.numel(), 4, root.data_ptr())
+    gpu_ctx.synchronize()
+    assert bytes(root.cpu().numpy()) == oracle.commit(data, 4)
+
+
+def _cfg(frieda_amd, pow_bits, B, last, nq):
+    return frieda_amd.PcsConfig(frieda_amd.FriConfig(B, last, nq), pow_bits)
+
+
+PROVE_CASES = [
+    ("pattern:1024", None, (20, 4, 0, 20)),
+    ("pattern:1024", 1024, (20, 4, 0, 20)),
+    ("pattern:4096", 4096, (20, 4, 1, 20)),
+    ("pattern:65536", 65536, (20, 4, 0, 20)),
+    ("ascii:This is the original data that needs to be made available.", None, (20, 4, 0, 20)),
+    ("pattern:300", 9, (8, 2, 1, 12)),
+    ("pattern:2000", 3, (6, 1, 2, 7)),
+    ("pattern:700", None, (10, 3, 0, 33)),
+    ("blob", None, (20, 4, 1, 20)),
+    ("blob", 262146, (20, 4, 0, 20)),
+]
+
+
+@pytest.mark.parametrize("spec,seed,cfg", PROVE_CASES, ids=lambda v: str(v)[:28])
+def test_prove_bit_exact_vs_oracle(gpu_ctx, oracle, blob, spec, seed, cfg):
+    """Whole proof (every root, alpha-dependent layer, nonce, witness, opening) byte-identical to the oracle's."""
+    import frieda_amd
+
+    data = resolve_input(spec, blob)
+    o_root, o_proof = oracle.commit_and_generate_proof(data, seed, oracle.make_config(*cfg))
+    g_root, g_proof = gpu_ctx.commit_and_generate_proof(data, seed, _cfg(frieda_amd, *cfg))
+    assert g_root == o_root
+    assert g_proof.proof_of_work == o_proof.c.proof_of_work
+    for li in range(g_proof.n_inner_layers + 1):
+        ol = o_proof.c.first_layer if li == 0 else o_proof.c.inner_layers[li - 1]
+        assert g_proof.layer(li)["commitment"] == bytes(ol.commitment), f"layer {li} root"
+    assert g_proof.serialize() == o_proof.serialize()
+    assert frieda_amd.verify(g_proof, seed)
+    assert oracle.verify(o_proof, seed)
+
+
+def test_reference_proof_tests_on_gpu(gpu_ctx, blob):
+    """src/proof.rs:119-193 through the GPU prover and the C-ABI verifier."""
+    import frieda_amd
+
+    cfg = _cfg(frieda_amd, 20, 4, 1, 20)
+    commitment, proof = gpu_ctx.commit_and_generate_proof(blob, None, cfg)
+    assert proof.n_inner_layers != 0
+    assert commitment == gpu_ctx.commit(blob, 4) and proof.commitment == commitment
+    assert frieda_amd.verify(proof, None)
+    p = proof.clone()
+    p.proof_of_work += 1
+    assert not frieda_amd.verify(p, None)
+    p = proof.clone()
+    e = p.evaluations
+    e[0] = (e[0].astype(np.uint64) + 1) % P
+    p.evaluations = e
+    assert not frieda_amd.verify(p, None)
+    p = proof.clone()
+    p.evaluations = p.evaluations[::-1]
+    assert not frieda_amd.verify(p, None)
+    p = proof.clone()
+    p.evaluations = p.evaluations[:-1]
+    with pytest.raises(frieda_amd.FriedaPanic):
+        frieda_amd.verify(p, None)
+    p = proof.clone()
+    e = p.evaluations
+    e[[0, 1]] = e[[1, 0]]
+    p.evaluations = e
+    assert not frieda_amd.verify(p, None)
+    p1 = gpu_ctx.generate_proof(blob, 1, cfg)
+    p2 = gpu_ctx.generate_proof(blob, 2, cfg)
+    assert p1.evaluations.tolist() != p2.evaluations.tolist()
+    assert frieda_amd.verify(p1, 1) and frieda_amd.verify(p2, 2)
+    assert not frieda_amd.verify(p1, 2) and not frieda_amd.verify(p2, 1)
+
+
+def test_panics_map_to_status(gpu_ctx):
+    import frieda_amd
+
+    with pytest.raises(frieda_amd.FriedaPanic):
+        gpu_ctx.generate_proof(b"tiny", None, _cfg(frieda_amd, 8, 4, 0, 4))
+
+
+# ------------------------------------------------------------------------------------------------
+# full sizes: properties that do not need the oracle at size
+# ------------------------------------------------------------------------------------------------
+def test_config3_commit_2p22_matches_oracle(gpu_ctx, oracle):
+    """BASELINE.json configs[2]: 2^22-domain commit(); the oracle needs ~10 s here, still affordable once."""
+    data = splitmix64_bytes(1, blob_len_for(22)).tobytes()
+    assert gpu_ctx.commit(data, 4) == oracle.commit(data, 4)
+
+
+@pytest.mark.parametrize("n", [22, 24])
+def test_full_size_prove_verify_and_tie(gpu_ctx, n):
+    """configs[2]/[4]: prove -> verify round trip, first FRI root == commit() root (src/proof.rs:126-135), the last
+    layer passes stwo's degree assertion (else FriedaPanic), tampering is rejected."""
+    import frieda_amd
+
+    data = splitmix64_bytes(100, blob_len_for(n))
+    cfg = _cfg(frieda_amd, 20, 4, 0, 20)
+    seed = data.size
+    commitment, proof = gpu_ctx.commit_and_generate_proof(data, seed, cfg)
+    assert commitment == gpu_ctx.commit(data, 4)
+    assert proof.n_inner_layers == n - 1 - 4
+    assert frieda_amd.verify(proof, seed)
+    assert not frieda_amd.verify(proof, seed + 1)
+    p = proof.clone()
+    e = p.evaluations
+    e[3, 2] ^= 1
+    p.evaluations = e
+    assert not frieda_amd.verify(p, seed)
+    # serialisation round trip keeps the proof valid
+    assert frieda_amd.verify(frieda_amd.Proof.deserialize(proof.serialize()), seed)
+
+
+def test_full_size_encode_linearity(gpu_ctx):
+    """RS encode is linear: E(a) + E(b) == E(a + b) on a 2^22 domain (coefficients drawn below 2^30 so that sums stay
+    canonical through the codec-free Level B entry point)."""
+    n, L = 22, 18
+    rng = np.random.default_rng(9)
+    a = rand_m31(rng, (4, 1 << L))
+    b = rand_m31(rng, (4, 1 << L))
+    s = ((a.astype(np.uint64) + b) % P).astype(np.uint32)
+    outs = []
+    for x in (a, b, s):
+        d_c, d_o = DevBuf.from_array(gpu_ctx, x), DevBuf(gpu_ctx, 16 << n)
+        _check(gpu_ctx, gpu_ctx._L.frieda_circle_evaluate(gpu_ctx._h, d_c.ptr, 4, L, n, d_o.ptr))
+        outs.append(d_o.to_array(np.uint32, (4, 1 << n)).astype(np.uint64))
+    assert np.array_equal((outs[0] + outs[1]) % P, outs[2])

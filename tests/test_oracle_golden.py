@@ -1,0 +1,203 @@
+"""CPU: the oracle against every known answer the reference's tests hold for this path and the
+reference's 13 test behaviours.  These pin the checker before it is trusted to check the HIP path."""
+import hashlib
+
+import numpy as np
+import pytest
+
+from conftest import pattern_bytes
+from util import load_vectors, resolve_input
+
+P = 2**31 - 1
+
+
+def test_bytes_to_one_felt(oracle):
+    # src/utils.rs:41-49
+    for i in range(256):
+        f = oracle.bytes_to_felt_le(bytes([i]))
+        assert f.tolist() == [i]
+
+
+def test_bytes_to_two_felt(oracle):
+    # src/utils.rs:52-66: two 30-bit copies of i packed LSB-first into 8 bytes -> [i, i, 0]
+    for i in range(513):
+        bits = (i & (2**30 - 1)) | ((i & (2**30 - 1)) << 30)
+        data = bits.to_bytes(8, "little")
+        assert oracle.bytes_to_felt_le(data).tolist() == [i, i, 0]
+
+
+def test_codec_against_python_bigint(oracle):
+    rng = np.random.default_rng(7)
+    for n in [0, 1, 3, 4, 15, 16, 29, 30, 31, 58, 119, 120, 121, 1000, 4097]:
+        data = rng.integers(0, 256, n, dtype=np.uint8).tobytes()
+        v = int.from_bytes(data, "little")
+        exp = [(v >> (30 * k)) & (2**30 - 1) for k in range((8 * n + 29) // 30)]
+        assert oracle.bytes_to_felt_le(data).tolist() == exp
+
+
+def test_padding_rule(oracle):
+    # src/utils.rs:23-27: next power of two >= 4, split in 4
+    for n, (fp, L) in {0: (4, 0), 1: (4, 0), 15: (4, 0), 16: (8, 1), 58: (16, 2), 1024: (512, 7), 262146: (131072, 15)}.items():
+        coef, lg = oracle.polynomial_from_bytes(bytes(n))
+        assert coef.size == fp and lg == L
+
+
+@pytest.mark.parametrize("vec", load_vectors()["commit"], ids=lambda v: v["input"][:24])
+def test_commit_known_answers(oracle, blob, vec):
+    # the first entry is the reference's golden root (src/commit.rs:28-38)
+    data = resolve_input(vec["input"], blob)
+    assert oracle.commit(data, vec["log_blowup_factor"]).hex() == vec["root"]
+
+
+def test_evaluation_heads(oracle):
+    heads = load_vectors()["evaluation_heads"]
+    coef, L = oracle.polynomial_from_bytes(pattern_bytes(1024).tobytes())
+    ev = oracle.circle_evaluate(coef, L + 4)
+    assert ev[0, :4].tolist() == heads["pattern:1024"]["col0"]
+    s = b"This is the original data that needs to be made available."
+    coef, L = oracle.polynomial_from_bytes(s)
+    ev = oracle.circle_evaluate(coef, L + 4)
+    assert ev[:, :2].tolist() == heads["ascii:" + s.decode()]["cols"]
+
+
+def test_fft_matches_direct_basis_evaluation(oracle):
+    """Independent check of A.2: out[i] = f(domain.at(brev(i))) with the circle-FFT basis y^j0 x^j1 pi(x)^j2 ..."""
+    import ctypes as C
+
+    rng = np.random.default_rng(3)
+    for n in (3, 4, 5):
+        coef = rng.integers(0, P, (1, 1 << n), dtype=np.uint32)
+        ev = oracle.circle_evaluate(coef, n)[0]
+        x, y = C.c_uint32(), C.c_uint32()
+        for i in range(1 << n):
+            oracle.lib().fo_circle_domain_at(n, oracle.lib().fo_bit_reverse_index(i, n), C.byref(x), C.byref(y))
+            px, py = x.value, y.value
+            acc = 0
+            for j in range(1 << n):
+                term = int(coef[0, j])
+                if j & 1:
+                    term = term * py % P
+                xx = px
+                for b in range(1, n):
+                    if (j >> b) & 1:
+                        term = term * xx % P
+                    xx = (2 * xx * xx - 1) % P
+                acc = (acc + term) % P
+            assert acc == ev[i]
+
+
+def test_standard_blake2s_matches_hashlib(oracle):
+    import ctypes as C
+
+    for n in [0, 1, 31, 32, 63, 64, 65, 127, 128, 129, 300]:
+        d = bytes((7 * i + 3) % 256 for i in range(n))
+        out = (C.c_uint8 * 32)()
+        a = np.frombuffer(d, dtype=np.uint8)
+        oracle.lib().fo_blake2s256(a.ctypes.data if n else None, n, out)
+        assert bytes(out) == hashlib.blake2s(d).digest()
+
+
+def test_merkle_hash_is_not_rfc_blake2s(oracle):
+    """Blake2sMerkleHasher is the bare compression function, not Blake2s-256."""
+    cols = np.arange(8, dtype=np.uint32).reshape(4, 2)
+    leaves = oracle.merkle_commit_layer(1, None, cols)
+    msg = np.array([0, 2, 4, 6] + [0] * 12, dtype="<u4").tobytes()
+    assert bytes(leaves[0]) != hashlib.blake2s(msg[:16]).digest()
+    assert bytes(leaves[0]) != hashlib.blake2s(msg).digest()
+
+
+# ---- the reference's proof tests (src/proof.rs:119-193, src/lib.rs:52-85) on the oracle ----
+PCS = dict(pow_bits=20, log_blowup_factor=4, log_last_layer_degree_bound=1, n_queries=20)
+
+
+@pytest.fixture(scope="module")
+def blob_proof(oracle, blob):
+    return oracle.commit_and_generate_proof(blob, None, oracle.make_config(**PCS))
+
+
+def test_generate_proof(blob_proof):
+    assert blob_proof[1].c.n_inner_layers != 0  # src/proof.rs:119-124
+
+
+def test_commit_and_generate_proof(oracle, blob, blob_proof):
+    root, proof = blob_proof  # src/proof.rs:126-135
+    assert root == oracle.commit(blob, 4)
+    assert bytes(proof.c.first_layer.commitment) == root
+
+
+def test_verify_proof(oracle, blob_proof):
+    assert oracle.verify(blob_proof[1], None)
+
+
+def test_verify_invalid_pow(oracle, blob_proof):
+    p = blob_proof[1].clone()
+    p.c.proof_of_work += 1
+    assert not oracle.verify(p, None)
+
+
+def _set_evals(p, ev):
+    flat = np.ascontiguousarray(ev, dtype=np.uint32).ravel()
+    for i, v in enumerate(flat):
+        p.c.evaluations[i] = int(v)
+
+
+def test_verify_invalid_evaluations(oracle, blob_proof):
+    p = blob_proof[1].clone()
+    ev = p.evaluations()
+    ev[0] = (ev[0].astype(np.uint64) + 1) % P
+    _set_evals(p, ev)
+    assert not oracle.verify(p, None)
+
+
+def test_verify_invalid_evaluations_order(oracle, blob_proof):
+    p = blob_proof[1].clone()
+    _set_evals(p, p.evaluations()[::-1])
+    assert not oracle.verify(p, None)
+
+
+def test_verify_invalid_evaluations_length_panics(oracle, blob_proof):
+    p = blob_proof[1].clone()  # src/proof.rs:166-173 #[should_panic]
+    p.c.n_evaluations -= 1
+    with pytest.raises(RuntimeError):
+        oracle.verify(p, None)
+    p.c.n_evaluations += 1
+
+
+def test_verify_invalid_1_evaluation_unordered(oracle, blob_proof):
+    p = blob_proof[1].clone()
+    ev = p.evaluations()
+    ev[[0, 1]] = ev[[1, 0]]
+    _set_evals(p, ev)
+    assert not oracle.verify(p, None)
+
+
+def test_verify_with_seed(oracle, blob):
+    cfg = oracle.make_config(**PCS)
+    _, p1 = oracle.commit_and_generate_proof(blob, 1, cfg)
+    _, p2 = oracle.commit_and_generate_proof(blob, 2, cfg)
+    assert p1.evaluations().tolist() != p2.evaluations().tolist()
+    assert oracle.verify(p1, 1) and oracle.verify(p2, 2)
+    assert not oracle.verify(p1, 2) and not oracle.verify(p2, 1)
+
+
+def test_end_to_end(oracle):
+    s = b"This is the original data that needs to be made available."  # src/lib.rs:52-85
+    cfg = oracle.make_config(20, 4, 0, 20)
+    root, proof = oracle.commit_and_generate_proof(s, None, cfg)
+    assert root == oracle.commit(s, 4)
+    assert oracle.verify(proof, None)
+
+
+@pytest.mark.parametrize("n_bytes,B,last", [(1024, 4, 0), (1024, 4, 1), (4096, 4, 0), (300, 2, 1), (2000, 1, 2), (700, 3, 0)])
+def test_fri_degree_invariant(oracle, n_bytes, B, last):
+    """stwo asserts the last layer interpolates below the degree bound; the prover returns the panic status if not."""
+    data = pattern_bytes(n_bytes).tobytes()
+    cfg = oracle.make_config(8, B, last, 12)
+    _, proof = oracle.commit_and_generate_proof(data, 5, cfg)
+    assert proof.c.n_last_layer_poly == 1 << last
+    assert oracle.verify(proof, 5)
+
+
+def test_too_small_polynomial_panics(oracle):
+    with pytest.raises(RuntimeError):
+        oracle.commit_and_generate_proof(b"tiny", None, oracle.make_config(8, 4, 0, 4))
