@@ -96,6 +96,10 @@ class Context:
     def set_twiddle_cache(self, enabled):
         _check(self._L.frieda_ctx_set_twiddle_cache(self._h, int(bool(enabled))), self._h)
 
+    def set_host_channel(self, enabled):
+        """Evaluate the Fiat-Shamir channel on the host between layers instead of inside the device kernels."""
+        _check(self._L.frieda_ctx_set_host_channel(self._h, int(bool(enabled))), self._h)
+
     def set_kernel_timing(self, enabled):
         _check(self._L.frieda_ctx_set_kernel_timing(self._h, int(bool(enabled))), self._h)
 

@@ -87,6 +87,12 @@ int frieda_ctx_set_twiddle_cache(frieda_ctx* ctx, int enabled) {
     return FRIEDA_OK;
 }
 
+int frieda_ctx_set_host_channel(frieda_ctx* ctx, int enabled) {
+    if (!ctx) return FRIEDA_ERR_ARG;
+    ctx->c.host_channel = enabled != 0;
+    return FRIEDA_OK;
+}
+
 int frieda_ctx_set_kernel_timing(frieda_ctx* ctx, int enabled) {
     if (!ctx) return FRIEDA_ERR_ARG;
     FR_GUARD_BEGIN

@@ -76,6 +76,7 @@ struct Ctx {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     bool cache_twiddles = true;
+    bool host_channel = false;  // evaluate the Fiat-Shamir channel on the host between layers (diagnostic / fallback path)
     std::map<uint32_t, TwiddleSet> twiddles;
     uint8_t* arena = nullptr;
     size_t arena_bytes = 0;

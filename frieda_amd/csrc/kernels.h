@@ -80,6 +80,25 @@ inline size_t merkle_layer_offset(uint32_t log_size, uint32_t layer_log) {
     return ((size_t)64 << log_size) - ((size_t)64 << layer_log);
 }
 
+// ---- tree.hip (fused commit phase) ----
+}  // namespace k
+struct DevTranscript;
+namespace k {
+// tree of the first FRI layer (the 4 evaluation columns): every level kept in d_layers; when tr is non-null the finishing
+// kernel mixes the root into the device transcript and draws the folding alpha
+void tree_first_layer(const Launch& L, const uint32_t* cols, size_t stride, uint32_t m, uint8_t* d_layers, DevTranscript* tr);
+// fold the layer `src` (log size src_log; circle evaluation or line layer) with the alpha in tr into dst_vals and build the
+// tree of the folded layer in the same launches; finishes with the channel step
+void fold_and_tree(const Launch& L, bool circle, const uint32_t* src, size_t src_stride, uint32_t src_log, uint32_t n,
+                   const uint32_t* d_itw, DomainScalars ds, uint32_t* dst_vals, uint8_t* d_layers, DevTranscript* tr);
+// all remaining layers (each <= 2048 points) in one workgroup, ending with the last-layer interpolation + mix_felts
+constexpr uint32_t TAIL_LOG = 11;
+void fri_tail(const Launch& L, const uint32_t* src, size_t src_stride, uint32_t src_log, bool src_is_circle, uint32_t n,
+              const uint32_t* d_itw, DomainScalars ds, uint32_t last_log, uint32_t last, uint32_t n_layers, uint32_t* const* vals,
+              uint8_t* const* trees, DevTranscript* tr);
+// proof-of-work scan keyed by tr->ch.digest; atomicMin into tr->nonce
+void grind_dev(const Launch& L, DevTranscript* tr, uint32_t pow_bits, uint64_t base, uint64_t count);
+
 // ---- fri.hip ----
 struct Alpha {
     uint32_t v[4];

@@ -9,8 +9,8 @@
 // Hash storage is array-of-structs: node i of a layer is the 32 bytes at 32*i, so the two children of a
 // parent are one contiguous 64-byte block and a whole wave reads a contiguous 4 KiB span.
 // Per node the work is one compression (~970 integer VALU ops) against 64 B read + 32 B written, which puts
-// the single-layer kernels at the crossover of the VALU and HBM ceilings; the multi-layer kernels keep the
-// intermediate layers on chip (LDS) so only what the caller asked to keep goes back to HBM.
+// the single-layer kernels at the crossover of the VALU and HBM ceilings.  These are the trait-granular kernels behind
+// `frieda_merkle_commit_layer`; whole trees go through the fused multi-level kernels of tree.hip.
 #include <hip/hip_runtime.h>
 
 #include "blake2s.h"
@@ -82,37 +82,6 @@ __global__ __launch_bounds__(MK_THREADS) void merkle_generic_kernel(const uint8_
     store_hash(out, i, st);
 }
 
-// Top of a tree in one workgroup: from a layer of `n_in` (<= 2 * MK_THREADS... any power of two <= 1024)
-// hashes down to the root, every intermediate layer written at its leaves-first offset when `layers` is
-// non-null.  Children are re-read from global memory written by this same workgroup, so a workgroup-scope
-// barrier + fence is sufficient.
-__global__ __launch_bounds__(MK_THREADS) void merkle_top_kernel(const uint8_t* __restrict__ in, uint32_t log_in,
-                                                                uint8_t* __restrict__ layers, uint32_t tree_log,
-                                                                uint8_t* __restrict__ scratch, uint8_t* __restrict__ root_out) {
-    // layer l (2^l nodes) lives at layers + offset(tree_log, l) when kept, else in scratch (ping-pong halves)
-    const uint8_t* src = in;
-    for (int l = (int)log_in - 1; l >= 0; l--) {
-        uint8_t* dst;
-        if (l == 0 && root_out)
-            dst = root_out;
-        else if (layers)
-            dst = layers + (((size_t)64 << tree_log) - ((size_t)64 << l));
-        else
-            dst = scratch + ((l & 1) ? (size_t)32 * 1024 : 0);
-        size_t cnt = (size_t)1 << l;
-        for (size_t i = threadIdx.x; i < cnt; i += MK_THREADS) {
-            uint32_t m[16], h[8];
-            load_children(src, i, m);
-            b2_merkle_block(m, h);
-            store_hash(dst, i, h);
-        }
-        __threadfence_block();
-        __syncthreads();
-        src = dst;
-    }
-}
-
-constexpr uint32_t TOP_LOG = 10;  // layers of <= 1024 nodes are finished by one workgroup
 
 }  // namespace
 
@@ -135,50 +104,6 @@ void merkle_layer_generic(const Launch& L, const uint8_t* d_prev, const uint32_t
     Scope scope(L, "merkle_generic", (double)n * (32.0 + (d_prev ? 64.0 : 0.0) + 4.0 * ncols));
     merkle_generic_kernel<<<(unsigned)((n + MK_THREADS - 1) / MK_THREADS), MK_THREADS, 0, s>>>(d_prev, d_col_ptrs, ncols, n,
                                                                                               d_out);
-}
-
-void merkle_tree4(const Launch& L, const uint32_t* c0, const uint32_t* c1, const uint32_t* c2, const uint32_t* c3, uint32_t m,
-                  uint8_t* d_layers) {
-    hipStream_t s = L.stream;
-    merkle_leaf4(L, c0, c1, c2, c3, (size_t)1 << m, d_layers);
-    uint32_t l = m;  // current finished layer
-    while (l > TOP_LOG) {
-        merkle_node(L, d_layers + merkle_layer_offset(m, l), (size_t)1 << (l - 1), d_layers + merkle_layer_offset(m, l - 1));
-        l--;
-    }
-    if (l > 0) {
-        Scope scope(L, "merkle_top", 96.0 * (double)(((size_t)1 << l) - 1));
-        merkle_top_kernel<<<1, MK_THREADS, 0, s>>>(d_layers + merkle_layer_offset(m, l), l, d_layers, m, nullptr, nullptr);
-    }
-}
-
-size_t merkle_root_scratch_bytes(uint32_t m) {
-    // ping-pong: leaves (32 * 2^m) + next layer (32 * 2^(m-1)); the upper layers reuse the two regions
-    return ((size_t)32 << m) + ((size_t)32 << (m > 0 ? m - 1 : 0)) + 2 * 32 * 1024;
-}
-
-void merkle_root4(const Launch& L, const uint32_t* c0, const uint32_t* c1, const uint32_t* c2, const uint32_t* c3, uint32_t m,
-                  uint8_t* d_scratch, uint8_t* d_root) {
-    uint8_t* a = d_scratch;
-    uint8_t* b = d_scratch + ((size_t)32 << m);
-    uint8_t* top = b + ((size_t)32 << (m > 0 ? m - 1 : 0));
-    hipStream_t s = L.stream;
-    if (m == 0) {
-        merkle_leaf4(L, c0, c1, c2, c3, 1, d_root);
-        return;
-    }
-    merkle_leaf4(L, c0, c1, c2, c3, (size_t)1 << m, a);
-    uint32_t l = m;
-    uint8_t *cur = a, *nxt = b;
-    while (l > TOP_LOG) {
-        merkle_node(L, cur, (size_t)1 << (l - 1), nxt);
-        uint8_t* t = cur;
-        cur = nxt;
-        nxt = t;
-        l--;
-    }
-    Scope scope(L, "merkle_top", 96.0 * (double)(((size_t)1 << l) - 1));
-    merkle_top_kernel<<<1, MK_THREADS, 0, s>>>(cur, l, nullptr, m, top, d_root);
 }
 
 }  // namespace k

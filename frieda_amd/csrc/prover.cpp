@@ -12,6 +12,9 @@
 
 #include <algorithm>
 
+#include <stddef.h>
+
+#include "dev_transcript.h"
 #include "host.h"
 
 namespace frieda {
@@ -263,6 +266,7 @@ int prove(Ctx* ctx, const uint8_t* data, size_t len, bool data_on_device, const 
     }
     size_t o_lastv = plan.take(sizeof(uint32_t) * 4 << last_log);
     size_t o_nonce = plan.take(8);
+    size_t o_tr = plan.take(sizeof(DevTranscript));
     // decommit gather: per layer <= 2 positions per query; hashes <= 2 * queries * log per layer
     const size_t max_words = (size_t)cfg.n_queries * 4 * (1 + (n_inner + 1));
     const size_t max_hashes = (size_t)cfg.n_queries * 2 * (size_t)(n + 1) * (n_inner + 1);
@@ -270,7 +274,8 @@ int prove(Ctx* ctx, const uint8_t* data, size_t len, bool data_on_device, const 
     size_t o_wout = plan.take(4 * max_words), o_hout = plan.take(32 * max_hashes);
     rc = ctx->ensure_arena(plan.off);
     if (rc) return rc;
-    const size_t pinned_need = std::max<size_t>(std::max<size_t>(4096, (sizeof(uint32_t) * 4) << last_log), 4 * max_words + 32 * max_hashes);
+    const size_t pinned_need =
+        std::max<size_t>(std::max<size_t>(sizeof(DevTranscript), (sizeof(uint32_t) * 4) << last_log), 4 * max_words + 32 * max_hashes);
     rc = ensure_pinned(ctx, pinned_need);
     if (rc) return rc;
     TwiddleSet tw;
@@ -295,79 +300,144 @@ int prove(Ctx* ctx, const uint8_t* data, size_t len, bool data_on_device, const 
     ch.init();
     if (seed) ch.mix_u64(*seed);  // src/proof.rs:40-42
 
-    auto fetch_root = [&](const FriLayerDev& lay, Hash32& root) -> int {
-        FR_HIP(ctx, hipMemcpyAsync(ctx->pinned, A + lay.o_tree + k::merkle_layer_offset(lay.log, 0), 32, hipMemcpyDeviceToHost, s));
-        FR_HIP(ctx, hipStreamSynchronize(s));
-        memcpy(root.data(), ctx->pinned, 32);
-        return FRIEDA_OK;
-    };
     auto cols = [&](const FriLayerDev& lay, int c) { return reinterpret_cast<uint32_t*>(A + lay.o_vals) + ((size_t)c << lay.log); };
-
-    // ---- FriProver::commit_first_layer ----
-    k::merkle_tree4(LN, cols(first, 0), cols(first, 1), cols(first, 2), cols(first, 3), n, A + first.o_tree);
     std::vector<Hash32> roots(1 + n_inner);
-    rc = fetch_root(first, roots[0]);
-    if (rc) return rc;
-    uint32_t rw[8];
-    hash_to_words(roots[0].data(), rw);
-    ch.mix_root(rw);
-
-    // ---- FriProver::commit_inner_layers ----
-    QM31 alpha = ch.draw_felt();
-    {
-        // LineEvaluation::new_zero then fold_circle_into_line
-        uint32_t* dst = (n_inner > 0) ? cols(inner[0], 0) : reinterpret_cast<uint32_t*>(A + o_lastv);
-        FR_HIP(ctx, hipMemsetAsync(dst, 0, sizeof(uint32_t) * 4 << (n - 1), s));
-        k::fold_circle_into_line(LN, dst, (size_t)1 << (n - 1), eval, N, n, tw.d_itw, tw.ds, k::Alpha{{alpha.a, alpha.b, alpha.c, alpha.d}});
-    }
-    for (uint32_t kx = 0; kx < n_inner; kx++) {
-        const FriLayerDev& lay = inner[kx];
-        k::merkle_tree4(LN, cols(lay, 0), cols(lay, 1), cols(lay, 2), cols(lay, 3), lay.log, A + lay.o_tree);
-        rc = fetch_root(lay, roots[kx + 1]);
-        if (rc) return rc;
-        hash_to_words(roots[kx + 1].data(), rw);
-        ch.mix_root(rw);
-        alpha = ch.draw_felt();
-        uint32_t* dst = (kx + 1 < n_inner) ? cols(inner[kx + 1], 0) : reinterpret_cast<uint32_t*>(A + o_lastv);
-        k::fold_line(LN, cols(lay, 0), (size_t)1 << lay.log, lay.log, n, tw.d_itw, tw.ds, k::Alpha{{alpha.a, alpha.b, alpha.c, alpha.d}}, dst,
-                     (size_t)1 << (lay.log - 1));
-    }
-
-    // ---- FriProver::commit_last_layer ----
-    const size_t n_lastdom = (size_t)1 << last_log;
-    FR_HIP(ctx, hipMemcpyAsync(ctx->pinned, A + o_lastv, sizeof(uint32_t) * 4 * n_lastdom, hipMemcpyDeviceToHost, s));
-    FR_HIP(ctx, hipStreamSynchronize(s));
-    std::vector<QM31> lastv(n_lastdom);
-    {
-        const uint32_t* h = reinterpret_cast<const uint32_t*>(ctx->pinned);
-        for (size_t i = 0; i < n_lastdom; i++) lastv[i] = {h[i], h[n_lastdom + i], h[2 * n_lastdom + i], h[3 * n_lastdom + i]};
-    }
-    line_interpolate(lastv, line_coset(n, last_log));
-    bit_reverse_vec(lastv, n_lastdom, last_log);  // into_ordered_coefficients
-    const size_t n_poly = (size_t)1 << last;
-    for (size_t i = n_poly; i < n_lastdom; i++)
-        if (!qm_is_zero(lastv[i])) return ctx->fail(FRIEDA_ERR_INVARIANT, "invalid degree");  // assert! upstream
-    lastv.resize(n_poly);
-    bit_reverse_vec(lastv, n_poly, last);  // LinePoly::from_ordered_coefficients
-    channel_mix_felts(ch, lastv);
-
-    // ---- grind (src/proof.rs:58-59) ----
-    unsigned long long* d_nonce = reinterpret_cast<unsigned long long*>(A + o_nonce);
+    std::vector<QM31> lastv;
     uint64_t nonce = ~0ull;
-    {
-        FR_HIP(ctx, hipMemsetAsync(d_nonce, 0xFF, 8, s));
+    // The whole commit phase runs on the device (transcript included) when the last layer fits the single-workgroup tail;
+    // otherwise (log_last_layer_degree_bound + log_blowup_factor > 11) the channel is evaluated on the host between layers.
+    const bool dev_channel = last_log <= k::TAIL_LOG && !ctx->host_channel;
+    if (dev_channel) {
+        DevTranscript* d_tr = reinterpret_cast<DevTranscript*>(A + o_tr);
+        const size_t hdr = offsetof(DevTranscript, last_poly);
+        {
+            DevTranscript* ht = reinterpret_cast<DevTranscript*>(ctx->pinned);
+            memset(ht, 0, hdr);
+            ht->ch = ch;
+            ht->nonce = ~0ull;
+            FR_HIP(ctx, hipMemcpyAsync(d_tr, ht, hdr, hipMemcpyHostToDevice, s));
+        }
+        // FriProver::commit_first_layer
+        k::tree_first_layer(LN, eval, N, n, A + first.o_tree, d_tr);
+        // FriProver::commit_inner_layers: layers above 2^11 points, one fused fold + tree each
+        const FriLayerDev* cur = &first;
+        bool circle = true;
+        uint32_t kx = 0;
+        while (kx < n_inner && inner[kx].log > k::TAIL_LOG) {
+            k::fold_and_tree(LN, circle, cols(*cur, 0), (size_t)1 << cur->log, cur->log, n, tw.d_itw, tw.ds, cols(inner[kx], 0),
+                             A + inner[kx].o_tree, d_tr);
+            cur = &inner[kx];
+            circle = false;
+            kx++;
+        }
+        // everything that is left, the last layer's interpolation and mix_felts included, in one workgroup
+        uint32_t* tvals[16];
+        uint8_t* ttrees[16];
+        const uint32_t n_tail = (n_inner - kx) + 1;
+        if (n_tail > 16) return ctx->fail(FRIEDA_ERR_INVARIANT, "internal: tail too long");
+        for (uint32_t i = 0; i + 1 < n_tail; i++) {
+            tvals[i] = cols(inner[kx + i], 0);
+            ttrees[i] = A + inner[kx + i].o_tree;
+        }
+        tvals[n_tail - 1] = reinterpret_cast<uint32_t*>(A + o_lastv);
+        ttrees[n_tail - 1] = nullptr;
+        k::fri_tail(LN, cols(*cur, 0), (size_t)1 << cur->log, cur->log, circle, n, tw.d_itw, tw.ds, last_log, last, n_tail, tvals, ttrees,
+                    d_tr);
+        // grind (src/proof.rs:58), keyed by the digest now sitting in the device transcript
+        const size_t n_poly = (size_t)1 << last;
+        const DevTranscript* ht = reinterpret_cast<const DevTranscript*>(ctx->pinned);
         uint64_t base = 0, chunk = (uint64_t)1 << 22;
         for (;;) {
-            k::grind_scan(LN, ch.digest, cfg.pow_bits, base, chunk, d_nonce);
-            FR_HIP(ctx, hipMemcpyAsync(ctx->pinned, d_nonce, 8, hipMemcpyDeviceToHost, s));
+            k::grind_dev(LN, d_tr, cfg.pow_bits, base, chunk);
+            FR_HIP(ctx, hipMemcpyAsync(ctx->pinned, d_tr, hdr + 16 * n_poly, hipMemcpyDeviceToHost, s));
             FR_HIP(ctx, hipStreamSynchronize(s));
-            memcpy(&nonce, ctx->pinned, 8);
-            if (nonce != ~0ull) break;
+            if (ht->status & 1u) return ctx->fail(FRIEDA_ERR_INVARIANT, "invalid degree");  // assert! upstream
+            if (ht->nonce != ~0ull) break;
             base += chunk;
             if (chunk < ((uint64_t)1 << 28)) chunk <<= 1;
         }
+        FR_HIP(ctx, hipGetLastError());
+        if (ht->n_roots != 1 + n_inner || ht->n_last_poly != n_poly) return ctx->fail(FRIEDA_ERR_INVARIANT, "internal: transcript out of step");
+        nonce = ht->nonce;
+        ch = ht->ch;
+        for (uint32_t li = 0; li <= n_inner; li++)
+            for (int w = 0; w < 8; w++)
+                for (int bb = 0; bb < 4; bb++) roots[li][4 * w + bb] = (uint8_t)(ht->roots[li][w] >> (8 * bb));
+        lastv.resize(n_poly);
+        for (size_t i = 0; i < n_poly; i++)
+            lastv[i] = {ht->last_poly[4 * i], ht->last_poly[4 * i + 1], ht->last_poly[4 * i + 2], ht->last_poly[4 * i + 3]};
+    } else {
+        auto fetch_root = [&](const FriLayerDev& lay, Hash32& root) -> int {
+            FR_HIP(ctx, hipMemcpyAsync(ctx->pinned, A + lay.o_tree + k::merkle_layer_offset(lay.log, 0), 32, hipMemcpyDeviceToHost, s));
+            FR_HIP(ctx, hipStreamSynchronize(s));
+            memcpy(root.data(), ctx->pinned, 32);
+            return FRIEDA_OK;
+        };
+
+        // ---- FriProver::commit_first_layer ----
+        k::merkle_tree4(LN, cols(first, 0), cols(first, 1), cols(first, 2), cols(first, 3), n, A + first.o_tree);
+        rc = fetch_root(first, roots[0]);
+        if (rc) return rc;
+        uint32_t rw[8];
+        hash_to_words(roots[0].data(), rw);
+        ch.mix_root(rw);
+
+        // ---- FriProver::commit_inner_layers ----
+        QM31 alpha = ch.draw_felt();
+        {
+            // LineEvaluation::new_zero then fold_circle_into_line
+            uint32_t* dst = (n_inner > 0) ? cols(inner[0], 0) : reinterpret_cast<uint32_t*>(A + o_lastv);
+            FR_HIP(ctx, hipMemsetAsync(dst, 0, sizeof(uint32_t) * 4 << (n - 1), s));
+            k::fold_circle_into_line(LN, dst, (size_t)1 << (n - 1), eval, N, n, tw.d_itw, tw.ds, k::Alpha{{alpha.a, alpha.b, alpha.c, alpha.d}});
+        }
+        for (uint32_t kx = 0; kx < n_inner; kx++) {
+            const FriLayerDev& lay = inner[kx];
+            k::merkle_tree4(LN, cols(lay, 0), cols(lay, 1), cols(lay, 2), cols(lay, 3), lay.log, A + lay.o_tree);
+            rc = fetch_root(lay, roots[kx + 1]);
+            if (rc) return rc;
+            hash_to_words(roots[kx + 1].data(), rw);
+            ch.mix_root(rw);
+            alpha = ch.draw_felt();
+            uint32_t* dst = (kx + 1 < n_inner) ? cols(inner[kx + 1], 0) : reinterpret_cast<uint32_t*>(A + o_lastv);
+            k::fold_line(LN, cols(lay, 0), (size_t)1 << lay.log, lay.log, n, tw.d_itw, tw.ds, k::Alpha{{alpha.a, alpha.b, alpha.c, alpha.d}}, dst,
+                         (size_t)1 << (lay.log - 1));
+        }
+
+        // ---- FriProver::commit_last_layer ----
+        const size_t n_lastdom = (size_t)1 << last_log;
+        FR_HIP(ctx, hipMemcpyAsync(ctx->pinned, A + o_lastv, sizeof(uint32_t) * 4 * n_lastdom, hipMemcpyDeviceToHost, s));
+        FR_HIP(ctx, hipStreamSynchronize(s));
+        lastv.assign(n_lastdom, QM31{0, 0, 0, 0});
+        {
+            const uint32_t* h = reinterpret_cast<const uint32_t*>(ctx->pinned);
+            for (size_t i = 0; i < n_lastdom; i++) lastv[i] = {h[i], h[n_lastdom + i], h[2 * n_lastdom + i], h[3 * n_lastdom + i]};
+        }
+        line_interpolate(lastv, line_coset(n, last_log));
+        bit_reverse_vec(lastv, n_lastdom, last_log);  // into_ordered_coefficients
+        const size_t n_poly = (size_t)1 << last;
+        for (size_t i = n_poly; i < n_lastdom; i++)
+            if (!qm_is_zero(lastv[i])) return ctx->fail(FRIEDA_ERR_INVARIANT, "invalid degree");  // assert! upstream
+        lastv.resize(n_poly);
+        bit_reverse_vec(lastv, n_poly, last);  // LinePoly::from_ordered_coefficients
+        channel_mix_felts(ch, lastv);
+
+        // ---- grind (src/proof.rs:58-59) ----
+        unsigned long long* d_nonce = reinterpret_cast<unsigned long long*>(A + o_nonce);
+        {
+            FR_HIP(ctx, hipMemsetAsync(d_nonce, 0xFF, 8, s));
+            uint64_t base = 0, chunk = (uint64_t)1 << 22;
+            for (;;) {
+                k::grind_scan(LN, ch.digest, cfg.pow_bits, base, chunk, d_nonce);
+                FR_HIP(ctx, hipMemcpyAsync(ctx->pinned, d_nonce, 8, hipMemcpyDeviceToHost, s));
+                FR_HIP(ctx, hipStreamSynchronize(s));
+                memcpy(&nonce, ctx->pinned, 8);
+                if (nonce != ~0ull) break;
+                base += chunk;
+                if (chunk < ((uint64_t)1 << 28)) chunk <<= 1;
+            }
+        }
     }
-    ch.mix_u64(nonce);
+    ch.mix_u64(nonce);  // src/proof.rs:59
 
     // ---- FriProver::decommit ----
     std::vector<uint32_t> queries = generate_queries(ch, n, cfg.n_queries);

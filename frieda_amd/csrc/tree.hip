@@ -1,0 +1,592 @@
+// tree.hip — the fused commit-phase kernels: multi-level Merkle subtrees with the FRI fold folded into leaf hashing,
+// the on-device Fiat–Shamir step, the single-workgroup FRI tail and the device-transcript grind (gfx950).
+//
+// Reference path: `MerkleProver::commit` over the 4 coordinate columns of each FRI layer, `FriOps::fold_*`,
+// `MerkleChannel::mix_root` + `Channel::draw_felt`, `FriProver::commit_last_layer`, `GrindOps::grind`
+// (/root/reference/src/commit.rs:17-21, src/proof.rs:52-59; stwo core/fri.rs, core/vcs/prover.rs).
+//
+// tree5_kernel   one workgroup owns 1024 consecutive level-A nodes and produces up to five tree levels (1024, 512,
+//                256, 128, 64 nodes), the intermediate levels living in LDS as struct-of-arrays (one 4-byte column per
+//                hash word, so ds_write_b32 / ds_read_b64 are bank-conflict free).  Level A is produced, by mode, from
+//                  LEAF4        the 4 SoA columns of a layer (leaf = H(c0,c1,c2,c3, 0 x 12)),
+//                  NODE         the hashes of the level below (node = H(left || right)),
+//                  FOLD_CIRCLE  / FOLD_LINE  the previous FRI layer: the fold of pair (2g, 2g+1) is computed in registers,
+//                               written to the new layer's columns and hashed at once — the folded layer is never re-read.
+//                Every level is stored (generate_proof needs the layers for decommitment) or only the last (commit).
+// top_kernel     one workgroup finishes a tree from <= 2048 hashes to the root and then, in lane 0, mixes the root into the
+//                device transcript and draws the next folding alpha.
+// tail_kernel    one workgroup runs every remaining FRI layer of <= 2048 points: fold, tree, channel, ... then interpolates
+//                the last layer (line iFFT in LDS), enforces stwo's degree assertion and mixes the polynomial.
+// grind_dev      proof-of-work scan keyed by the digest in the device transcript.
+//
+// Roofline: Blake2s compression is ~960 integer VALU instructions of which half (v_alignbit_b32, v_add3_u32) issue at
+// half rate on gfx950 (profiles/r01_valu_rate_mi355x.txt): ~1456 full-rate slots per 64 B hashed, i.e. the kernels are
+// bound by the integer VALU pipe (~38 G compressions/s chip-wide), not by HBM.
+#include <hip/hip_runtime.h>
+
+#include "blake2s.h"
+#include "dev_transcript.h"
+#include "kernels.h"
+
+namespace frieda {
+namespace k {
+
+namespace {
+
+constexpr int T5_THREADS = 256;
+constexpr uint32_t T5_UNITS = 1024;
+constexpr uint32_t T5_LEVELS = 5;
+constexpr int WG1_THREADS = 1024;  // single-workgroup kernels: more waves = lower latency on the wide levels
+
+// ---- LDS hash levels, struct-of-arrays: word w of hash j at reg[w * stride + j], stride = count + 4 (even) ----
+__device__ __forceinline__ void lds_put(uint32_t* reg, uint32_t stride, uint32_t j, const uint32_t (&h)[8]) {
+#pragma unroll
+    for (int w = 0; w < 8; w++) reg[w * stride + j] = h[w];
+}
+__device__ __forceinline__ void lds_children(const uint32_t* reg, uint32_t stride, uint32_t j, uint32_t (&m)[16]) {
+#pragma unroll
+    for (int w = 0; w < 8; w++) {
+        uint2 v = *reinterpret_cast<const uint2*>(reg + w * stride + 2 * j);
+        m[w] = v.x;
+        m[8 + w] = v.y;
+    }
+}
+__device__ __forceinline__ void store_hash(uint8_t* out, size_t i, const uint32_t (&h)[8]) {
+    uint4* o = reinterpret_cast<uint4*>(out + 32 * i);
+    o[0] = make_uint4(h[0], h[1], h[2], h[3]);
+    o[1] = make_uint4(h[4], h[5], h[6], h[7]);
+}
+__device__ __forceinline__ void load_children(const uint8_t* prev, size_t i, uint32_t (&m)[16]) {
+    const uint4* p = reinterpret_cast<const uint4*>(prev + 64 * i);
+    uint4 a = p[0], b = p[1], c = p[2], d = p[3];
+    m[0] = a.x, m[1] = a.y, m[2] = a.z, m[3] = a.w;
+    m[4] = b.x, m[5] = b.y, m[6] = b.z, m[7] = b.w;
+    m[8] = c.x, m[9] = c.y, m[10] = c.z, m[11] = c.w;
+    m[12] = d.x, m[13] = d.y, m[14] = d.z, m[15] = d.w;
+}
+// leaf of 4 column words: the twelve zero message words are compile-time constants, so their adds fold away
+__device__ __forceinline__ void leaf_hash(uint32_t v0, uint32_t v1, uint32_t v2, uint32_t v3, uint32_t (&h)[8]) {
+    const uint32_t m[16] = {v0, v1, v2, v3, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    b2_merkle_block(m, h);
+}
+__device__ __forceinline__ size_t layer_off(uint32_t tree_log, uint32_t layer) {
+    return ((size_t)64 << tree_log) - ((size_t)64 << layer);
+}
+
+__device__ __forceinline__ uint32_t inv_circle_twiddle(const uint32_t* __restrict__ itw, uint32_t n, size_t i, uint32_t inv_init_y) {
+    if (n < 3) return (i & 1u) ? m31_neg(inv_init_y) : inv_init_y;
+    size_t j = i >> 2;
+    uint32_t r = (uint32_t)(i & 3u);
+    uint32_t v = itw[2 * j + (r < 2 ? 1 : 0)];
+    return (r == 1 || r == 2) ? m31_neg(v) : v;
+}
+
+// fold of the adjacent pair (2g, 2g+1) of a 4-column SoA layer: f0 + alpha * f1 with (f0, f1) = (a + b, (a - b) * itw)
+__device__ __forceinline__ QM31 fold_pair(const uint32_t* __restrict__ src, size_t stride, size_t g, uint32_t it, const QM31& alpha) {
+    uint2 a = reinterpret_cast<const uint2*>(src)[g];
+    uint2 b = reinterpret_cast<const uint2*>(src + stride)[g];
+    uint2 c = reinterpret_cast<const uint2*>(src + 2 * stride)[g];
+    uint2 d = reinterpret_cast<const uint2*>(src + 3 * stride)[g];
+    QM31 x = {a.x, b.x, c.x, d.x}, y = {a.y, b.y, c.y, d.y};
+    QM31 f0 = qm_add(x, y), f1 = qm_scale(qm_sub(x, y), it);
+    return qm_add(f0, qm_mul(alpha, f1));
+}
+
+// lane-0 Fiat–Shamir step after a root: Blake2sMerkleChannel::mix_root, Channel::draw_felt
+__device__ void channel_after_root(DevTranscript* tr, const uint32_t (&root)[8]) {
+    Channel ch = tr->ch;
+    ch.mix_root(root);
+    QM31 al = ch.draw_felt();
+    tr->ch = ch;
+    tr->alpha[0] = al.a;
+    tr->alpha[1] = al.b;
+    tr->alpha[2] = al.c;
+    tr->alpha[3] = al.d;
+    uint32_t k = tr->n_roots;
+    if (k < DT_MAX_LAYERS) {
+#pragma unroll
+        for (int w = 0; w < 8; w++) tr->roots[k][w] = root[w];
+        tr->alphas[k][0] = al.a;
+        tr->alphas[k][1] = al.b;
+        tr->alphas[k][2] = al.c;
+        tr->alphas[k][3] = al.d;
+    }
+    tr->n_roots = k + 1;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+// tree5
+// ------------------------------------------------------------------------------------------------
+enum TreeMode { T_LEAF4 = 0, T_NODE = 1, T_FOLD_CIRCLE = 2, T_FOLD_LINE = 3 };
+
+struct TreeArgs {
+    const uint32_t* cols;    // LEAF4: this layer's columns; FOLD: the previous layer's columns
+    size_t col_stride;
+    const uint8_t* children;  // NODE: hashes of the level below A (two per A node)
+    uint32_t* out_vals;       // FOLD: the new layer's columns
+    size_t out_stride;
+    const uint32_t* itw;  // FOLD_CIRCLE: inverse table base; FOLD_LINE: the inverse level of the previous layer's domain
+    uint32_t n;           // circle domain log size
+    uint32_t inv_init_y;
+    const DevTranscript* tr;  // FOLD: alpha
+    uint32_t level_a;         // layer index of level A (2^level_a nodes in the launch)
+    uint32_t tree_log;        // log size of the tree (leaves-first offsets)
+    uint8_t* layers;          // store_all: tree storage base
+    uint8_t* last_out;        // !store_all: destination of the last produced level (indexed by global node index)
+    int store_all;
+};
+
+namespace {
+
+template <int MODE>
+__global__ __launch_bounds__(T5_THREADS) void tree5_kernel(TreeArgs a) {
+    __shared__ __attribute__((aligned(16))) uint32_t RA[8 * (T5_UNITS + 4)];
+    __shared__ __attribute__((aligned(16))) uint32_t RB[8 * (T5_UNITS / 2 + 4)];
+    const uint32_t t = threadIdx.x;
+    const size_t total_a = (size_t)1 << a.level_a;
+    const size_t wg_base = (size_t)blockIdx.x * T5_UNITS;
+    const uint32_t cnt_a = (uint32_t)(total_a - wg_base < T5_UNITS ? total_a - wg_base : T5_UNITS);  // a power of two
+    uint32_t nl = 1;
+    while (nl < T5_LEVELS && (cnt_a >> nl) >= 1) nl++;
+
+    QM31 alpha = {0, 0, 0, 0};
+    if (MODE == T_FOLD_CIRCLE || MODE == T_FOLD_LINE) alpha = {a.tr->alpha[0], a.tr->alpha[1], a.tr->alpha[2], a.tr->alpha[3]};
+
+    // ---- level A ----
+    {
+        const bool last = nl == 1;
+        uint8_t* gout = a.store_all ? a.layers + layer_off(a.tree_log, a.level_a) : (last ? a.last_out : nullptr);
+        for (uint32_t j = t; j < cnt_a; j += T5_THREADS) {
+            const size_t g = wg_base + j;
+            uint32_t h[8];
+            if (MODE == T_NODE) {
+                uint32_t m[16];
+                load_children(a.children, g, m);
+                b2_merkle_block(m, h);
+            } else if (MODE == T_LEAF4) {
+                leaf_hash(a.cols[g], a.cols[a.col_stride + g], a.cols[2 * a.col_stride + g], a.cols[3 * a.col_stride + g], h);
+            } else {
+                uint32_t it = (MODE == T_FOLD_CIRCLE) ? inv_circle_twiddle(a.itw, a.n, g, a.inv_init_y) : a.itw[g];
+                QM31 r = fold_pair(a.cols, a.col_stride, g, it, alpha);
+                a.out_vals[g] = r.a;
+                a.out_vals[a.out_stride + g] = r.b;
+                a.out_vals[2 * a.out_stride + g] = r.c;
+                a.out_vals[3 * a.out_stride + g] = r.d;
+                leaf_hash(r.a, r.b, r.c, r.d, h);
+            }
+            if (gout) store_hash(gout, g, h);
+            if (!last) lds_put(RA, cnt_a + 4, j, h);
+        }
+        __syncthreads();
+    }
+    // ---- levels B..E from LDS ----
+    for (uint32_t l = 1; l < nl; l++) {
+        const uint32_t cnt = cnt_a >> l;
+        uint32_t* dst = (l & 1) ? RB : RA;
+        const uint32_t* src = (l & 1) ? RA : RB;
+        const bool last = l + 1 == nl;
+        uint8_t* gout = a.store_all ? a.layers + layer_off(a.tree_log, a.level_a - l) : (last ? a.last_out : nullptr);
+        for (uint32_t j = t; j < cnt; j += T5_THREADS) {
+            uint32_t m[16], h[8];
+            lds_children(src, 2 * cnt + 4, j, m);
+            b2_merkle_block(m, h);
+            if (gout) store_hash(gout, (wg_base >> l) + j, h);
+            if (!last) lds_put(dst, cnt + 4, j, h);
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// single-workgroup reduction of a level held in LDS down to the root
+// ------------------------------------------------------------------------------------------------
+// `cur` holds 2^log_count hashes (SoA stride 2^log_count + 4).  Every produced level l < log_count is stored at its
+// leaves-first offset when `layers` is non-null.  On return lane 0 holds the root in `root`.
+__device__ void wg_reduce_to_root(uint32_t* cur, uint32_t* other, uint32_t log_count, uint8_t* layers, uint32_t tree_log,
+                                  uint32_t (&root)[8]) {
+    const uint32_t t = threadIdx.x;
+    for (int l = (int)log_count - 1; l >= 0; l--) {
+        const uint32_t cnt = 1u << l;
+        uint8_t* gout = layers ? layers + layer_off(tree_log, (uint32_t)l) : nullptr;
+        for (uint32_t j = t; j < cnt; j += WG1_THREADS) {
+            uint32_t m[16], h[8];
+            lds_children(cur, 2 * cnt + 4, j, m);
+            b2_merkle_block(m, h);
+            if (gout) store_hash(gout, j, h);
+            lds_put(other, cnt + 4, j, h);
+        }
+        __syncthreads();
+        uint32_t* tmp = cur;
+        cur = other;
+        other = tmp;
+    }
+    if (t == 0) {
+#pragma unroll
+        for (int w = 0; w < 8; w++) root[w] = cur[w * 5];  // stride of a 1-node level is 1 + 4
+    }
+}
+
+struct TopArgs {
+    const uint8_t* in;  // 2^l_in hashes (array of structs)
+    uint32_t l_in;      // <= 11
+    uint8_t* layers;    // non-null: store every produced level at its leaves-first offset
+    uint32_t tree_log;
+    uint8_t* root_out;  // non-null: also store the root here
+    DevTranscript* tr;  // non-null: mix the root and draw the next alpha
+};
+
+__global__ __launch_bounds__(WG1_THREADS) void top_kernel(TopArgs a) {
+    __shared__ __attribute__((aligned(16))) uint32_t R0[8 * (1024 + 4)];
+    __shared__ __attribute__((aligned(16))) uint32_t R1[8 * (512 + 4)];
+    const uint32_t t = threadIdx.x;
+    uint32_t root[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (a.l_in == 0) {
+        if (t == 0) {
+            const uint32_t* p = reinterpret_cast<const uint32_t*>(a.in);
+#pragma unroll
+            for (int w = 0; w < 8; w++) root[w] = p[w];
+        }
+    } else {
+        const uint32_t l = a.l_in - 1, cnt = 1u << l;
+        uint8_t* gout = a.layers ? a.layers + layer_off(a.tree_log, l) : nullptr;
+        for (uint32_t j = t; j < cnt; j += WG1_THREADS) {
+            uint32_t m[16], h[8];
+            load_children(a.in, j, m);
+            b2_merkle_block(m, h);
+            if (gout) store_hash(gout, j, h);
+            lds_put(R0, cnt + 4, j, h);
+        }
+        __syncthreads();
+        wg_reduce_to_root(R0, R1, l, a.layers, a.tree_log, root);
+    }
+    if (t == 0) {
+        if (a.root_out) store_hash(a.root_out, 0, root);
+        if (a.tr) channel_after_root(a.tr, root);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// FRI tail: every remaining layer of <= 2048 points in one workgroup
+// ------------------------------------------------------------------------------------------------
+constexpr uint32_t TAIL_MAX_LAYERS = 16;
+constexpr uint32_t TAIL_CAP = 2048;
+
+struct TailArgs {
+    const uint32_t* src;  // current layer (its tree is committed and the alpha for folding it is in tr)
+    size_t src_stride;
+    uint32_t src_log;
+    int src_is_circle;
+    uint32_t n;
+    const uint32_t* itw;
+    uint32_t inv_init_y;
+    uint32_t last_log;  // log size of the last layer's domain
+    uint32_t last;      // log_last_layer_degree_bound
+    uint32_t n_layers;  // folds to perform; the last one produces the last layer
+    uint32_t* vals[TAIL_MAX_LAYERS];
+    uint8_t* trees[TAIL_MAX_LAYERS];
+    DevTranscript* tr;
+};
+
+__global__ __launch_bounds__(WG1_THREADS) void tail_kernel(TailArgs a) {
+    __shared__ __attribute__((aligned(16))) uint32_t R0[8 * (TAIL_CAP + 4)];
+    __shared__ __attribute__((aligned(16))) uint32_t R1[8 * (TAIL_CAP / 2 + 4)];
+    __shared__ __attribute__((aligned(16))) uint32_t MSG[8 + 4 * DT_MAX_LAST_POLY + 16];
+    __shared__ uint32_t s_alpha[4];
+    const uint32_t t = threadIdx.x;
+    DevTranscript* tr = a.tr;
+
+    const uint32_t* src = a.src;
+    size_t src_stride = a.src_stride;
+    uint32_t src_log = a.src_log;
+    bool circle = a.src_is_circle != 0;
+
+    for (uint32_t kx = 0; kx < a.n_layers; kx++) {
+        const uint32_t m_new = src_log - 1, cnt = 1u << m_new;
+        const bool is_last = kx + 1 == a.n_layers;
+        if (t < 4) s_alpha[t] = tr->alpha[t];
+        __syncthreads();
+        const QM31 alpha = {s_alpha[0], s_alpha[1], s_alpha[2], s_alpha[3]};
+        // line layer of log size src_log sits on twiddle level n - 1 - src_log
+        const uint32_t* itw_level = circle ? a.itw : a.itw + tw_level_offset_dev(a.n, a.n - 1 - src_log);
+        uint32_t* dstv = a.vals[kx];
+        for (uint32_t j = t; j < cnt; j += WG1_THREADS) {
+            uint32_t it = circle ? inv_circle_twiddle(a.itw, a.n, j, a.inv_init_y) : itw_level[j];
+            QM31 r = fold_pair(src, src_stride, j, it, alpha);
+            dstv[j] = r.a;
+            dstv[cnt + j] = r.b;
+            dstv[2 * cnt + j] = r.c;
+            dstv[3 * cnt + j] = r.d;
+            if (!is_last) {
+                uint32_t h[8];
+                leaf_hash(r.a, r.b, r.c, r.d, h);
+                store_hash(a.trees[kx], j, h);  // leaf layer sits at offset 0
+                lds_put(R0, cnt + 4, j, h);
+            } else {
+                // keep the last layer in LDS for the interpolation: coordinate c of point j at R0[c * cnt + j]
+                R0[j] = r.a;
+                R0[cnt + j] = r.b;
+                R0[2 * cnt + j] = r.c;
+                R0[3 * cnt + j] = r.d;
+            }
+        }
+        __syncthreads();
+        if (is_last) break;
+        uint32_t root[8];
+        wg_reduce_to_root(R0, R1, m_new, a.trees[kx], m_new, root);
+        if (t == 0) channel_after_root(tr, root);
+        __syncthreads();
+        src = dstv;
+        src_stride = cnt;
+        src_log = m_new;
+        circle = false;
+    }
+
+    // ---- FriProver::commit_last_layer: LineEvaluation::interpolate (stwo core/poly/line.rs) ----
+    const uint32_t lg = a.last_log, cnt = 1u << lg;
+    // bit-reverse into natural order: W[c][i] = V[c][brev(i)]
+    uint32_t* V = R0;
+    uint32_t* W = R1;
+    for (uint32_t i = t; i < cnt; i += WG1_THREADS) {
+        uint32_t b = bit_reverse(i, lg);
+#pragma unroll
+        for (int c = 0; c < 4; c++) W[c * cnt + i] = V[c * cnt + b];
+    }
+    __syncthreads();
+    // line_ifft: for sub-domain size 2^k (k = lg .. 1): (l, r) -> (l + r, (l - r) / x_i), x_i = the i-th point of the
+    // k-log coset in natural order = inverse level n-1-k at index brev(i, k-1)
+    for (uint32_t kk = lg; kk >= 1; kk--) {
+        const uint32_t half = 1u << (kk - 1);
+        const uint32_t* lvl = a.itw + tw_level_offset_dev(a.n, a.n - 1 - kk);
+        for (uint32_t p = t; p < (cnt >> 1); p += WG1_THREADS) {
+            uint32_t i = p & (half - 1), base = (p >> (kk - 1)) << kk;
+            uint32_t it = lvl[bit_reverse(i, kk - 1)];
+            uint32_t i0 = base + i, i1 = i0 + half;
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                uint32_t l = W[c * cnt + i0], r = W[c * cnt + i1];
+                W[c * cnt + i0] = m31_add(l, r);
+                W[c * cnt + i1] = m31_mul(m31_sub(l, r), it);
+            }
+        }
+        __syncthreads();
+    }
+    // scale by 1/len = 2^(31 - lg) (2^31 == 1 mod P); W is now the coefficient vector in LinePoly's internal order.
+    // Ordered coefficient brev(j) must vanish for brev(j) >= 2^last; the kept coefficients, re-bit-reversed over `last`
+    // bits, are W[q << (lg - last)].
+    const uint32_t len_inv = (lg == 0) ? 1u : (1u << (31 - lg));
+    const uint32_t sh = lg - a.last;
+    uint32_t bad = 0;
+    for (uint32_t j = t; j < cnt; j += WG1_THREADS) {
+        uint32_t v[4];
+#pragma unroll
+        for (int c = 0; c < 4; c++) v[c] = m31_mul(W[c * cnt + j], len_inv);
+        if ((j & ((1u << sh) - 1)) == 0) {
+            uint32_t q = j >> sh;
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                MSG[8 + 4 * q + c] = v[c];
+                tr->last_poly[4 * q + c] = v[c];
+            }
+        } else if (v[0] | v[1] | v[2] | v[3]) {
+            bad = 1;
+        }
+    }
+    if (bad) atomicOr(&tr->status, 1u);
+    const uint32_t n_poly = 1u << a.last;
+    const uint32_t msg_words = 8 + 4 * n_poly;
+    for (uint32_t i = msg_words + t; i < ((msg_words + 15) / 16) * 16; i += WG1_THREADS) MSG[i] = 0;
+    __syncthreads();
+    if (t == 0) {
+        // Blake2sChannel::mix_felts(last_layer_poly)
+        Channel ch = tr->ch;
+#pragma unroll
+        for (int w = 0; w < 8; w++) MSG[w] = ch.digest[w];
+        uint32_t r[8];
+        b2s256_words(MSG, 4 * msg_words, r);
+        ch.update_digest(r);
+        tr->ch = ch;
+        tr->n_last_poly = n_poly;
+    }
+}
+
+struct GrindArgs {
+    DevTranscript* tr;
+    uint32_t pow_bits;
+    unsigned long long base, count;
+};
+
+__global__ __launch_bounds__(256) void grind_dev_kernel(GrindArgs a) {
+    unsigned long long t = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= a.count) return;
+    unsigned long long nonce = a.base + t;
+    uint32_t m[16] = {(uint32_t)nonce, (uint32_t)(nonce >> 32), 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    uint32_t h[8], r[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) h[i] = a.tr->ch.digest[i];
+    b2_compress(h, m, 0, 0, 0, 0, r);
+    uint32_t tz;
+    if (r[0])
+        tz = __ffs(r[0]) - 1;
+    else if (r[1])
+        tz = 32 + __ffs(r[1]) - 1;
+    else if (r[2])
+        tz = 64 + __ffs(r[2]) - 1;
+    else if (r[3])
+        tz = 96 + __ffs(r[3]) - 1;
+    else
+        tz = 128;
+    if (tz >= a.pow_bits) atomicMin(&a.tr->nonce, nonce);
+}
+
+void launch_tree5(const Launch& L, int mode, const TreeArgs& a, const char* name, double alg_bytes) {
+    const size_t total = (size_t)1 << a.level_a;
+    const unsigned grid = (unsigned)((total + T5_UNITS - 1) / T5_UNITS);
+    Scope scope(L, name, alg_bytes);
+    switch (mode) {
+        case T_LEAF4: tree5_kernel<T_LEAF4><<<grid, T5_THREADS, 0, L.stream>>>(a); break;
+        case T_NODE: tree5_kernel<T_NODE><<<grid, T5_THREADS, 0, L.stream>>>(a); break;
+        case T_FOLD_CIRCLE: tree5_kernel<T_FOLD_CIRCLE><<<grid, T5_THREADS, 0, L.stream>>>(a); break;
+        default: tree5_kernel<T_FOLD_LINE><<<grid, T5_THREADS, 0, L.stream>>>(a); break;
+    }
+}
+
+// levels produced by one tree5 launch whose level A has 2^level_a nodes
+uint32_t tree5_levels(uint32_t level_a) {
+    uint32_t in_wg = level_a < 10 ? level_a : 10;  // log2 of the A nodes one workgroup owns
+    return in_wg + 1 < T5_LEVELS ? in_wg + 1 : T5_LEVELS;
+}
+
+constexpr uint32_t TOP_MAX_LOG = 11;
+
+// algorithmic bytes of `levels` consecutive node levels whose first (largest) has 2^la nodes: 64 B in + 32 B out each
+double node_levels_bytes(uint32_t la, uint32_t levels) {
+    double b = 0;
+    for (uint32_t i = 0; i < levels; i++) b += 96.0 * (double)((size_t)1 << (la - i));
+    return b;
+}
+
+}  // namespace
+
+// Builds the tree of a layer whose level A is produced by `mode`; finishes with the root (and the channel step when tr).
+// `layers` non-null = keep every level (leaves-first); else only the root survives and `scratch` (>= 2 * 32 * 2^(m-4) B) is used.
+void build_tree(const Launch& L, int mode, TreeArgs a, uint32_t m, uint8_t* layers, uint8_t* scratch, uint8_t* root_out,
+                DevTranscript* tr) {
+    a.level_a = m;
+    a.tree_log = m;
+    a.layers = layers;
+    a.store_all = layers != nullptr;
+    uint8_t* s0 = scratch;
+    uint8_t* s1 = scratch ? scratch + ((size_t)32 << (m > 4 ? m - 4 : 0)) : nullptr;
+    a.last_out = s0;
+    uint32_t lv = tree5_levels(m);
+    {
+        // level A: leaves (16 B columns in, 32 B out) or fold+leaves (32 B pair in, 16 B values + 32 B hash out)
+        double bytes = (mode == T_LEAF4 ? 48.0 : 80.0) * (double)((size_t)1 << m) + node_levels_bytes(m > 0 ? m - 1 : 0, lv - 1);
+        const char* nm = mode == T_LEAF4 ? "tree5_leaf" : (mode == T_FOLD_CIRCLE ? "tree5_fold_circle" : "tree5_fold_line");
+        launch_tree5(L, mode, a, nm, bytes);
+    }
+    uint32_t cur = m - (lv - 1);  // lowest-index (smallest) level produced so far
+    const uint8_t* cur_ptr = layers ? layers + merkle_layer_offset(m, cur) : s0;
+    while (cur > TOP_MAX_LOG) {
+        TreeArgs b = a;
+        b.level_a = cur - 1;
+        b.children = cur_ptr;
+        b.last_out = (cur_ptr == s0) ? s1 : s0;
+        uint32_t l2 = tree5_levels(cur - 1);
+        launch_tree5(L, T_NODE, b, "tree5_node", node_levels_bytes(cur - 1, l2));
+        cur = cur - l2;
+        cur_ptr = layers ? layers + merkle_layer_offset(m, cur) : b.last_out;
+    }
+    TopArgs tp;
+    tp.in = cur_ptr;
+    tp.l_in = cur;
+    tp.layers = layers;
+    tp.tree_log = m;
+    tp.root_out = root_out;
+    tp.tr = tr;
+    {
+        Scope scope(L, "tree_top", node_levels_bytes(cur > 0 ? cur - 1 : 0, cur));
+        top_kernel<<<1, WG1_THREADS, 0, L.stream>>>(tp);
+    }
+}
+
+void merkle_tree4(const Launch& L, const uint32_t* c0, const uint32_t* c1, const uint32_t* c2, const uint32_t* c3, uint32_t m,
+                  uint8_t* d_layers) {
+    // columns must be equally strided for the fused kernel; the Level B entry point passes d_cols[4][2^m]
+    TreeArgs a{};
+    a.cols = c0;
+    a.col_stride = (size_t)(c1 - c0);
+    (void)c2;
+    (void)c3;
+    build_tree(L, T_LEAF4, a, m, d_layers, nullptr, nullptr, nullptr);
+}
+
+size_t merkle_root_scratch_bytes(uint32_t m) { return ((size_t)64 << (m > 4 ? m - 4 : 0)) + 256; }
+
+void merkle_root4(const Launch& L, const uint32_t* c0, const uint32_t* c1, const uint32_t* c2, const uint32_t* c3, uint32_t m,
+                  uint8_t* d_scratch, uint8_t* d_root) {
+    TreeArgs a{};
+    a.cols = c0;
+    a.col_stride = (size_t)(c1 - c0);
+    (void)c2;
+    (void)c3;
+    build_tree(L, T_LEAF4, a, m, nullptr, d_scratch, d_root, nullptr);
+}
+
+void tree_first_layer(const Launch& L, const uint32_t* cols, size_t stride, uint32_t m, uint8_t* layers, DevTranscript* tr) {
+    TreeArgs a{};
+    a.cols = cols;
+    a.col_stride = stride;
+    build_tree(L, T_LEAF4, a, m, layers, nullptr, nullptr, tr);
+}
+
+void fold_and_tree(const Launch& L, bool circle, const uint32_t* src, size_t src_stride, uint32_t src_log, uint32_t n,
+                   const uint32_t* d_itw, DomainScalars ds, uint32_t* dst_vals, uint8_t* layers, DevTranscript* tr) {
+    const uint32_t m = src_log - 1;
+    TreeArgs a{};
+    a.cols = src;
+    a.col_stride = src_stride;
+    a.out_vals = dst_vals;
+    a.out_stride = (size_t)1 << m;
+    a.itw = circle ? d_itw : d_itw + tw_level_offset(n, n - 1 - src_log);
+    a.n = n;
+    a.inv_init_y = ds.inv_init_y;
+    a.tr = tr;
+    build_tree(L, circle ? T_FOLD_CIRCLE : T_FOLD_LINE, a, m, layers, nullptr, nullptr, tr);
+}
+
+void fri_tail(const Launch& L, const uint32_t* src, size_t src_stride, uint32_t src_log, bool src_is_circle, uint32_t n,
+              const uint32_t* d_itw, DomainScalars ds, uint32_t last_log, uint32_t last, uint32_t n_layers, uint32_t* const* vals,
+              uint8_t* const* trees, DevTranscript* tr) {
+    TailArgs a{};
+    a.src = src;
+    a.src_stride = src_stride;
+    a.src_log = src_log;
+    a.src_is_circle = src_is_circle ? 1 : 0;
+    a.n = n;
+    a.itw = d_itw;
+    a.inv_init_y = ds.inv_init_y;
+    a.last_log = last_log;
+    a.last = last;
+    a.n_layers = n_layers;
+    for (uint32_t i = 0; i < n_layers && i < TAIL_MAX_LAYERS; i++) {
+        a.vals[i] = vals[i];
+        a.trees[i] = trees[i];
+    }
+    a.tr = tr;
+    double bytes = 0;
+    for (uint32_t i = 0; i < n_layers; i++) bytes += 168.0 * (double)((size_t)1 << (src_log - 1 - i));
+    Scope scope(L, "fri_tail", bytes);
+    tail_kernel<<<1, WG1_THREADS, 0, L.stream>>>(a);
+}
+
+void grind_dev(const Launch& L, DevTranscript* tr, uint32_t pow_bits, uint64_t base, uint64_t count) {
+    GrindArgs a{tr, pow_bits, base, count};
+    Scope scope(L, "grind", 0.0);
+    grind_dev_kernel<<<(unsigned)((count + 255) / 256), 256, 0, L.stream>>>(a);
+}
+
+}  // namespace k
+}  // namespace frieda

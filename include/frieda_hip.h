@@ -65,6 +65,11 @@ int frieda_ctx_synchronize(frieda_ctx* ctx);
  * them on every call as the reference does (src/commit.rs:15) */
 int frieda_ctx_set_twiddle_cache(frieda_ctx* ctx, int enabled);
 
+/* transcript policy: 0 (default) the Fiat-Shamir channel of generate_proof runs on the device inside the commit-phase
+ * kernels; 1 evaluates it on the host between layers (one 32-byte D2H + synchronise per layer).  Proofs are identical;
+ * configurations whose last FRI layer exceeds 2^11 points always use the host policy. */
+int frieda_ctx_set_host_channel(frieda_ctx* ctx, int enabled);
+
 /* measurement aid: when enabled, HIP events are recorded on the ctx stream around every kernel launch.
  * frieda_ctx_kernel_timing_report synchronises the stream and writes a JSON object
  * {"kernels": [{"name", "launches", "total_ms", "alg_bytes"}]} (alg_bytes = algorithmic HBM bytes by the byte model

@@ -41,6 +41,15 @@ __global__ __launch_bounds__(256) void rate_kernel(uint32_t* out, int iters) {
                 if (OP == 11) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(*reinterpret_cast<uint64_t*>(&pk[i])) : "v"(pk[(i + 1) & 7]), "v"(pk[(i + 2) & 7]));
                 if (OP == 12) asm volatile("v_lshl_add_u32 %0, %0, 3, %1" : "+v"(x) : "v"(y));
                 if (OP == 13) asm volatile("v_bfi_b32 %0, %0, %1, %2" : "+v"(x) : "v"(y), "v"(z));
+                if (OP == 14) asm volatile("v_xor_b32_sdwa %0, %1, %2 dst_sel:WORD_0 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1 src1_sel:WORD_1" : "+v"(x) : "v"(y), "v"(z));
+                if (OP == 15) asm volatile("v_xor_b32_dpp %0, %1, %2 quad_perm:[1,2,3,0] row_mask:0xf bank_mask:0xf" : "+v"(x) : "v"(y), "v"(z));
+                if (OP == 16) asm volatile("v_lshlrev_b32 %0, 7, %0" : "+v"(x));
+                if (OP == 17) asm volatile("v_or_b32 %0, %0, %1" : "+v"(x) : "v"(y));
+                if (OP == 18) asm volatile("v_sub_u32 %0, %0, %1" : "+v"(x) : "v"(y));
+                if (OP == 19) asm volatile("v_and_b32 %0, %0, %1" : "+v"(x) : "v"(y));
+                if (OP == 20) asm volatile("v_mov_b32_dpp %0, %1 quad_perm:[1,2,3,0] row_mask:0xf bank_mask:0xf" : "+v"(x) : "v"(y));
+                if (OP == 21) asm volatile("v_add_u32_dpp %0, %1, %2 quad_perm:[1,2,3,0] row_mask:0xf bank_mask:0xf" : "+v"(x) : "v"(y), "v"(z));
+                if (OP == 22) asm volatile("v_alignbyte_b32 %0, %0, %0, 1" : "+v"(x));
             }
         }
     }
@@ -86,5 +95,14 @@ int main() {
     run<11>("v_pk_fma_f32 (2 lanes-ops)", 2);
     run<12>("v_lshl_add_u32", 1);
     run<13>("v_bfi_b32", 1);
+    run<14>("v_xor_b32_sdwa", 1);
+    run<15>("v_xor_b32_dpp quad_perm", 1);
+    run<16>("v_lshlrev_b32", 1);
+    run<17>("v_or_b32", 1);
+    run<18>("v_sub_u32", 1);
+    run<19>("v_and_b32", 1);
+    run<20>("v_mov_b32_dpp quad_perm", 1);
+    run<21>("v_add_u32_dpp quad_perm", 1);
+    run<22>("v_alignbyte_b32", 1);
     return 0;
 }
