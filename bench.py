@@ -174,6 +174,7 @@ def main():
         ctx.synchronize()
         root = bytes(roots_dev.cpu().numpy())
 
+    host_phases = ctx.last_prove_phases() if args.workload == "prove" else None
     elems = 4.0 * (1 << n)
     value = world * elems * args.steps / dt
 
@@ -232,6 +233,7 @@ def main():
             "achieved_GBps_wall": path_bytes / (dt / args.steps) / 1e9,
             "frac_of_hbm_peak_wall": path_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS,
             "gpu_kernel_ms_per_step": gpu_ms,
+            "host_phase_marks_ms_last_step": host_phases,
             "frac_of_hbm_peak_kernels": (path_bytes / (gpu_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if gpu_ms > 0 else None,
             "kernels": [
                 {"name": k["name"], "ms_per_step": k["total_ms"] / args.steps, "launches_per_step": k["launches"] / args.steps} for k in kern

@@ -65,6 +65,7 @@ def lib():
         "frieda_ctx_set_twiddle_cache": (C.c_int, [vp, C.c_int]),
         "frieda_ctx_set_host_channel": (C.c_int, [vp, C.c_int]),
         "frieda_ctx_set_kernel_timing": (C.c_int, [vp, C.c_int]),
+        "frieda_ctx_last_prove_phases": (C.c_int, [vp, C.POINTER(C.c_double)]),
         "frieda_ctx_kernel_timing_report": (sz, [vp, vp, sz, C.c_int]),
         "frieda_commit": (C.c_int, [vp, vp, sz, u32, vp]),
         "frieda_commit_device": (C.c_int, [vp, vp, sz, u32, vp]),

@@ -103,6 +103,12 @@ class Context:
     def set_kernel_timing(self, enabled):
         _check(self._L.frieda_ctx_set_kernel_timing(self._h, int(bool(enabled))), self._h)
 
+    def last_prove_phases(self):
+        """Host wall-clock marks (ms since entry) of the last generate_proof: enqueued, device done, queries, gather, assembled."""
+        a = (C.c_double * 8)()
+        _check(self._L.frieda_ctx_last_prove_phases(self._h, a), self._h)
+        return dict(zip(["enqueued", "device_done", "queries", "gathered", "assembled"], list(a)[:5]))
+
     def kernel_timing_report(self, reset=True):
         """Per-kernel HIP-event timings accumulated since the last reset: list of dicts."""
         import json

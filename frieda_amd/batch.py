@@ -1,0 +1,48 @@
+"""Batch data-parallelism over independent blobs: one process per GPU, blob i -> rank i mod world, no
+data-path collective; the only exchange is an all_gather of the 32-byte commitment roots (RCCL over xGMI with the nccl
+backend; gloo on CPU in the tests).
+
+`commit_fn(blob) -> bytes[32]` is injected so that the sharding / gather logic is testable without a GPU; the default is the
+HIP path of this package (there is no CPU fallback).
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_indices(n_blobs, rank, world):
+    """Blob indices owned by `rank`: round-robin (blob i -> rank i mod world)."""
+    return list(range(rank, n_blobs, world))
+
+
+def commit_batch(blobs, log_blowup_factor, commit_fn=None, device=None):
+    """Every rank passes the same list of blobs (or at least its own entries); returns the list of all roots, in blob order,
+    on every rank."""
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    if commit_fn is None:
+        from . import api
+
+        ctx = api.default_context()
+        commit_fn = lambda b: ctx.commit(b, log_blowup_factor)  # noqa: E731
+    n = len(blobs)
+    mine = shard_indices(n, rank, world)
+    per_rank = (n + world - 1) // world
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device()) if (dist.is_initialized() and dist.get_backend() == "nccl") else torch.device("cpu")
+    local = torch.zeros(per_rank * 32, dtype=torch.uint8, device=device)
+    for slot, i in enumerate(mine):
+        root = commit_fn(blobs[i])
+        assert len(root) == 32
+        local[32 * slot : 32 * slot + 32] = torch.frombuffer(bytearray(root), dtype=torch.uint8).to(device)
+    if world > 1:
+        gathered = torch.zeros(world * per_rank * 32, dtype=torch.uint8, device=device)
+        dist.all_gather_into_tensor(gathered, local)
+    else:
+        gathered = local
+    flat = gathered.cpu().numpy().tobytes()
+    roots = [None] * n
+    for r in range(world):
+        for slot, i in enumerate(shard_indices(n, r, world)):
+            off = (r * per_rank + slot) * 32
+            roots[i] = flat[off : off + 32]
+    return roots

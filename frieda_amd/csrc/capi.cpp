@@ -93,6 +93,12 @@ int frieda_ctx_set_host_channel(frieda_ctx* ctx, int enabled) {
     return FRIEDA_OK;
 }
 
+int frieda_ctx_last_prove_phases(const frieda_ctx* ctx, double out_ms[8]) {
+    if (!ctx || !out_ms) return FRIEDA_ERR_ARG;
+    for (int i = 0; i < 8; i++) out_ms[i] = ctx->c.phase_ms[i];
+    return FRIEDA_OK;
+}
+
 int frieda_ctx_set_kernel_timing(frieda_ctx* ctx, int enabled) {
     if (!ctx) return FRIEDA_ERR_ARG;
     FR_GUARD_BEGIN

@@ -83,6 +83,7 @@ struct Ctx {
     void* pinned = nullptr;  // small pinned staging block for D2H of roots / nonces
     size_t pinned_bytes = 0;
     std::string err;
+    double phase_ms[8] = {0};  // host wall-clock marks of the last prove() (ms since entry): enqueued, device done, queries, gather, assembled
     KernelTimerImpl* timer = nullptr;  // non-null while kernel timing is enabled
 
     k::Launch launch() const;

@@ -11,11 +11,20 @@
 // butterflies against zero: they only replicate the coefficient block 2^(n-L) times.  They are never
 // executed — the first real pass reads coefficient `idx mod 2^L` instead.
 //
-// Passes.  A pass executes a run of layers i_hi..i_lo on tiles held in LDS: the tile is the 2^t (t =
-// i_hi-i_lo+1) values of bits [i_lo, i_hi] times 2^log_w consecutive values of the low bits (so that global
-// accesses are 2^log_w-word contiguous runs), all other index bits fixed per workgroup.  The last pass has
-// i_lo = 0 and reads/writes fully contiguous tiles.  HBM traffic per pass: 4 B read + 4 B written per
-// element; all 4 columns share the twiddle tables (grid.y = column).
+// Passes.  A pass executes a run of layers i_hi..i_lo on a 4096-word tile per column held in LDS: the tile is
+// the 2^t (t = i_hi-i_lo+1) values of index bits [i_lo, i_hi] times 2^log_w consecutive values of the low bits
+// (so global accesses are 64-byte runs), all other index bits fixed per workgroup.  The last pass has i_lo = 0
+// and reads/writes fully contiguous 16 KiB tiles with 16-byte accesses.
+//
+// Stages.  Inside a pass the layers are executed four at a time: a thread reads the 16 tile elements that differ
+// in the stage's four index bits into registers, runs 4 x 8 butterflies on them, and writes them back — three LDS
+// round trips for 12 layers instead of twelve.  The 15 twiddles of a stage depend only on the other index bits, so
+// they are fetched once and reused for all columns of the workgroup (the 4 coordinate columns share the domain).
+// LDS addresses are padded by idx >> 4, which makes every stage's 32-lane access conflict free.
+//
+// Cost.  One butterfly = v_mad_u64_u32 + Mersenne fold + two modular add/sub = 17 full-rate VALU slots (multiplies,
+// v_alignbit and v_min are half rate on gfx950); 4 columns x L x N/2 butterflies make the encode VALU-bound at about
+// twice its HBM time.
 #include <hip/hip_runtime.h>
 
 #include "kernels.h"
@@ -26,6 +35,12 @@ namespace k {
 namespace {
 
 constexpr int NTT_THREADS = 256;
+constexpr uint32_t TILE_LOG = 12;
+constexpr uint32_t TILE_WORDS = (1u << TILE_LOG) + (1u << (TILE_LOG - 4));  // padded
+constexpr uint32_t MAX_COLS_PER_WG = 4;
+constexpr uint32_t MID_LOG_W = 4;  // 64-byte contiguous runs in the strided passes
+
+__device__ __forceinline__ uint32_t pad(uint32_t e) { return e + (e >> 4); }
 
 // circle-layer twiddle Y[h] from the first line level: pairs (x, y) -> [y, -y, -x, x]
 __device__ __forceinline__ uint32_t circle_twiddle(const uint32_t* __restrict__ tw, uint32_t n, uint32_t h, uint32_t init_y) {
@@ -35,48 +50,131 @@ __device__ __forceinline__ uint32_t circle_twiddle(const uint32_t* __restrict__ 
     return (r == 1 || r == 2) ? m31_neg(v) : v;
 }
 
-__global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(const uint32_t* __restrict__ in, size_t in_stride,
-                                                               uint32_t in_mask, uint32_t* __restrict__ out,
-                                                               size_t out_stride, const uint32_t* __restrict__ tw,
-                                                               uint32_t n, uint32_t i_hi, uint32_t i_lo, uint32_t log_w,
-                                                               uint32_t init_y) {
+struct NttArgs {
+    const uint32_t* in;
+    size_t in_stride;
+    uint32_t in_mask;
+    uint32_t* out;
+    size_t out_stride;
+    const uint32_t* tw;
+    uint32_t n, i_hi, i_lo, log_w, init_y;
+    uint32_t ncols;       // columns handled by one workgroup (<= 4); grid.y strides over groups of this many
+    uint32_t n_stages;    // <= 3
+    uint32_t stage_r[3];  // layers per stage, top stage first
+};
+
+// One stage of R layers on tile bits [lo, lo + R): every thread processes groups of 2^R elements.
+template <int R>
+__device__ __forceinline__ void run_stage(uint32_t* lds, const NttArgs& a, uint32_t tb, uint32_t lo, uint32_t hblk) {
+    constexpr int E = 1 << R;
+    const uint32_t n_groups = 1u << (tb - R);
+    for (uint32_t g = threadIdx.x; g < n_groups; g += NTT_THREADS) {
+        const uint32_t base = ((g >> lo) << (lo + R)) | (g & ((1u << lo) - 1));
+        // twiddles: layer q of the stage acts on tile bit b = lo + R - 1 - q, global layer i = i_lo + b - log_w
+        uint32_t twd[E - 1];
+#pragma unroll
+        for (int q = 0; q < R; q++) {
+            const uint32_t b = lo + R - 1 - q;
+            const uint32_t i = a.i_lo + b - a.log_w;
+            const uint32_t hbase = (hblk << (a.i_hi - i)) | (base >> (b + 1));
+#pragma unroll
+            for (int u = 0; u < (1 << q); u++) {
+                const uint32_t h = hbase | (uint32_t)u;
+                twd[(1 << q) - 1 + u] = (i >= 1) ? a.tw[tw_level_offset_dev(a.n, i - 1) + h] : circle_twiddle(a.tw, a.n, h, a.init_y);
+            }
+        }
+        for (uint32_t c = 0; c < a.ncols; c++) {
+            uint32_t* col = lds + c * TILE_WORDS;
+            uint32_t x[E];
+#pragma unroll
+            for (int r = 0; r < E; r++) x[r] = col[pad(base | ((uint32_t)r << lo))];
+#pragma unroll
+            for (int q = 0; q < R; q++) {
+                const int bit = R - 1 - q;
+#pragma unroll
+                for (int r = 0; r < E; r++) {
+                    if (r & (1 << bit)) continue;
+                    const int u = r >> (bit + 1);
+                    const uint32_t t = m31_mul(x[r | (1 << bit)], twd[(1 << q) - 1 + u]);
+                    const uint32_t v = x[r];
+                    x[r] = m31_add(v, t);
+                    x[r | (1 << bit)] = m31_sub(v, t);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < E; r++) col[pad(base | ((uint32_t)r << lo))] = x[r];
+        }
+    }
+}
+
+__global__ __launch_bounds__(NTT_THREADS) void ntt_tile_kernel(NttArgs a) {
     extern __shared__ uint32_t lds[];
-    const uint32_t t = i_hi - i_lo + 1;
-    const uint32_t tile_log = t + log_w;
-    const uint32_t tile = 1u << tile_log;
-    const uint32_t wmask = (1u << log_w) - 1;
-    const uint32_t nwb_log = i_lo - log_w;  // number of w-blocks per (hblk) = 2^(i_lo - log_w)
+    const uint32_t t = a.i_hi - a.i_lo + 1;
+    const uint32_t tb = t + a.log_w;  // tile bits (<= 12)
+    const uint32_t tile = 1u << tb;
+    const uint32_t wmask = (1u << a.log_w) - 1;
+    const uint32_t nwb_log = a.i_lo - a.log_w;
     const uint32_t wblk = blockIdx.x & ((1u << nwb_log) - 1);
     const uint32_t hblk = blockIdx.x >> nwb_log;
-    const uint32_t gbase = (hblk << (i_hi + 1)) | (wblk << log_w);
-    in += (size_t)blockIdx.y * in_stride;
-    out += (size_t)blockIdx.y * out_stride;
+    const uint32_t gbase = (hblk << (a.i_hi + 1)) | (wblk << a.log_w);
+    const size_t col0 = (size_t)blockIdx.y * a.ncols;
+    const uint32_t* in = a.in + col0 * a.in_stride;
+    uint32_t* out = a.out + col0 * a.out_stride;
+    // 16-byte global accesses need 4-word runs: tiles of >= 4 words whose low run (2^log_w, or the whole tile when
+    // log_w == 0) is a multiple of 4, and 16-byte aligned column bases
+    const bool vec = tb >= 2 && (a.log_w == 0 || a.log_w >= 2) && ((a.in_stride | a.out_stride) & 3) == 0 &&
+                     ((reinterpret_cast<uintptr_t>(a.in) | reinterpret_cast<uintptr_t>(a.out)) & 15) == 0 && (a.in_mask & 3u) == 3u;
 
-    for (uint32_t e = threadIdx.x; e < tile; e += NTT_THREADS) {
-        uint32_t g = gbase | ((e >> log_w) << i_lo) | (e & wmask);
-        lds[e] = in[g & in_mask];
+    for (uint32_t c = 0; c < a.ncols; c++) {
+        uint32_t* col = lds + c * TILE_WORDS;
+        const uint32_t* src = in + c * a.in_stride;
+        if (vec) {
+            for (uint32_t e = 4 * threadIdx.x; e < tile; e += 4 * NTT_THREADS) {
+                uint32_t g = gbase | ((e >> a.log_w) << a.i_lo) | (e & wmask);
+                uint4 v = *reinterpret_cast<const uint4*>(src + (g & a.in_mask));
+                uint32_t p = pad(e);  // e is a multiple of 4: the four words stay inside one 16-word group
+                col[p] = v.x;
+                col[p + 1] = v.y;
+                col[p + 2] = v.z;
+                col[p + 3] = v.w;
+            }
+        } else {
+            for (uint32_t e = threadIdx.x; e < tile; e += NTT_THREADS) {
+                uint32_t g = gbase | ((e >> a.log_w) << a.i_lo) | (e & wmask);
+                col[pad(e)] = src[g & a.in_mask];
+            }
+        }
     }
     __syncthreads();
 
-    for (int i = (int)i_hi; i >= (int)i_lo; i--) {
-        const uint32_t s = (uint32_t)i - i_lo;
-        const uint32_t* lvl = (i >= 1) ? tw + tw_level_offset_dev(n, (uint32_t)i - 1) : tw;
-        for (uint32_t b = threadIdx.x; b < (tile >> 1); b += NTT_THREADS) {
-            uint32_t w = b & wmask, bj = b >> log_w;
-            uint32_t j0 = ((bj >> s) << (s + 1)) | (bj & ((1u << s) - 1));
-            uint32_t h = (hblk << (i_hi - (uint32_t)i)) | (j0 >> (s + 1));
-            uint32_t twv = (i >= 1) ? lvl[h] : circle_twiddle(tw, n, h, init_y);
-            uint32_t e0 = (j0 << log_w) | w, e1 = e0 + (1u << (s + log_w));
-            uint32_t a = lds[e0], tt = m31_mul(lds[e1], twv);
-            lds[e0] = m31_add(a, tt);
-            lds[e1] = m31_sub(a, tt);
+    uint32_t top = tb;  // one past the top tile bit of the next stage
+    for (uint32_t s = 0; s < a.n_stages; s++) {
+        const uint32_t r = a.stage_r[s], lo = top - r;
+        switch (r) {
+            case 4: run_stage<4>(lds, a, tb, lo, hblk); break;
+            case 3: run_stage<3>(lds, a, tb, lo, hblk); break;
+            case 2: run_stage<2>(lds, a, tb, lo, hblk); break;
+            default: run_stage<1>(lds, a, tb, lo, hblk); break;
         }
+        top = lo;
         __syncthreads();
     }
 
-    for (uint32_t e = threadIdx.x; e < tile; e += NTT_THREADS) {
-        uint32_t g = gbase | ((e >> log_w) << i_lo) | (e & wmask);
-        out[g] = lds[e];
+    for (uint32_t c = 0; c < a.ncols; c++) {
+        const uint32_t* col = lds + c * TILE_WORDS;
+        uint32_t* dst = out + c * a.out_stride;
+        if (vec) {
+            for (uint32_t e = 4 * threadIdx.x; e < tile; e += 4 * NTT_THREADS) {
+                uint32_t g = gbase | ((e >> a.log_w) << a.i_lo) | (e & wmask);
+                uint32_t p = pad(e);
+                *reinterpret_cast<uint4*>(dst + g) = make_uint4(col[p], col[p + 1], col[p + 2], col[p + 3]);
+            }
+        } else {
+            for (uint32_t e = threadIdx.x; e < tile; e += NTT_THREADS) {
+                uint32_t g = gbase | ((e >> a.log_w) << a.i_lo) | (e & wmask);
+                dst[g] = col[pad(e)];
+            }
+        }
     }
 }
 
@@ -87,9 +185,17 @@ __global__ void ntt_broadcast_kernel(const uint32_t* __restrict__ in, size_t in_
     if (i < n_out) out[(size_t)blockIdx.y * out_stride + i] = in[(size_t)blockIdx.y * in_stride];
 }
 
-constexpr uint32_t LAST_PASS_MAX_LOG = 12;  // 16 KiB tile
-constexpr uint32_t MID_PASS_MAX_LOG = 8;    // 2^8 x 16 words = 16 KiB tile
-constexpr uint32_t MID_LOG_W = 4;           // 64-byte contiguous runs
+void set_stages(NttArgs& a, uint32_t t) {
+    // split t layers into ceil(t / 4) stages of nearly equal size, larger first
+    uint32_t ns = (t + 3) / 4;
+    a.n_stages = ns;
+    uint32_t left = t;
+    for (uint32_t s = 0; s < ns; s++) {
+        uint32_t r = (left + (ns - s) - 1) / (ns - s);
+        a.stage_r[s] = r;
+        left -= r;
+    }
+}
 
 }  // namespace
 
@@ -98,7 +204,7 @@ void circle_evaluate(const Launch& L_, const uint32_t* d_coef, size_t coef_strid
     const size_t N = (size_t)1 << n;
     hipStream_t s = L_.stream;
     // algorithmic bytes of the encode: read 2^L, write 2^n words per column (16N(1 + 2^-B) for 4 columns),
-    // attributed to the passes in proportion to the elements they move
+    // split evenly over the passes
     const double enc_bytes = 4.0 * ncols * ((double)N + (double)((size_t)1 << L));
     if (L == 0) {
         Scope scope(L_, "ntt_broadcast", enc_bytes);
@@ -106,36 +212,56 @@ void circle_evaluate(const Launch& L_, const uint32_t* d_coef, size_t coef_strid
         ntt_broadcast_kernel<<<grid, 256, 0, s>>>(d_coef, coef_stride, d_out, out_stride, N);
         return;
     }
-    // real layers i = L-1 .. 0; the last pass takes up to LAST_PASS_MAX_LOG of them, the earlier passes split the rest
-    uint32_t last_t = L < LAST_PASS_MAX_LOG ? L : LAST_PASS_MAX_LOG;
+    // columns per workgroup: the largest divisor of ncols that is <= 4 (the 4 coordinate columns share every twiddle)
+    uint32_t cpw = MAX_COLS_PER_WG;
+    while (ncols % cpw) cpw--;
+    const size_t lds_bytes = (size_t)cpw * TILE_WORDS * sizeof(uint32_t);
+    static bool lds_opt_in = false;  // 4 column tiles = 68 KiB of dynamic LDS: above the 64 KiB default
+    if (!lds_opt_in) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ntt_tile_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)(MAX_COLS_PER_WG * TILE_WORDS * sizeof(uint32_t)));
+        lds_opt_in = true;
+    }
+
+    // real layers i = L-1 .. 0; the last pass takes up to 12 of them, the strided passes before it up to 8 each
+    const uint32_t last_t = L < TILE_LOG ? L : TILE_LOG;
     uint32_t rest = L - last_t;
-    uint32_t n_mid = (rest + MID_PASS_MAX_LOG - 1) / MID_PASS_MAX_LOG;
-    const uint32_t* src = d_coef;
-    size_t src_stride = coef_stride;
-    uint32_t src_mask = (uint32_t)(((size_t)1 << L) - 1);
+    const uint32_t mid_max = TILE_LOG - MID_LOG_W;
+    const uint32_t n_mid = (rest + mid_max - 1) / mid_max;
+    NttArgs a{};
+    a.in = d_coef;
+    a.in_stride = coef_stride;
+    a.in_mask = (uint32_t)(((size_t)1 << L) - 1);
+    a.out = d_out;
+    a.out_stride = out_stride;
+    a.tw = d_tw;
+    a.n = n;
+    a.init_y = ds.init_y;
+    a.ncols = cpw;
     uint32_t i_hi = L - 1;
     for (uint32_t p = 0; p < n_mid; p++) {
-        uint32_t t = (rest + (n_mid - p) - 1) / (n_mid - p);  // even split of what is left
-        uint32_t i_lo = i_hi + 1 - t;
-        uint32_t log_w = MID_LOG_W;  // i_lo >= last_t >= MID_LOG_W whenever a mid pass exists (L > 12)
-        dim3 grid((unsigned)(N >> (t + log_w)), ncols);
-        size_t lds_bytes = (size_t)4 << (t + log_w);
+        uint32_t t = (rest + (n_mid - p) - 1) / (n_mid - p);
+        a.i_hi = i_hi;
+        a.i_lo = i_hi + 1 - t;
+        a.log_w = MID_LOG_W;  // i_lo >= last_t = 12 >= log_w whenever a strided pass exists
+        set_stages(a, t);
+        dim3 grid((unsigned)(N >> (t + a.log_w)), ncols / cpw);
         Scope scope(L_, "ntt_pass_mid", enc_bytes / (n_mid + 1));
-        ntt_pass_kernel<<<grid, NTT_THREADS, lds_bytes, s>>>(src, src_stride, src_mask, d_out, out_stride, d_tw, n, i_hi, i_lo,
-                                                            log_w, ds.init_y);
-        src = d_out;
-        src_stride = out_stride;
-        src_mask = (uint32_t)(N - 1);
+        ntt_tile_kernel<<<grid, NTT_THREADS, lds_bytes, s>>>(a);
+        a.in = d_out;
+        a.in_stride = out_stride;
+        a.in_mask = (uint32_t)(N - 1);
         rest -= t;
-        i_hi = i_lo - 1;
+        i_hi = a.i_lo - 1;
     }
     {
-        uint32_t t = last_t;  // i_hi == t - 1, i_lo == 0
-        dim3 grid((unsigned)(N >> t), ncols);
-        size_t lds_bytes = (size_t)4 << t;
+        a.i_hi = i_hi;  // == last_t - 1
+        a.i_lo = 0;
+        a.log_w = 0;
+        set_stages(a, last_t);
+        dim3 grid((unsigned)(N >> last_t), ncols / cpw);
         Scope scope(L_, "ntt_pass_last", enc_bytes / (n_mid + 1));
-        ntt_pass_kernel<<<grid, NTT_THREADS, lds_bytes, s>>>(src, src_stride, src_mask, d_out, out_stride, d_tw, n, i_hi, 0, 0,
-                                                            ds.init_y);
+        ntt_tile_kernel<<<grid, NTT_THREADS, lds_bytes, s>>>(a);
     }
 }
 

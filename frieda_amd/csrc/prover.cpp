@@ -11,6 +11,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
 
 #include <stddef.h>
 
@@ -282,6 +283,11 @@ int prove(Ctx* ctx, const uint8_t* data, size_t len, bool data_on_device, const 
     rc = ctx->get_twiddles(n, tw);
     if (rc) return rc;
     hipStream_t s = ctx->stream;
+    const auto t_start = std::chrono::steady_clock::now();
+    auto ms_since = [](std::chrono::steady_clock::time_point t0) {
+        return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    };
+    for (double& v : ctx->phase_ms) v = 0.0;
     const k::Launch LN = ctx->launch();
     uint8_t* A = ctx->arena;
 
@@ -348,6 +354,7 @@ int prove(Ctx* ctx, const uint8_t* data, size_t len, bool data_on_device, const 
         const DevTranscript* ht = reinterpret_cast<const DevTranscript*>(ctx->pinned);
         uint64_t base = 0, chunk = (uint64_t)1 << 22;
         for (;;) {
+            if (base == 0) ctx->phase_ms[0] = ms_since(t_start);  // commit phase fully enqueued
             k::grind_dev(LN, d_tr, cfg.pow_bits, base, chunk);
             FR_HIP(ctx, hipMemcpyAsync(ctx->pinned, d_tr, hdr + 16 * n_poly, hipMemcpyDeviceToHost, s));
             FR_HIP(ctx, hipStreamSynchronize(s));
@@ -437,10 +444,12 @@ int prove(Ctx* ctx, const uint8_t* data, size_t len, bool data_on_device, const 
             }
         }
     }
+    ctx->phase_ms[1] = ms_since(t_start);  // commit phase + grind complete on the device (first synchronise)
     ch.mix_u64(nonce);  // src/proof.rs:59
 
     // ---- FriProver::decommit ----
     std::vector<uint32_t> queries = generate_queries(ch, n, cfg.n_queries);
+    ctx->phase_ms[2] = ms_since(t_start);  // queries drawn
     GatherPlan g;
     // Proof.evaluations (src/proof.rs:62-66)
     for (uint32_t q : queries)
@@ -470,6 +479,7 @@ int prove(Ctx* ctx, const uint8_t* data, size_t len, bool data_on_device, const 
     if (!g.hash_idx.empty()) FR_HIP(ctx, hipMemcpyAsync(hp + wbytes, A + o_hout, 32 * g.hash_idx.size(), hipMemcpyDeviceToHost, s));
     FR_HIP(ctx, hipStreamSynchronize(s));
     FR_HIP(ctx, hipGetLastError());
+    ctx->phase_ms[3] = ms_since(t_start);  // gather done (second and last synchronise)
 
     // ---- assemble Proof (src/proof.rs:67-76) ----
     const uint32_t* wv = reinterpret_cast<const uint32_t*>(hp);
@@ -499,6 +509,7 @@ int prove(Ctx* ctx, const uint8_t* data, size_t len, bool data_on_device, const 
             hi++;
         }
     }
+    ctx->phase_ms[4] = ms_since(t_start);  // proof assembled
     memcpy(out_commitment, roots[0].data(), 32);
     return FRIEDA_OK;
 }

@@ -421,6 +421,9 @@ __global__ __launch_bounds__(256) void grind_dev_kernel(GrindArgs a) {
     unsigned long long t = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
     if (t >= a.count) return;
     unsigned long long nonce = a.base + t;
+    // a smaller qualifying nonce is already known: nothing this lane finds can lower the minimum (workgroups are
+    // dispatched roughly in index order, so the scan stops soon after the first hit instead of finishing the chunk)
+    if (__hip_atomic_load(&a.tr->nonce, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < nonce) return;
     uint32_t m[16] = {(uint32_t)nonce, (uint32_t)(nonce >> 32), 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     uint32_t h[8], r[8];
 #pragma unroll

@@ -75,6 +75,9 @@ int frieda_ctx_set_host_channel(frieda_ctx* ctx, int enabled);
  * {"kernels": [{"name", "launches", "total_ms", "alg_bytes"}]} (alg_bytes = algorithmic HBM bytes by the byte model
  * of DESIGN.md §5); returns the bytes needed including the NUL; reset != 0 clears the accumulated spans. */
 int frieda_ctx_set_kernel_timing(frieda_ctx* ctx, int enabled);
+/* host wall-clock marks of the last generate_proof on this ctx, ms since entry: [0] commit phase enqueued, [1] device
+ * commit phase + grind complete, [2] queries drawn, [3] openings gathered, [4] proof assembled */
+int frieda_ctx_last_prove_phases(const frieda_ctx* ctx, double out_ms[8]);
 size_t frieda_ctx_kernel_timing_report(frieda_ctx* ctx, char* buf, size_t cap, int reset);
 
 /* ---- Level A: frieda's public API ------------------------------------------------------------- */

@@ -1,0 +1,189 @@
+"""CPU: the C-ABI library loads without a GPU and exports every symbol the header declares; the product's host-side logic
+(codec shape, wire format, verifier) against the oracle.  No compute entry point is called here."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import pattern_bytes
+
+P = 2**31 - 1
+
+
+@pytest.fixture(scope="module")
+def L():
+    import __graft_entry__ as g
+
+    g.build()
+    from frieda_amd import _lib
+
+    return _lib.lib()
+
+
+def test_library_exports_every_declared_symbol(L):
+    from frieda_amd import _lib
+
+    syms = _lib.declared_symbols()
+    assert len(syms) >= 45
+    for s in syms:
+        assert hasattr(L, s), f"libfrieda_hip.so does not export {s}"
+    # the ctypes signature table covers the header exactly
+    assert sorted(L._signatures) == syms
+    assert L.frieda_abi_version() == 1
+    assert b"panic" in L.frieda_status_string(3)
+
+
+def test_header_has_no_torch_or_cxx_types():
+    from frieda_amd import _lib
+
+    import re
+
+    text = re.sub(r"/\*.*?\*/", "", open(_lib.HEADER_PATH).read(), flags=re.S)  # declarations only, comments stripped
+    for bad in ("torch", "at::", "std::", "template", "class ", "&"):
+        assert bad not in text, bad
+
+
+def test_product_never_imports_oracle():
+    import os
+    import re
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for dp, _, files in os.walk(os.path.join(root, "frieda_amd")):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h")):
+                src = open(os.path.join(dp, f), errors="replace").read()
+                assert not re.search(r"^\s*(from|import)\s+oracle|#include\s+\".*oracle", src, re.M), f
+
+
+def test_codec_shape_matches_reference_f64_rule(L, oracle):
+    nf, npad, lg = C.c_size_t(), C.c_size_t(), C.c_uint32()
+    sizes = list(range(0, 600)) + [1023, 1024, 1025, 3839, 3840, 3841, 65536, 262146, 983040, 3932160, 15728640, 15728641]
+    for n in sizes:
+        L.frieda_codec_shape(n, C.byref(nf), C.byref(npad), C.byref(lg))
+        f = oracle.lib().fo_felt_count(n)
+        fp = oracle.lib().fo_padded_len(f)
+        assert (nf.value, npad.value) == (f, fp), n
+        assert (1 << (lg.value + 2)) == fp
+
+
+def test_merkle_layer_offsets(L, oracle):
+    for m in range(0, 20):
+        for l in range(0, m + 1):
+            assert L.frieda_merkle_layer_offset(m, l) == oracle.lib().fo_merkle_layer_offset(m, l)
+
+
+def test_null_arguments_are_rejected(L):
+    assert L.frieda_ctx_create(0, None, None) == 1
+    assert L.frieda_commit(None, None, 0, 4, None) == 1
+    assert L.frieda_verify(None, None, None) == 1
+    assert L.frieda_proof_deserialize(None, 0, None) == 1
+
+
+# ---- wire format + verifier against oracle-made proofs ----
+@pytest.fixture(scope="module")
+def proofs(oracle, blob):
+    out = {}
+    out["blob"] = oracle.commit_and_generate_proof(blob, None, oracle.make_config(20, 4, 1, 20))
+    out["p1024"] = oracle.commit_and_generate_proof(pattern_bytes(1024).tobytes(), 1024, oracle.make_config(20, 4, 0, 20))
+    out["small"] = oracle.commit_and_generate_proof(pattern_bytes(300).tobytes(), 9, oracle.make_config(8, 2, 1, 12))
+    return out
+
+
+def test_wire_image_round_trip_and_cross_verify(L, proofs):
+    import frieda_amd
+
+    for name, (root, op) in proofs.items():
+        img = op.serialize()
+        p = frieda_amd.Proof.deserialize(img)
+        assert p.serialize() == img, name
+        assert p.commitment == root
+        assert p.proof_of_work == op.c.proof_of_work
+        assert p.log_size_bound == op.c.log_size_bound
+        assert np.array_equal(p.evaluations, op.evaluations())
+        assert p.n_inner_layers == op.c.n_inner_layers
+    seeds = {"blob": None, "p1024": 1024, "small": 9}
+    for name, (root, op) in proofs.items():
+        p = frieda_amd.Proof.deserialize(op.serialize())
+        assert frieda_amd.verify(p, seeds[name])
+        assert not frieda_amd.verify(p, 12345)
+
+
+def test_malformed_images_are_rejected(L, proofs):
+    import frieda_amd
+
+    img = proofs["small"][1].serialize()
+    for bad in (b"", img[:7], img[:-1], img + b"\x00", b"XXXX" + img[4:], img[:36] + b"\xff\xff\xff\xff" + img[40:]):
+        with pytest.raises(frieda_amd.FriedaError):
+            frieda_amd.Proof.deserialize(bad)
+
+
+def test_product_verifier_matches_reference_rejections(proofs):
+    """src/proof.rs:143-181 on the product's host verifier, fed with an oracle-made proof."""
+    import frieda_amd
+
+    base = frieda_amd.Proof.deserialize(proofs["blob"][1].serialize())
+    assert frieda_amd.verify(base, None)
+    p = base.clone()
+    p.proof_of_work += 1
+    assert not frieda_amd.verify(p, None)
+    p = base.clone()
+    e = p.evaluations
+    e[0] = (e[0].astype(np.uint64) + 1) % P
+    p.evaluations = e
+    assert not frieda_amd.verify(p, None)
+    p = base.clone()
+    p.evaluations = p.evaluations[::-1]
+    assert not frieda_amd.verify(p, None)
+    p = base.clone()
+    p.evaluations = p.evaluations[:-1]
+    with pytest.raises(frieda_amd.FriedaPanic):
+        frieda_amd.verify(p, None)
+    p = base.clone()
+    e = p.evaluations
+    e[[0, 1]] = e[[1, 0]]
+    p.evaluations = e
+    assert not frieda_amd.verify(p, None)
+
+
+def test_tampered_witnesses_are_rejected(proofs):
+    import frieda_amd
+
+    img = bytearray(proofs["p1024"][1].serialize())
+    base = frieda_amd.Proof.deserialize(bytes(img))
+    assert frieda_amd.verify(base, 1024)
+    rng = np.random.default_rng(1)
+    rejected = 0
+    trials = 0
+    for _ in range(60):
+        pos = int(rng.integers(36, len(img)))  # past the header words
+        img2 = bytearray(img)
+        img2[pos] ^= 1 << int(rng.integers(0, 8))
+        try:
+            p = frieda_amd.Proof.deserialize(bytes(img2))
+        except frieda_amd.FriedaError:
+            continue
+        trials += 1
+        try:
+            if not frieda_amd.verify(p, 1024):
+                rejected += 1
+        except frieda_amd.FriedaPanic:
+            rejected += 1
+    assert trials > 20 and rejected == trials
+
+
+def test_product_and_oracle_verifiers_agree_on_random_tampering(oracle, proofs):
+    import frieda_amd
+
+    _, op = proofs["small"]
+    base = frieda_amd.Proof.deserialize(op.serialize())
+    rng = np.random.default_rng(5)
+    for _ in range(25):
+        o2 = op.clone()
+        p2 = base.clone()
+        ev = p2.evaluations
+        i, c = int(rng.integers(0, ev.shape[0])), int(rng.integers(0, 4))
+        ev[i, c] = (int(ev[i, c]) + int(rng.integers(0, 2))) % P  # sometimes a no-op
+        p2.evaluations = ev
+        for k, v in enumerate(ev.ravel()):
+            o2.c.evaluations[k] = int(v)
+        assert frieda_amd.verify(p2, 9) == oracle.verify(o2, 9)

@@ -1,0 +1,71 @@
+"""CPU: the N > 1 path — blobs sharded one per rank, all_gather of the 32-byte roots — with world_size 2 over gloo.
+The commit function is injected (here: the oracle, as the checker) so the sharding and gather logic runs without a GPU."""
+import os
+import socket
+import sys
+
+import pytest
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n_blobs, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+
+    from conftest import splitmix64_bytes
+    from frieda_amd import batch
+    from oracle import oracle as O
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    blobs = [splitmix64_bytes(100 + i, 1000 + 37 * i).tobytes() for i in range(n_blobs)]
+    calls = []
+
+    def commit_fn(b):
+        calls.append(len(b))
+        return O.commit(b, 4)
+
+    roots = batch.commit_batch(blobs, 4, commit_fn=commit_fn)
+    q.put((rank, [r.hex() for r in roots], calls))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_blobs", [2, 5])
+def test_commit_batch_world2_gloo(oracle, n_blobs):
+    from conftest import splitmix64_bytes
+
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_blobs, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    expected = [oracle.commit(splitmix64_bytes(100 + i, 1000 + 37 * i).tobytes(), 4).hex() for i in range(n_blobs)]
+    for rank, roots, calls in results:
+        assert roots == expected  # every rank ends with every root, in blob order
+        assert len(calls) == len(range(rank, n_blobs, world))  # and hashed only its own shard
+
+
+def test_shard_indices():
+    from frieda_amd.batch import shard_indices
+
+    assert shard_indices(8, 3, 8) == [3]
+    assert shard_indices(5, 0, 2) == [0, 2, 4]
+    assert shard_indices(5, 1, 2) == [1, 3]
+    assert sorted(sum((shard_indices(11, r, 4) for r in range(4)), [])) == list(range(11))
