@@ -27,6 +27,8 @@
 // twice its HBM time.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "kernels.h"
 
 namespace frieda {
@@ -64,30 +66,37 @@ struct NttArgs {
 };
 
 // One stage of R layers on tile bits [lo, lo + R): every thread processes groups of 2^R elements.
-template <int R>
-__device__ __forceinline__ void run_stage(uint32_t* lds, const NttArgs& a, uint32_t tb, uint32_t lo, uint32_t hblk) {
+// LO >= 0 fixes `lo` at compile time (the hot shapes): the 2^R LDS addresses of a group are then pad(base) plus immediates
+// (pad(base | x) == pad(base) + pad(x) because base has zeros where x = r << lo has bits) and so are the twiddle addresses.
+template <int R, int LO>
+__device__ __forceinline__ void run_stage(uint32_t* lds, const NttArgs& a, uint32_t tb, uint32_t lo_rt, uint32_t hblk) {
     constexpr int E = 1 << R;
+    const uint32_t lo = LO >= 0 ? (uint32_t)LO : lo_rt;
     const uint32_t n_groups = 1u << (tb - R);
     for (uint32_t g = threadIdx.x; g < n_groups; g += NTT_THREADS) {
         const uint32_t base = ((g >> lo) << (lo + R)) | (g & ((1u << lo) - 1));
+        const uint32_t pbase = pad(base);
         // twiddles: layer q of the stage acts on tile bit b = lo + R - 1 - q, global layer i = i_lo + b - log_w
         uint32_t twd[E - 1];
 #pragma unroll
         for (int q = 0; q < R; q++) {
             const uint32_t b = lo + R - 1 - q;
             const uint32_t i = a.i_lo + b - a.log_w;
-            const uint32_t hbase = (hblk << (a.i_hi - i)) | (base >> (b + 1));
+            const uint32_t hbase = (hblk << (a.i_hi - i)) | (base >> (b + 1));  // its low q bits are zero
+            if (i >= 1) {
+                const uint32_t* lvl = a.tw + tw_level_offset_dev(a.n, i - 1) + hbase;
 #pragma unroll
-            for (int u = 0; u < (1 << q); u++) {
-                const uint32_t h = hbase | (uint32_t)u;
-                twd[(1 << q) - 1 + u] = (i >= 1) ? a.tw[tw_level_offset_dev(a.n, i - 1) + h] : circle_twiddle(a.tw, a.n, h, a.init_y);
+                for (int u = 0; u < (1 << q); u++) twd[(1 << q) - 1 + u] = lvl[u];
+            } else {
+#pragma unroll
+                for (int u = 0; u < (1 << q); u++) twd[(1 << q) - 1 + u] = circle_twiddle(a.tw, a.n, hbase + (uint32_t)u, a.init_y);
             }
         }
         for (uint32_t c = 0; c < a.ncols; c++) {
-            uint32_t* col = lds + c * TILE_WORDS;
+            uint32_t* col = lds + c * TILE_WORDS + pbase;
             uint32_t x[E];
 #pragma unroll
-            for (int r = 0; r < E; r++) x[r] = col[pad(base | ((uint32_t)r << lo))];
+            for (int r = 0; r < E; r++) x[r] = col[pad((uint32_t)r << lo)];
 #pragma unroll
             for (int q = 0; q < R; q++) {
                 const int bit = R - 1 - q;
@@ -102,7 +111,7 @@ __device__ __forceinline__ void run_stage(uint32_t* lds, const NttArgs& a, uint3
                 }
             }
 #pragma unroll
-            for (int r = 0; r < E; r++) col[pad(base | ((uint32_t)r << lo))] = x[r];
+            for (int r = 0; r < E; r++) col[pad((uint32_t)r << lo)] = x[r];
         }
     }
 }
@@ -150,12 +159,20 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_tile_kernel(NttArgs a) {
     uint32_t top = tb;  // one past the top tile bit of the next stage
     for (uint32_t s = 0; s < a.n_stages; s++) {
         const uint32_t r = a.stage_r[s], lo = top - r;
-        switch (r) {
-            case 4: run_stage<4>(lds, a, tb, lo, hblk); break;
-            case 3: run_stage<3>(lds, a, tb, lo, hblk); break;
-            case 2: run_stage<2>(lds, a, tb, lo, hblk); break;
-            default: run_stage<1>(lds, a, tb, lo, hblk); break;
-        }
+        if (r == 4 && lo == 8)
+            run_stage<4, 8>(lds, a, tb, lo, hblk);
+        else if (r == 4 && lo == 4)
+            run_stage<4, 4>(lds, a, tb, lo, hblk);
+        else if (r == 4 && lo == 0)
+            run_stage<4, 0>(lds, a, tb, lo, hblk);
+        else if (r == 4)
+            run_stage<4, -1>(lds, a, tb, lo, hblk);
+        else if (r == 3)
+            run_stage<3, -1>(lds, a, tb, lo, hblk);
+        else if (r == 2)
+            run_stage<2, -1>(lds, a, tb, lo, hblk);
+        else
+            run_stage<1, -1>(lds, a, tb, lo, hblk);
         top = lo;
         __syncthreads();
     }
@@ -174,6 +191,120 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_tile_kernel(NttArgs a) {
                 uint32_t g = gbase | ((e >> a.log_w) << a.i_lo) | (e & wmask);
                 dst[g] = col[pad(e)];
             }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// The hot shape: a full 4096-word tile whose layers split into NS stages of exactly four (NS = 3, LOG_W = 0: the
+// contiguous last pass of 12 layers; NS = 2, LOG_W = 4: a strided pass of 8 layers).  One group of 16 elements per thread
+// and stage, so all 15 * NS twiddles of the thread are loaded once into registers and the columns are streamed through a
+// single 17 KiB LDS tile one after the other (9 workgroups fit a CU's LDS; registers allow 5-6 waves per SIMD).  The next
+// column's tile is prefetched into registers while the current one is computed; the contiguous pass stores its results
+// straight from registers (16 consecutive words per thread).
+// ------------------------------------------------------------------------------------------------
+template <int NS, int LOG_W>
+__global__ __launch_bounds__(NTT_THREADS) void ntt_tile12_kernel(NttArgs a) {
+    __shared__ uint32_t lds[TILE_WORDS];
+    const uint32_t g = threadIdx.x;
+    const uint32_t nwb_log = a.i_lo - LOG_W;
+    const uint32_t wblk = blockIdx.x & ((1u << nwb_log) - 1);
+    const uint32_t hblk = blockIdx.x >> nwb_log;
+    const uint32_t gbase = (hblk << (a.i_hi + 1)) | (wblk << LOG_W);
+    constexpr uint32_t wmask = (1u << LOG_W) - 1;
+    const size_t col0 = (size_t)blockIdx.y * a.ncols;
+    const uint32_t* in = a.in + col0 * a.in_stride;
+    uint32_t* out = a.out + col0 * a.out_stride;
+
+    // per-stage group base (padded) and twiddles
+    uint32_t pbase[NS];
+    uint32_t twd[NS][15];
+#pragma unroll
+    for (int s = 0; s < NS; s++) {
+        const uint32_t lo = 8 - 4 * s;
+        const uint32_t base = ((g >> lo) << (lo + 4)) | (g & ((1u << lo) - 1));
+        pbase[s] = pad(base);
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const uint32_t b = lo + 3 - q;
+            const uint32_t i = a.i_lo + b - LOG_W;
+            const uint32_t hbase = (hblk << (a.i_hi - i)) | (base >> (b + 1));
+            if (LOG_W == 0 && s == NS - 1 && q == 3) {  // i == 0: the circle layer
+#pragma unroll
+                for (int u = 0; u < 8; u++) twd[s][7 + u] = circle_twiddle(a.tw, a.n, hbase + (uint32_t)u, a.init_y);
+            } else {
+                const uint32_t* lvl = a.tw + tw_level_offset_dev(a.n, i - 1) + hbase;
+#pragma unroll
+                for (int u = 0; u < (1 << q); u++) twd[s][(1 << q) - 1 + u] = lvl[u];
+            }
+        }
+    }
+
+    // tile element e (multiple of 4) of this thread's k-th 16-byte piece, and its global index
+    auto piece_e = [&](int kk) { return 4u * g + 1024u * (uint32_t)kk; };
+    auto global_of = [&](uint32_t e) { return gbase | ((e >> LOG_W) << a.i_lo) | (e & wmask); };
+
+    uint4 pre[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; kk++) pre[kk] = *reinterpret_cast<const uint4*>(in + (global_of(piece_e(kk)) & a.in_mask));
+
+    for (uint32_t c = 0; c < a.ncols; c++) {
+        // tile of column c: registers -> LDS
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++) {
+            const uint32_t p = pad(piece_e(kk));
+            lds[p] = pre[kk].x;
+            lds[p + 1] = pre[kk].y;
+            lds[p + 2] = pre[kk].z;
+            lds[p + 3] = pre[kk].w;
+        }
+        __syncthreads();
+        if (c + 1 < a.ncols) {  // prefetch the next column while this one is computed
+            const uint32_t* src = in + (size_t)(c + 1) * a.in_stride;
+#pragma unroll
+            for (int kk = 0; kk < 4; kk++) pre[kk] = *reinterpret_cast<const uint4*>(src + (global_of(piece_e(kk)) & a.in_mask));
+        }
+        uint32_t x[16];
+#pragma unroll
+        for (int s = 0; s < NS; s++) {
+            const uint32_t lo = 8 - 4 * s;
+            uint32_t* col = lds + pbase[s];
+#pragma unroll
+            for (int r = 0; r < 16; r++) x[r] = col[pad((uint32_t)r << lo)];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int bit = 3 - q;
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    if (r & (1 << bit)) continue;
+                    const int u = r >> (bit + 1);
+                    const uint32_t t = m31_mul(x[r | (1 << bit)], twd[s][(1 << q) - 1 + u]);
+                    const uint32_t v = x[r];
+                    x[r] = m31_add(v, t);
+                    x[r | (1 << bit)] = m31_sub(v, t);
+                }
+            }
+            if (s + 1 < NS || LOG_W != 0) {
+#pragma unroll
+                for (int r = 0; r < 16; r++) col[pad((uint32_t)r << lo)] = x[r];
+            }
+            __syncthreads();
+        }
+        uint32_t* dst = out + (size_t)c * a.out_stride;
+        if (LOG_W == 0) {
+            // last stage has lo = 0: the thread holds tile elements 16 g .. 16 g + 15, contiguous in memory
+            uint4* o = reinterpret_cast<uint4*>(dst + gbase + 16u * g);
+            o[0] = make_uint4(x[0], x[1], x[2], x[3]);
+            o[1] = make_uint4(x[4], x[5], x[6], x[7]);
+            o[2] = make_uint4(x[8], x[9], x[10], x[11]);
+            o[3] = make_uint4(x[12], x[13], x[14], x[15]);
+        } else {
+#pragma unroll
+            for (int kk = 0; kk < 4; kk++) {
+                const uint32_t e = piece_e(kk), p = pad(e);
+                *reinterpret_cast<uint4*>(dst + global_of(e)) = make_uint4(lds[p], lds[p + 1], lds[p + 2], lds[p + 3]);
+            }
+            __syncthreads();  // the next column overwrites the tile
         }
     }
 }
@@ -213,7 +344,12 @@ void circle_evaluate(const Launch& L_, const uint32_t* d_coef, size_t coef_strid
         return;
     }
     // columns per workgroup: the largest divisor of ncols that is <= 4 (the 4 coordinate columns share every twiddle)
-    uint32_t cpw = MAX_COLS_PER_WG;
+    static const uint32_t cpw_max = [] {
+        const char* e = getenv("FRIEDA_NTT_CPW");  // tuning knob: columns per workgroup (1, 2 or 4)
+        uint32_t v = e ? (uint32_t)atoi(e) : MAX_COLS_PER_WG;
+        return (v >= 1 && v <= MAX_COLS_PER_WG) ? v : MAX_COLS_PER_WG;
+    }();
+    uint32_t cpw = cpw_max;
     while (ncols % cpw) cpw--;
     const size_t lds_bytes = (size_t)cpw * TILE_WORDS * sizeof(uint32_t);
     static bool lds_opt_in = false;  // 4 column tiles = 68 KiB of dynamic LDS: above the 64 KiB default
@@ -237,32 +373,44 @@ void circle_evaluate(const Launch& L_, const uint32_t* d_coef, size_t coef_strid
     a.tw = d_tw;
     a.n = n;
     a.init_y = ds.init_y;
-    a.ncols = cpw;
+    uint32_t cpw4 = MAX_COLS_PER_WG;
+    while (ncols % cpw4) cpw4--;
+    // one pass over layers a.i_hi .. a.i_lo
+    auto launch_pass = [&](uint32_t t, const char* name) {
+        const bool aligned = ((a.in_stride | a.out_stride) & 3) == 0 && (a.in_mask & 3u) == 3u &&
+                             ((reinterpret_cast<uintptr_t>(a.in) | reinterpret_cast<uintptr_t>(a.out)) & 15) == 0;
+        Scope scope(L_, name, enc_bytes / (n_mid + 1));
+        if (aligned && t + a.log_w == TILE_LOG && (t == 12 || t == 8)) {
+            a.ncols = cpw4;
+            dim3 grid((unsigned)(N >> TILE_LOG), ncols / cpw4);
+            if (a.log_w == 0)
+                ntt_tile12_kernel<3, 0><<<grid, NTT_THREADS, 0, s>>>(a);
+            else
+                ntt_tile12_kernel<2, MID_LOG_W><<<grid, NTT_THREADS, 0, s>>>(a);
+        } else {
+            a.ncols = cpw;
+            set_stages(a, t);
+            dim3 grid((unsigned)(N >> (t + a.log_w)), ncols / cpw);
+            ntt_tile_kernel<<<grid, NTT_THREADS, lds_bytes, s>>>(a);
+        }
+    };
     uint32_t i_hi = L - 1;
     for (uint32_t p = 0; p < n_mid; p++) {
         uint32_t t = (rest + (n_mid - p) - 1) / (n_mid - p);
         a.i_hi = i_hi;
         a.i_lo = i_hi + 1 - t;
         a.log_w = MID_LOG_W;  // i_lo >= last_t = 12 >= log_w whenever a strided pass exists
-        set_stages(a, t);
-        dim3 grid((unsigned)(N >> (t + a.log_w)), ncols / cpw);
-        Scope scope(L_, "ntt_pass_mid", enc_bytes / (n_mid + 1));
-        ntt_tile_kernel<<<grid, NTT_THREADS, lds_bytes, s>>>(a);
+        launch_pass(t, "ntt_pass_mid");
         a.in = d_out;
         a.in_stride = out_stride;
         a.in_mask = (uint32_t)(N - 1);
         rest -= t;
         i_hi = a.i_lo - 1;
     }
-    {
-        a.i_hi = i_hi;  // == last_t - 1
-        a.i_lo = 0;
-        a.log_w = 0;
-        set_stages(a, last_t);
-        dim3 grid((unsigned)(N >> last_t), ncols / cpw);
-        Scope scope(L_, "ntt_pass_last", enc_bytes / (n_mid + 1));
-        ntt_tile_kernel<<<grid, NTT_THREADS, lds_bytes, s>>>(a);
-    }
+    a.i_hi = i_hi;  // == last_t - 1
+    a.i_lo = 0;
+    a.log_w = 0;
+    launch_pass(last_t, "ntt_pass_last");
 }
 
 }  // namespace k

@@ -36,7 +36,7 @@ namespace {
 constexpr int T5_THREADS = 256;
 constexpr uint32_t T5_UNITS = 1024;
 constexpr uint32_t T5_LEVELS = 5;
-constexpr int WG1_THREADS = 1024;  // single-workgroup kernels: more waves = lower latency on the wide levels
+constexpr int WG1_THREADS = 512;  // single-workgroup kernels: 2 waves per SIMD saturate the VALU; 256 VGPRs per lane for the quad hash
 
 // ---- LDS hash levels, struct-of-arrays: word w of hash j at reg[w * stride + j], stride = count + 4 (even) ----
 __device__ __forceinline__ void lds_put(uint32_t* reg, uint32_t stride, uint32_t j, const uint32_t (&h)[8]) {
@@ -92,28 +92,6 @@ __device__ __forceinline__ QM31 fold_pair(const uint32_t* __restrict__ src, size
     return qm_add(f0, qm_mul(alpha, f1));
 }
 
-// lane-0 Fiat–Shamir step after a root: Blake2sMerkleChannel::mix_root, Channel::draw_felt
-__device__ void channel_after_root(DevTranscript* tr, const uint32_t (&root)[8]) {
-    Channel ch = tr->ch;
-    ch.mix_root(root);
-    QM31 al = ch.draw_felt();
-    tr->ch = ch;
-    tr->alpha[0] = al.a;
-    tr->alpha[1] = al.b;
-    tr->alpha[2] = al.c;
-    tr->alpha[3] = al.d;
-    uint32_t k = tr->n_roots;
-    if (k < DT_MAX_LAYERS) {
-#pragma unroll
-        for (int w = 0; w < 8; w++) tr->roots[k][w] = root[w];
-        tr->alphas[k][0] = al.a;
-        tr->alphas[k][1] = al.b;
-        tr->alphas[k][2] = al.c;
-        tr->alphas[k][3] = al.d;
-    }
-    tr->n_roots = k + 1;
-}
-
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------
@@ -140,14 +118,14 @@ struct TreeArgs {
 
 namespace {
 
-template <int MODE>
+template <int MODE, uint32_t UNITS>
 __global__ __launch_bounds__(T5_THREADS) void tree5_kernel(TreeArgs a) {
-    __shared__ __attribute__((aligned(16))) uint32_t RA[8 * (T5_UNITS + 4)];
-    __shared__ __attribute__((aligned(16))) uint32_t RB[8 * (T5_UNITS / 2 + 4)];
+    __shared__ __attribute__((aligned(16))) uint32_t RA[8 * (UNITS + 4)];
+    __shared__ __attribute__((aligned(16))) uint32_t RB[8 * (UNITS / 2 + 4)];
     const uint32_t t = threadIdx.x;
     const size_t total_a = (size_t)1 << a.level_a;
-    const size_t wg_base = (size_t)blockIdx.x * T5_UNITS;
-    const uint32_t cnt_a = (uint32_t)(total_a - wg_base < T5_UNITS ? total_a - wg_base : T5_UNITS);  // a power of two
+    const size_t wg_base = (size_t)blockIdx.x * UNITS;
+    const uint32_t cnt_a = (uint32_t)(total_a - wg_base < UNITS ? total_a - wg_base : UNITS);  // a power of two
     uint32_t nl = 1;
     while (nl < T5_LEVELS && (cnt_a >> nl) >= 1) nl++;
 
@@ -200,31 +178,190 @@ __global__ __launch_bounds__(T5_THREADS) void tree5_kernel(TreeArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// single-workgroup reduction of a level held in LDS down to the root
+// four-lane Blake2s compression for the latency-bound top of a tree
 // ------------------------------------------------------------------------------------------------
-// `cur` holds 2^log_count hashes (SoA stride 2^log_count + 4).  Every produced level l < log_count is stored at its
-// leaves-first offset when `layers` is non-null.  On return lane 0 holds the root in `root`.
-__device__ void wg_reduce_to_root(uint32_t* cur, uint32_t* other, uint32_t log_count, uint8_t* layers, uint32_t tree_log,
-                                  uint32_t (&root)[8]) {
-    const uint32_t t = threadIdx.x;
+// A lone wave issues a VALU instruction only every 4-8 cycles, so one compression per lane takes ~2.9 us however few
+// hashes a level has.  For levels of <= 256 nodes the four lanes of an aligned quad share one compression instead: lane q
+// owns state column q (v[q], v[4+q], v[8+q], v[12+q]); the column step is lane-local, the diagonal step rotates b, c, d by
+// 1, 2, 3 lanes with DPP quad_perm moves.  The 16 message words stay in LDS in the layout word(idx) = idx + (idx >> 3)
+// (two 8-word hashes stored 9 words apart, which also spreads the quads over the banks); every lane keeps its forty
+// per-round message offsets in registers.  Lane q ends up with output words q and 4 + q.
+constexpr uint32_t QS = 9;  // words between consecutive hashes in the quad (array-of-structs) LDS layout
+
+template <int CTRL>
+__device__ __forceinline__ uint32_t quad_perm(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, CTRL, 0xF, 0xF, true);
+}
+constexpr int QROT1 = 0x39;  // lane q reads lane q+1
+constexpr int QROT2 = 0x4E;  // lane q reads lane q+2
+constexpr int QROT3 = 0x93;  // lane q reads lane q+3
+
+struct QuadOffsets {
+    uint32_t w[40];  // round r, fetch k (0,1: column step; 2,3: diagonal step): LDS word offset of the message word
+};
+
+__device__ __forceinline__ void quad_offsets_init(QuadOffsets& o, uint32_t q) {
+#pragma unroll
+    for (int r = 0; r < 10; r++) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint32_t pos = (k < 2 ? 0u : 8u) + 2u * q + (uint32_t)(k & 1);
+            // SIGMA[r][pos] with a lane-dependent pos: select among the four lanes' constants
+            uint32_t idx = b2detail::SIGMA[r][(k < 2 ? 0 : 8) + (k & 1)];
+            if (q == 1) idx = b2detail::SIGMA[r][(k < 2 ? 0 : 8) + 2 + (k & 1)];
+            if (q == 2) idx = b2detail::SIGMA[r][(k < 2 ? 0 : 8) + 4 + (k & 1)];
+            if (q == 3) idx = b2detail::SIGMA[r][(k < 2 ? 0 : 8) + 6 + (k & 1)];
+            (void)pos;
+            o.w[4 * r + k] = idx + (idx >> 3);
+        }
+    }
+}
+
+struct Quad2 {
+    uint32_t lo, hi;  // output words q and 4 + q
+};
+
+// state in: a = h[q], b = h[4+q], c = IV[q], d = IV[4+q] ^ {t0, t1, f0, f1}[q]
+__device__ __forceinline__ Quad2 b2_compress_quad(const uint32_t* msg, const QuadOffsets& o, uint32_t ha, uint32_t hb, uint32_t c,
+                                                  uint32_t d) {
+    uint32_t a = ha, b = hb;
+#pragma unroll
+    for (int r = 0; r < 10; r++) {
+        const uint32_t m0 = msg[o.w[4 * r]], m1 = msg[o.w[4 * r + 1]], m2 = msg[o.w[4 * r + 2]], m3 = msg[o.w[4 * r + 3]];
+        FR_B2_G(a, b, c, d, m0, m1);
+        b = quad_perm<QROT1>(b);
+        c = quad_perm<QROT2>(c);
+        d = quad_perm<QROT3>(d);
+        FR_B2_G(a, b, c, d, m2, m3);
+        b = quad_perm<QROT3>(b);
+        c = quad_perm<QROT2>(c);
+        d = quad_perm<QROT1>(d);
+    }
+    return {ha ^ a ^ c, hb ^ b ^ d};
+}
+
+// Merkle node from the zero state (Blake2sMerkleHasher::hash_node): h = 0, t = f = 0
+__device__ __forceinline__ Quad2 merkle_node_quad(const uint32_t* msg, const QuadOffsets& o, uint32_t q) {
+    return b2_compress_quad(msg, o, 0u, 0u, b2detail::IV[q & 3], b2detail::IV[4 + (q & 3)]);
+}
+__device__ __forceinline__ uint32_t iv_sel(uint32_t i) {
+    // IV[i] with a lane-dependent index, without a memory table
+    uint32_t v = b2detail::IV[0];
+#pragma unroll
+    for (int k = 1; k < 8; k++) v = (i == (uint32_t)k) ? b2detail::IV[k] : v;
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// single-workgroup tree machinery: LDS regions and the level loop
+// ------------------------------------------------------------------------------------------------
+// Levels of >= 1024 hashes live in LDS as struct-of-arrays (S regions, one thread per node); levels of <= 512 hashes live
+// in the quad layout (Q regions) because their parents (<= 256 nodes) are hashed by quads.
+struct WgRegions {
+    uint32_t* S0;  // SoA, capacity cap0 hashes
+    uint32_t* S1;  // SoA, capacity cap0 / 2 hashes
+    uint32_t* QA;  // quad layout, 512 hashes
+    uint32_t* QB;  // quad layout, 256 hashes
+};
+constexpr uint32_t QA_WORDS = 512 * QS, QB_WORDS = 256 * QS;
+
+__device__ __forceinline__ void q_put_hash(uint32_t* Q, uint32_t j, const uint32_t (&h)[8]) {
+#pragma unroll
+    for (int w = 0; w < 8; w++) Q[QS * j + w] = h[w];
+}
+// store words q and 4+q of hash j (32-byte array-of-structs in global memory)
+__device__ __forceinline__ void store_hash_quad(uint8_t* out, uint32_t j, uint32_t q, Quad2 v) {
+    uint32_t* p = reinterpret_cast<uint32_t*>(out + 32 * (size_t)j);
+    p[q] = v.lo;
+    p[4 + q] = v.hi;
+}
+
+// Reduces a level of 2^log_count hashes already in LDS (SoA in `s_cur` when 2^log_count >= 1024, else quad layout in
+// `q_cur`) down to the root.  Every produced level l is stored at its leaves-first offset when `layers` is non-null.
+// Returns the LDS address of the root (8 consecutive words), valid for all threads after the final barrier.
+__device__ const uint32_t* wg_reduce(const WgRegions& R, uint32_t* s_cur, uint32_t* s_other, uint32_t* q_cur, uint32_t* q_other,
+                                     uint32_t log_count, uint8_t* layers, uint32_t tree_log, const QuadOffsets& qo) {
+    const uint32_t t = threadIdx.x, q = t & 3;
+    (void)R;
     for (int l = (int)log_count - 1; l >= 0; l--) {
         const uint32_t cnt = 1u << l;
         uint8_t* gout = layers ? layers + layer_off(tree_log, (uint32_t)l) : nullptr;
-        for (uint32_t j = t; j < cnt; j += WG1_THREADS) {
-            uint32_t m[16], h[8];
-            lds_children(cur, 2 * cnt + 4, j, m);
-            b2_merkle_block(m, h);
-            if (gout) store_hash(gout, j, h);
-            lds_put(other, cnt + 4, j, h);
+        if (cnt >= 512) {
+            // one node per thread; children in SoA
+            for (uint32_t j = t; j < cnt; j += WG1_THREADS) {
+                uint32_t m[16], h[8];
+                lds_children(s_cur, 2 * cnt + 4, j, m);
+                b2_merkle_block(m, h);
+                if (gout) store_hash(gout, j, h);
+                if (cnt >= 1024)
+                    lds_put(s_other, cnt + 4, j, h);
+                else
+                    q_put_hash(q_cur, j, h);  // 512 hashes: the parents are quad-hashed
+            }
+            uint32_t* tmp = s_cur;
+            s_cur = s_other;
+            s_other = tmp;
+        } else {
+            // one node per quad; children in the quad layout of q_cur, parents to q_other
+            for (uint32_t j = t >> 2; j < cnt; j += WG1_THREADS / 4) {
+                Quad2 v = merkle_node_quad(q_cur + 2 * QS * j, qo, q);
+                if (gout) store_hash_quad(gout, j, q, v);
+                q_other[QS * j + q] = v.lo;
+                q_other[QS * j + 4 + q] = v.hi;
+            }
+            uint32_t* tmp = q_cur;
+            q_cur = q_other;
+            q_other = tmp;
         }
         __syncthreads();
-        uint32_t* tmp = cur;
-        cur = other;
-        other = tmp;
     }
-    if (t == 0) {
-#pragma unroll
-        for (int w = 0; w < 8; w++) root[w] = cur[w * 5];  // stride of a 1-node level is 1 + 4
+    return q_cur;  // a 1-hash level is always in the quad layout
+}
+
+// Fiat–Shamir step after a root, by quad 0: Blake2sMerkleChannel::mix_root (standard Blake2s-256 of digest || root) and
+// Channel::draw_felt (digest || counter, retried until all eight words are < 2P).  `root_lds`: 8 words; `mb`: 17-word LDS
+// message buffer.  Must be called by lanes 0..3 only (one full quad).
+__device__ void channel_after_root_quad(DevTranscript* tr, const uint32_t* root_lds, uint32_t* mb, const QuadOffsets& qo) {
+    const uint32_t q = threadIdx.x & 3;
+    // message = digest (words 0..7) || root (words 8..15) in the idx + (idx >> 3) layout
+    mb[q] = tr->ch.digest[q];
+    mb[4 + q] = tr->ch.digest[4 + q];
+    mb[QS + q] = root_lds[q];
+    mb[QS + 4 + q] = root_lds[4 + q];
+    const uint32_t root_lo = root_lds[q], root_hi = root_lds[4 + q];
+    // h = IV ^ parameter block (digest 32, fanout 1, depth 1); t0 = 64 bytes; f0 = ~0 (single, final block)
+    const uint32_t hq = iv_sel(q) ^ (q == 0 ? 0x01010020u : 0u), h4q = iv_sel(4 + q);
+    const uint32_t dflag = (q == 0) ? 64u : (q == 2 ? 0xFFFFFFFFu : 0u);
+    Quad2 dg = b2_compress_quad(mb, qo, hq, h4q, iv_sel(q), iv_sel(4 + q) ^ dflag);
+    // draw_felt on the new digest
+    uint32_t n_sent = 0;
+    Quad2 rnd;
+    for (;;) {
+        mb[q] = dg.lo;
+        mb[4 + q] = dg.hi;
+        mb[QS + q] = (q == 0) ? n_sent : 0u;
+        mb[QS + 4 + q] = 0u;
+        n_sent++;
+        rnd = b2_compress_quad(mb, qo, hq, h4q, iv_sel(q), iv_sel(4 + q) ^ dflag);
+        uint32_t ok = (rnd.lo < 2u * P31 && rnd.hi < 2u * P31) ? 1u : 0u;
+        ok &= quad_perm<QROT1>(ok);
+        ok &= quad_perm<QROT2>(ok);
+        if (ok) break;
+    }
+    const uint32_t al = m31_reduce_2p(rnd.lo);
+    const uint32_t k = tr->n_roots;
+    tr->ch.digest[q] = dg.lo;
+    tr->ch.digest[4 + q] = dg.hi;
+    tr->alpha[q] = al;
+    if (k < DT_MAX_LAYERS) {
+        tr->roots[k][q] = root_lo;
+        tr->roots[k][4 + q] = root_hi;
+        tr->alphas[k][q] = al;
+    }
+    if (q == 0) {
+        tr->ch.n_challenges += 1;
+        tr->ch.n_sent = n_sent;
+        tr->n_roots = k + 1;
     }
 }
 
@@ -238,32 +375,51 @@ struct TopArgs {
 };
 
 __global__ __launch_bounds__(WG1_THREADS) void top_kernel(TopArgs a) {
-    __shared__ __attribute__((aligned(16))) uint32_t R0[8 * (1024 + 4)];
-    __shared__ __attribute__((aligned(16))) uint32_t R1[8 * (512 + 4)];
-    const uint32_t t = threadIdx.x;
-    uint32_t root[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    __shared__ __attribute__((aligned(16))) uint32_t S0[8 * (1024 + 4)];
+    __shared__ __attribute__((aligned(16))) uint32_t S1[8 * (512 + 4)];
+    __shared__ __attribute__((aligned(16))) uint32_t QA[QA_WORDS];
+    __shared__ __attribute__((aligned(16))) uint32_t QB[QB_WORDS];
+    __shared__ uint32_t MB[2 * QS];
+    const uint32_t t = threadIdx.x, q = t & 3;
+    QuadOffsets qo;
+    quad_offsets_init(qo, q);
+    WgRegions R{S0, S1, QA, QB};
+    const uint32_t* root_lds;
     if (a.l_in == 0) {
-        if (t == 0) {
-            const uint32_t* p = reinterpret_cast<const uint32_t*>(a.in);
-#pragma unroll
-            for (int w = 0; w < 8; w++) root[w] = p[w];
-        }
+        if (t < 8) QA[t] = reinterpret_cast<const uint32_t*>(a.in)[t];
+        __syncthreads();
+        root_lds = QA;
     } else {
         const uint32_t l = a.l_in - 1, cnt = 1u << l;
         uint8_t* gout = a.layers ? a.layers + layer_off(a.tree_log, l) : nullptr;
-        for (uint32_t j = t; j < cnt; j += WG1_THREADS) {
-            uint32_t m[16], h[8];
-            load_children(a.in, j, m);
-            b2_merkle_block(m, h);
-            if (gout) store_hash(gout, j, h);
-            lds_put(R0, cnt + 4, j, h);
+        if (cnt >= 512) {
+            for (uint32_t j = t; j < cnt; j += WG1_THREADS) {
+                uint32_t m[16], h[8];
+                load_children(a.in, j, m);
+                b2_merkle_block(m, h);
+                if (gout) store_hash(gout, j, h);
+                if (cnt >= 1024)
+                    lds_put(S0, cnt + 4, j, h);
+                else
+                    q_put_hash(QA, j, h);
+            }
+            __syncthreads();
+            root_lds = wg_reduce(R, S0, S1, QA, QB, l, a.layers, a.tree_log, qo);
+        } else {
+            // children (2 cnt <= 512 hashes) from global into the quad layout, then quad levels all the way
+            const uint32_t* inw = reinterpret_cast<const uint32_t*>(a.in);
+            for (uint32_t e = t; e < 16 * cnt; e += WG1_THREADS) QA[QS * (e >> 3) + (e & 7)] = inw[e];
+            __syncthreads();
+            root_lds = wg_reduce(R, S0, S1, QA, QB, l + 1, a.layers, a.tree_log, qo);
         }
-        __syncthreads();
-        wg_reduce_to_root(R0, R1, l, a.layers, a.tree_log, root);
     }
-    if (t == 0) {
-        if (a.root_out) store_hash(a.root_out, 0, root);
-        if (a.tr) channel_after_root(a.tr, root);
+    if (t < 4) {
+        if (a.root_out) {
+            uint32_t* ro = reinterpret_cast<uint32_t*>(a.root_out);
+            ro[q] = root_lds[q];
+            ro[4 + q] = root_lds[4 + q];
+        }
+        if (a.tr) channel_after_root_quad(a.tr, root_lds, MB, qo);
     }
 }
 
@@ -290,12 +446,18 @@ struct TailArgs {
 };
 
 __global__ __launch_bounds__(WG1_THREADS) void tail_kernel(TailArgs a) {
-    __shared__ __attribute__((aligned(16))) uint32_t R0[8 * (TAIL_CAP + 4)];
-    __shared__ __attribute__((aligned(16))) uint32_t R1[8 * (TAIL_CAP / 2 + 4)];
-    __shared__ __attribute__((aligned(16))) uint32_t MSG[8 + 4 * DT_MAX_LAST_POLY + 16];
+    __shared__ __attribute__((aligned(16))) uint32_t S0[8 * (TAIL_CAP + 4)];
+    __shared__ __attribute__((aligned(16))) uint32_t S1[8 * (TAIL_CAP / 2 + 4)];
+    __shared__ __attribute__((aligned(16))) uint32_t QA[QA_WORDS];
+    __shared__ __attribute__((aligned(16))) uint32_t QB[QB_WORDS];
+    __shared__ uint32_t MB[2 * QS];
     __shared__ uint32_t s_alpha[4];
-    const uint32_t t = threadIdx.x;
+    uint32_t* const MSG = S0 + 4 * TAIL_CAP + 8;  // the upper half of S0 is free once the last layer is reached
+    const uint32_t t = threadIdx.x, q = t & 3;
     DevTranscript* tr = a.tr;
+    QuadOffsets qo;
+    quad_offsets_init(qo, q);
+    WgRegions R{S0, S1, QA, QB};
 
     const uint32_t* src = a.src;
     size_t src_stride = a.src_stride;
@@ -322,20 +484,22 @@ __global__ __launch_bounds__(WG1_THREADS) void tail_kernel(TailArgs a) {
                 uint32_t h[8];
                 leaf_hash(r.a, r.b, r.c, r.d, h);
                 store_hash(a.trees[kx], j, h);  // leaf layer sits at offset 0
-                lds_put(R0, cnt + 4, j, h);
+                if (cnt >= 1024)
+                    lds_put(S0, cnt + 4, j, h);
+                else
+                    q_put_hash(QA, j, h);
             } else {
-                // keep the last layer in LDS for the interpolation: coordinate c of point j at R0[c * cnt + j]
-                R0[j] = r.a;
-                R0[cnt + j] = r.b;
-                R0[2 * cnt + j] = r.c;
-                R0[3 * cnt + j] = r.d;
+                // keep the last layer in LDS for the interpolation: coordinate c of point j at S0[c * cnt + j]
+                S0[j] = r.a;
+                S0[cnt + j] = r.b;
+                S0[2 * cnt + j] = r.c;
+                S0[3 * cnt + j] = r.d;
             }
         }
         __syncthreads();
         if (is_last) break;
-        uint32_t root[8];
-        wg_reduce_to_root(R0, R1, m_new, a.trees[kx], m_new, root);
-        if (t == 0) channel_after_root(tr, root);
+        const uint32_t* root_lds = wg_reduce(R, S0, S1, QA, QB, m_new, a.trees[kx], m_new, qo);
+        if (t < 4) channel_after_root_quad(tr, root_lds, MB, qo);
         __syncthreads();
         src = dstv;
         src_stride = cnt;
@@ -346,8 +510,8 @@ __global__ __launch_bounds__(WG1_THREADS) void tail_kernel(TailArgs a) {
     // ---- FriProver::commit_last_layer: LineEvaluation::interpolate (stwo core/poly/line.rs) ----
     const uint32_t lg = a.last_log, cnt = 1u << lg;
     // bit-reverse into natural order: W[c][i] = V[c][brev(i)]
-    uint32_t* V = R0;
-    uint32_t* W = R1;
+    uint32_t* V = S0;
+    uint32_t* W = S1;
     for (uint32_t i = t; i < cnt; i += WG1_THREADS) {
         uint32_t b = bit_reverse(i, lg);
 #pragma unroll
@@ -383,11 +547,11 @@ __global__ __launch_bounds__(WG1_THREADS) void tail_kernel(TailArgs a) {
 #pragma unroll
         for (int c = 0; c < 4; c++) v[c] = m31_mul(W[c * cnt + j], len_inv);
         if ((j & ((1u << sh) - 1)) == 0) {
-            uint32_t q = j >> sh;
+            uint32_t qq = j >> sh;
 #pragma unroll
             for (int c = 0; c < 4; c++) {
-                MSG[8 + 4 * q + c] = v[c];
-                tr->last_poly[4 * q + c] = v[c];
+                MSG[8 + 4 * qq + c] = v[c];
+                tr->last_poly[4 * qq + c] = v[c];
             }
         } else if (v[0] | v[1] | v[2] | v[3]) {
             bad = 1;
@@ -443,21 +607,38 @@ __global__ __launch_bounds__(256) void grind_dev_kernel(GrindArgs a) {
     if (tz >= a.pow_bits) atomicMin(&a.tr->nonce, nonce);
 }
 
+// Launches with few level-A nodes cannot fill the chip and are latency-bound: they use 256-node workgroups (one hash per
+// thread and level, four times as many workgroups) instead of 1024-node ones.
+constexpr uint32_t T5_SMALL_LOG = 16;  // level_a below this: 256-node workgroups
+uint32_t tree5_units_log(uint32_t level_a) { return level_a < T5_SMALL_LOG ? 8u : 10u; }
+
 void launch_tree5(const Launch& L, int mode, const TreeArgs& a, const char* name, double alg_bytes) {
     const size_t total = (size_t)1 << a.level_a;
-    const unsigned grid = (unsigned)((total + T5_UNITS - 1) / T5_UNITS);
+    const bool small = tree5_units_log(a.level_a) == 8;
+    const uint32_t units = small ? 256u : T5_UNITS;
+    const unsigned grid = (unsigned)((total + units - 1) / units);
     Scope scope(L, name, alg_bytes);
-    switch (mode) {
-        case T_LEAF4: tree5_kernel<T_LEAF4><<<grid, T5_THREADS, 0, L.stream>>>(a); break;
-        case T_NODE: tree5_kernel<T_NODE><<<grid, T5_THREADS, 0, L.stream>>>(a); break;
-        case T_FOLD_CIRCLE: tree5_kernel<T_FOLD_CIRCLE><<<grid, T5_THREADS, 0, L.stream>>>(a); break;
-        default: tree5_kernel<T_FOLD_LINE><<<grid, T5_THREADS, 0, L.stream>>>(a); break;
+    if (small) {
+        switch (mode) {
+            case T_LEAF4: tree5_kernel<T_LEAF4, 256><<<grid, T5_THREADS, 0, L.stream>>>(a); break;
+            case T_NODE: tree5_kernel<T_NODE, 256><<<grid, T5_THREADS, 0, L.stream>>>(a); break;
+            case T_FOLD_CIRCLE: tree5_kernel<T_FOLD_CIRCLE, 256><<<grid, T5_THREADS, 0, L.stream>>>(a); break;
+            default: tree5_kernel<T_FOLD_LINE, 256><<<grid, T5_THREADS, 0, L.stream>>>(a); break;
+        }
+    } else {
+        switch (mode) {
+            case T_LEAF4: tree5_kernel<T_LEAF4, T5_UNITS><<<grid, T5_THREADS, 0, L.stream>>>(a); break;
+            case T_NODE: tree5_kernel<T_NODE, T5_UNITS><<<grid, T5_THREADS, 0, L.stream>>>(a); break;
+            case T_FOLD_CIRCLE: tree5_kernel<T_FOLD_CIRCLE, T5_UNITS><<<grid, T5_THREADS, 0, L.stream>>>(a); break;
+            default: tree5_kernel<T_FOLD_LINE, T5_UNITS><<<grid, T5_THREADS, 0, L.stream>>>(a); break;
+        }
     }
 }
 
 // levels produced by one tree5 launch whose level A has 2^level_a nodes
 uint32_t tree5_levels(uint32_t level_a) {
-    uint32_t in_wg = level_a < 10 ? level_a : 10;  // log2 of the A nodes one workgroup owns
+    const uint32_t ul = tree5_units_log(level_a);
+    uint32_t in_wg = level_a < ul ? level_a : ul;  // log2 of the A nodes one workgroup owns
     return in_wg + 1 < T5_LEVELS ? in_wg + 1 : T5_LEVELS;
 }
 
