@@ -10,6 +10,7 @@ from .api import (  # noqa: F401
     FriedaPanic,
     PcsConfig,
     Proof,
+    ProofPipeline,
     commit,
     commit_and_generate_proof,
     default_context,
@@ -24,6 +25,7 @@ __all__ = [
     "FriedaPanic",
     "PcsConfig",
     "Proof",
+    "ProofPipeline",
     "commit",
     "commit_and_generate_proof",
     "default_context",

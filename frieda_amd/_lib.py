@@ -72,6 +72,9 @@ def lib():
         "frieda_commit_and_generate_proof": (C.c_int, [vp, vp, sz, u64p, PcsConfigC, vp, pp]),
         "frieda_commit_and_generate_proof_device": (C.c_int, [vp, vp, sz, u64p, PcsConfigC, vp, pp]),
         "frieda_generate_proof": (C.c_int, [vp, vp, sz, u64p, PcsConfigC, pp]),
+        "frieda_prove_begin": (C.c_int, [vp, vp, sz, u64p, PcsConfigC]),
+        "frieda_prove_begin_device": (C.c_int, [vp, vp, sz, u64p, PcsConfigC]),
+        "frieda_prove_finish": (C.c_int, [vp, vp, pp]),
         "frieda_verify": (C.c_int, [vp, u64p, C.POINTER(C.c_int)]),
         "frieda_proof_free": (None, [vp]),
         "frieda_proof_clone": (C.c_int, [vp, pp]),

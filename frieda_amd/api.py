@@ -153,6 +153,22 @@ class Context:
     def generate_proof(self, data, seed, pcs_config):
         return self.commit_and_generate_proof(data, seed, pcs_config)[1]
 
+    # ---- split form: overlap several proofs on one GPU with one Context per in-flight proof ----
+    def prove_begin(self, data, seed, pcs_config):
+        a = _as_bytes(data)
+        self._keep = a  # the host blob must outlive the asynchronous upload
+        _check(self._L.frieda_prove_begin(self._h, a.ctypes.data if a.size else None, a.size, _seed_ptr(seed), pcs_config._c()), self._h)
+
+    def prove_begin_device(self, d_ptr, length, seed, pcs_config):
+        _check(self._L.frieda_prove_begin_device(self._h, d_ptr, length, _seed_ptr(seed), pcs_config._c()), self._h)
+
+    def prove_finish(self):
+        root = (C.c_uint8 * 32)()
+        out = C.c_void_p()
+        _check(self._L.frieda_prove_finish(self._h, root, C.byref(out)), self._h)
+        self._keep = None
+        return bytes(root), Proof(out)
+
 
 class Proof:
     """frieda::proof::Proof (src/proof.rs:19-26).  Fields are public upstream, so they are readable and writable here."""
@@ -246,6 +262,41 @@ class Proof:
         out = C.c_void_p()
         _check(_lib.lib().frieda_proof_deserialize(a.ctypes.data, a.size, C.byref(out)))
         return Proof(out)
+
+
+class ProofPipeline:
+    """Keeps up to `depth` proofs in flight on one GPU (one Context = stream + workspace each), so that the latency-bound
+    tail of one proof (tree tops, small FRI layers, host round trips) overlaps the throughput-bound kernels of the next.
+    submit() returns the oldest finished (commitment, proof) once the pipeline is full, else None; drain() flushes."""
+
+    def __init__(self, device=0, depth=2):
+        self.ctxs = [Context(device) for _ in range(depth)]
+        self.inflight = []  # contexts with a proof in flight, oldest first
+        self.free = list(self.ctxs)
+
+    def submit_device(self, d_ptr, length, seed, pcs_config):
+        done = None
+        if not self.free:
+            ctx = self.inflight.pop(0)
+            done = ctx.prove_finish()
+            self.free.append(ctx)
+        ctx = self.free.pop(0)
+        ctx.prove_begin_device(d_ptr, length, seed, pcs_config)
+        self.inflight.append(ctx)
+        return done
+
+    def drain(self):
+        out = []
+        while self.inflight:
+            ctx = self.inflight.pop(0)
+            out.append(ctx.prove_finish())
+            self.free.append(ctx)
+        return out
+
+    def close(self):
+        self.drain()
+        for c in self.ctxs:
+            c.close()
 
 
 # ---- module-level API with an implicit per-thread default context (frieda's free functions) ----

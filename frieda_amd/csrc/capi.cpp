@@ -165,6 +165,35 @@ int frieda_generate_proof(frieda_ctx* ctx, const uint8_t* data, size_t len, cons
     return prove_common(ctx, data, len, false, seed, cfg, nullptr, out);
 }
 
+int frieda_prove_begin(frieda_ctx* ctx, const uint8_t* data, size_t len, const uint64_t* seed, frieda_pcs_config cfg) {
+    if (!ctx || (!data && len)) return FRIEDA_ERR_ARG;
+    FR_GUARD_BEGIN
+    return prove_begin(&ctx->c, data, len, false, seed, cfg);
+    FR_GUARD_END(ctx)
+}
+int frieda_prove_begin_device(frieda_ctx* ctx, const void* d_data, size_t len, const uint64_t* seed, frieda_pcs_config cfg) {
+    if (!ctx || (!d_data && len)) return FRIEDA_ERR_ARG;
+    FR_GUARD_BEGIN
+    return prove_begin(&ctx->c, static_cast<const uint8_t*>(d_data), len, true, seed, cfg);
+    FR_GUARD_END(ctx)
+}
+int frieda_prove_finish(frieda_ctx* ctx, uint8_t out_commitment[32], frieda_proof** out) {
+    if (!ctx || !out) return FRIEDA_ERR_ARG;
+    *out = nullptr;
+    FR_GUARD_BEGIN
+    frieda_proof* p = new frieda_proof();
+    uint8_t root[32];
+    int rc = prove_finish(&ctx->c, root, p->p);
+    if (rc != FRIEDA_OK) {
+        delete p;
+        return rc;
+    }
+    if (out_commitment) memcpy(out_commitment, root, 32);
+    *out = p;
+    return FRIEDA_OK;
+    FR_GUARD_END(ctx)
+}
+
 int frieda_verify(const frieda_proof* proof, const uint64_t* seed, int* ok) {
     if (!proof || !ok) return FRIEDA_ERR_ARG;
     frieda_ctx* none = nullptr;

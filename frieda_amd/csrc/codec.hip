@@ -41,21 +41,25 @@ __device__ __forceinline__ uint4 extract4(const uint32_t (&w)[5]) {
 
 __global__ __launch_bounds__(256) void unpack30_aligned_kernel(const uint8_t* __restrict__ in, size_t len,
                                                                uint32_t* __restrict__ out, size_t n_quads) {
-    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    // the workgroup's 256 quads cover bytes [3840 b, 3840 (b + 1)) = 960 aligned dwords: stage them through LDS with
+    // coalesced loads, then every thread funnel-shifts its own 15-byte window
+    __shared__ uint32_t stage[964];
+    const size_t d_base = (size_t)blockIdx.x * 960;
+    for (uint32_t i = threadIdx.x; i < 964; i += 256) stage[i] = load_dword_guarded(in, len, d_base + i);
+    __syncthreads();
+    size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (t >= n_quads) return;
-    size_t byte0 = 15 * t;
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if (byte0 < len) {
-        size_t d0 = byte0 >> 2;
-        uint32_t w[5];
+    const uint32_t byte0 = 15u * threadIdx.x;  // relative to the workgroup's first byte (a multiple of 4)
+    const uint32_t d0 = byte0 >> 2;
+    uint32_t w[5];
 #pragma unroll
-        for (int i = 0; i < 5; i++) w[i] = load_dword_guarded(in, len, d0 + i);
-        switch (byte0 & 3) {
-            case 0: v = extract4<0>(w); break;
-            case 1: v = extract4<8>(w); break;
-            case 2: v = extract4<16>(w); break;
-            default: v = extract4<24>(w); break;
-        }
+    for (int i = 0; i < 5; i++) w[i] = stage[d0 + i];
+    uint4 v;
+    switch (byte0 & 3) {
+        case 0: v = extract4<0>(w); break;
+        case 1: v = extract4<8>(w); break;
+        case 2: v = extract4<16>(w); break;
+        default: v = extract4<24>(w); break;
     }
     reinterpret_cast<uint4*>(out)[t] = v;
 }

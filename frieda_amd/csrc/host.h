@@ -7,6 +7,7 @@
 
 #include <array>
 #include <map>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -67,6 +68,11 @@ struct TwiddleSet {
     k::DomainScalars ds{};
 };
 
+struct ProveJob;  // state of a proof between prove_begin and prove_finish (prover.cpp)
+struct ProveJobDeleter {
+    void operator()(ProveJob* j) const;
+};
+
 // per-kernel HIP-event timer: events are recorded on the ctx stream around each launch; durations are read back
 // (after a stream synchronise) by report()
 struct KernelTimerImpl;
@@ -85,6 +91,7 @@ struct Ctx {
     std::string err;
     double phase_ms[8] = {0};  // host wall-clock marks of the last prove() (ms since entry): enqueued, device done, queries, gather, assembled
     KernelTimerImpl* timer = nullptr;  // non-null while kernel timing is enabled
+    std::unique_ptr<ProveJob, ProveJobDeleter> job;  // the proof in flight, if any
 
     k::Launch launch() const;
     int set_kernel_timing(bool enabled);
@@ -119,6 +126,10 @@ int commit_device(Ctx* ctx, const uint8_t* d_data, size_t len, uint32_t log_blow
 int commit_host(Ctx* ctx, const uint8_t* data, size_t len, uint32_t log_blowup, uint8_t out_root[32]);
 int prove(Ctx* ctx, const uint8_t* data, size_t len, bool data_on_device, const uint64_t* seed, frieda_pcs_config cfg,
           uint8_t out_commitment[32], ProofData& out);
+// split form: prove_begin enqueues the whole commit phase and returns without synchronising; prove_finish waits for it,
+// opens the queries and assembles the proof.  One proof in flight per ctx; use several ctxs to overlap proofs.
+int prove_begin(Ctx* ctx, const uint8_t* data, size_t len, bool data_on_device, const uint64_t* seed, frieda_pcs_config cfg);
+int prove_finish(Ctx* ctx, uint8_t out_commitment[32], ProofData& out);
 // returns FRIEDA_OK with *ok set, or FRIEDA_ERR_INVARIANT where the reference panics
 int verify(const ProofData& proof, const uint64_t* seed, int* ok);
 

@@ -235,10 +235,36 @@ size_t plan_merkle_decommit(const std::vector<uint32_t>& positions, const FriLay
 
 }  // namespace
 
-int prove(Ctx* ctx, const uint8_t* data, size_t len, bool data_on_device, const uint64_t* seed, frieda_pcs_config cfg,
-          uint8_t out_commitment[32], ProofData& out) {
+// State of a proof between prove_begin (commit phase enqueued) and prove_finish (decommit + assembly).
+struct ProveJob {
+    frieda_pcs_config cfg{};
+    Shape sh{};
+    uint32_t n = 0, last = 0, last_log = 0, n_inner = 0;
+    size_t N = 0;
+    FriLayerDev first{};
+    std::vector<FriLayerDev> inner;
+    size_t o_lastv = 0, o_nonce = 0, o_tr = 0, o_widx = 0, o_hidx = 0, o_wout = 0, o_hout = 0;
+    size_t max_words = 0, max_hashes = 0;
+    Channel ch{};
+    bool dev_channel = false;
+    std::vector<Hash32> roots;
+    std::vector<QM31> lastv;
+    uint64_t nonce = ~0ull, grind_base = 0, grind_chunk = 0;
+    std::chrono::steady_clock::time_point t_start;
+};
+
+void ProveJobDeleter::operator()(ProveJob* j) const { delete j; }
+
+static double ms_since(std::chrono::steady_clock::time_point t0) {
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+}
+
+int prove_begin(Ctx* ctx, const uint8_t* data, size_t len, bool data_on_device, const uint64_t* seed, frieda_pcs_config cfg) {
+    if (ctx->job) return ctx->fail(FRIEDA_ERR_ARG, "a proof is already in flight on this context");
     const uint32_t B = cfg.log_blowup_factor, last = cfg.log_last_layer_degree_bound;
-    Shape sh;
+    std::unique_ptr<ProveJob, ProveJobDeleter> jp(new ProveJob());
+    ProveJob& J = *jp;
+    Shape& sh = J.sh;
     int rc = make_shape(ctx, len, B, sh);
     if (rc) return rc;
     // FriProver::commit_last_layer asserts evaluation.len() == last_layer_domain_size: needs L - 1 >= last;
@@ -248,45 +274,48 @@ int prove(Ctx* ctx, const uint8_t* data, size_t len, bool data_on_device, const 
     if (cfg.n_queries == 0 || cfg.n_queries > 4096) return ctx->fail(FRIEDA_ERR_ARG, "n_queries out of range");
     if (cfg.pow_bits > 48) return ctx->fail(FRIEDA_ERR_ARG, "pow_bits > 48");
     FR_HIP(ctx, hipSetDevice(ctx->device));
-    const uint32_t n = sh.n, last_log = last + B;
-    const size_t N = sh.N;
-    const uint32_t n_inner = (n - 1) - last_log;
+    J.cfg = cfg;
+    J.last = last;
+    const uint32_t n = J.n = sh.n, last_log = J.last_log = last + B;
+    const size_t N = J.N = sh.N;
+    const uint32_t n_inner = J.n_inner = (n - 1) - last_log;
 
     // ---- workspace plan ----
     ArenaPlan plan;
     size_t o_data = plan.take(data_on_device ? 0 : len);
     size_t o_coef = plan.take(sizeof(uint32_t) * sh.cs.n_padded);
-    FriLayerDev first{plan.take(sizeof(uint32_t) * 4 * N), 0, n};
+    FriLayerDev& first = J.first;
+    first = FriLayerDev{plan.take(sizeof(uint32_t) * 4 * N), 0, n};
     first.o_tree = plan.take(k::merkle_layer_offset(n, 0) + 32);
-    std::vector<FriLayerDev> inner(n_inner);
+    std::vector<FriLayerDev>& inner = J.inner;
+    inner.resize(n_inner);
     for (uint32_t kx = 0; kx < n_inner; kx++) {
         uint32_t lg = n - 1 - kx;
         inner[kx].log = lg;
         inner[kx].o_vals = plan.take(sizeof(uint32_t) * 4 << lg);
         inner[kx].o_tree = plan.take(k::merkle_layer_offset(lg, 0) + 32);
     }
-    size_t o_lastv = plan.take(sizeof(uint32_t) * 4 << last_log);
-    size_t o_nonce = plan.take(8);
-    size_t o_tr = plan.take(sizeof(DevTranscript));
+    const size_t o_lastv = J.o_lastv = plan.take(sizeof(uint32_t) * 4 << last_log);
+    const size_t o_nonce = J.o_nonce = plan.take(8);
+    const size_t o_tr = J.o_tr = plan.take(sizeof(DevTranscript));
     // decommit gather: per layer <= 2 positions per query; hashes <= 2 * queries * log per layer
-    const size_t max_words = (size_t)cfg.n_queries * 4 * (1 + (n_inner + 1));
-    const size_t max_hashes = (size_t)cfg.n_queries * 2 * (size_t)(n + 1) * (n_inner + 1);
-    size_t o_widx = plan.take(8 * max_words), o_hidx = plan.take(8 * max_hashes);
-    size_t o_wout = plan.take(4 * max_words), o_hout = plan.take(32 * max_hashes);
+    J.max_words = (size_t)cfg.n_queries * 4 * (1 + (n_inner + 1));
+    J.max_hashes = (size_t)cfg.n_queries * 2 * (size_t)(n + 1) * (n_inner + 1);
+    J.o_widx = plan.take(8 * J.max_words);
+    J.o_hidx = plan.take(8 * J.max_hashes);
+    J.o_wout = plan.take(4 * J.max_words);
+    J.o_hout = plan.take(32 * J.max_hashes);
     rc = ctx->ensure_arena(plan.off);
     if (rc) return rc;
-    const size_t pinned_need =
-        std::max<size_t>(std::max<size_t>(sizeof(DevTranscript), (sizeof(uint32_t) * 4) << last_log), 4 * max_words + 32 * max_hashes);
+    const size_t pinned_need = std::max<size_t>(std::max<size_t>(sizeof(DevTranscript), (sizeof(uint32_t) * 4) << last_log),
+                                                4 * J.max_words + 32 * J.max_hashes);
     rc = ensure_pinned(ctx, pinned_need);
     if (rc) return rc;
     TwiddleSet tw;
     rc = ctx->get_twiddles(n, tw);
     if (rc) return rc;
     hipStream_t s = ctx->stream;
-    const auto t_start = std::chrono::steady_clock::now();
-    auto ms_since = [](std::chrono::steady_clock::time_point t0) {
-        return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-    };
+    J.t_start = std::chrono::steady_clock::now();
     for (double& v : ctx->phase_ms) v = 0.0;
     const k::Launch LN = ctx->launch();
     uint8_t* A = ctx->arena;
@@ -302,17 +331,17 @@ int prove(Ctx* ctx, const uint8_t* data, size_t len, bool data_on_device, const 
     k::unpack30(LN, d_data, len, coef, sh.cs.n_padded);
     k::circle_evaluate(LN, coef, (size_t)1 << sh.L, 4, sh.L, n, tw.d_tw, tw.ds, eval, N);
 
-    Channel ch;
+    Channel& ch = J.ch;
     ch.init();
     if (seed) ch.mix_u64(*seed);  // src/proof.rs:40-42
 
     auto cols = [&](const FriLayerDev& lay, int c) { return reinterpret_cast<uint32_t*>(A + lay.o_vals) + ((size_t)c << lay.log); };
-    std::vector<Hash32> roots(1 + n_inner);
-    std::vector<QM31> lastv;
-    uint64_t nonce = ~0ull;
+    std::vector<Hash32>& roots = J.roots;
+    roots.assign(1 + n_inner, Hash32{});
+    std::vector<QM31>& lastv = J.lastv;
     // The whole commit phase runs on the device (transcript included) when the last layer fits the single-workgroup tail;
     // otherwise (log_last_layer_degree_bound + log_blowup_factor > 11) the channel is evaluated on the host between layers.
-    const bool dev_channel = last_log <= k::TAIL_LOG && !ctx->host_channel;
+    const bool dev_channel = J.dev_channel = last_log <= k::TAIL_LOG && !ctx->host_channel;
     if (dev_channel) {
         DevTranscript* d_tr = reinterpret_cast<DevTranscript*>(A + o_tr);
         const size_t hdr = offsetof(DevTranscript, last_poly);
@@ -349,30 +378,13 @@ int prove(Ctx* ctx, const uint8_t* data, size_t len, bool data_on_device, const 
         ttrees[n_tail - 1] = nullptr;
         k::fri_tail(LN, cols(*cur, 0), (size_t)1 << cur->log, cur->log, circle, n, tw.d_itw, tw.ds, last_log, last, n_tail, tvals, ttrees,
                     d_tr);
-        // grind (src/proof.rs:58), keyed by the digest now sitting in the device transcript
-        const size_t n_poly = (size_t)1 << last;
-        const DevTranscript* ht = reinterpret_cast<const DevTranscript*>(ctx->pinned);
-        uint64_t base = 0, chunk = (uint64_t)1 << 22;
-        for (;;) {
-            if (base == 0) ctx->phase_ms[0] = ms_since(t_start);  // commit phase fully enqueued
-            k::grind_dev(LN, d_tr, cfg.pow_bits, base, chunk);
-            FR_HIP(ctx, hipMemcpyAsync(ctx->pinned, d_tr, hdr + 16 * n_poly, hipMemcpyDeviceToHost, s));
-            FR_HIP(ctx, hipStreamSynchronize(s));
-            if (ht->status & 1u) return ctx->fail(FRIEDA_ERR_INVARIANT, "invalid degree");  // assert! upstream
-            if (ht->nonce != ~0ull) break;
-            base += chunk;
-            if (chunk < ((uint64_t)1 << 28)) chunk <<= 1;
-        }
+        // grind (src/proof.rs:58), keyed by the digest now sitting in the device transcript: first chunk + transcript download
+        J.grind_base = 0;
+        J.grind_chunk = (uint64_t)1 << 22;
+        k::grind_dev(LN, d_tr, cfg.pow_bits, J.grind_base, J.grind_chunk);
+        FR_HIP(ctx, hipMemcpyAsync(ctx->pinned, d_tr, hdr + ((size_t)16 << last), hipMemcpyDeviceToHost, s));
         FR_HIP(ctx, hipGetLastError());
-        if (ht->n_roots != 1 + n_inner || ht->n_last_poly != n_poly) return ctx->fail(FRIEDA_ERR_INVARIANT, "internal: transcript out of step");
-        nonce = ht->nonce;
-        ch = ht->ch;
-        for (uint32_t li = 0; li <= n_inner; li++)
-            for (int w = 0; w < 8; w++)
-                for (int bb = 0; bb < 4; bb++) roots[li][4 * w + bb] = (uint8_t)(ht->roots[li][w] >> (8 * bb));
-        lastv.resize(n_poly);
-        for (size_t i = 0; i < n_poly; i++)
-            lastv[i] = {ht->last_poly[4 * i], ht->last_poly[4 * i + 1], ht->last_poly[4 * i + 2], ht->last_poly[4 * i + 3]};
+        ctx->phase_ms[0] = ms_since(J.t_start);  // commit phase fully enqueued
     } else {
         auto fetch_root = [&](const FriLayerDev& lay, Hash32& root) -> int {
             FR_HIP(ctx, hipMemcpyAsync(ctx->pinned, A + lay.o_tree + k::merkle_layer_offset(lay.log, 0), 32, hipMemcpyDeviceToHost, s));
@@ -437,19 +449,67 @@ int prove(Ctx* ctx, const uint8_t* data, size_t len, bool data_on_device, const 
                 k::grind_scan(LN, ch.digest, cfg.pow_bits, base, chunk, d_nonce);
                 FR_HIP(ctx, hipMemcpyAsync(ctx->pinned, d_nonce, 8, hipMemcpyDeviceToHost, s));
                 FR_HIP(ctx, hipStreamSynchronize(s));
-                memcpy(&nonce, ctx->pinned, 8);
-                if (nonce != ~0ull) break;
+                memcpy(&J.nonce, ctx->pinned, 8);
+                if (J.nonce != ~0ull) break;
                 base += chunk;
                 if (chunk < ((uint64_t)1 << 28)) chunk <<= 1;
             }
         }
+        ctx->phase_ms[0] = ms_since(J.t_start);
     }
-    ctx->phase_ms[1] = ms_since(t_start);  // commit phase + grind complete on the device (first synchronise)
+    ctx->job = std::move(jp);
+    return FRIEDA_OK;
+}
+
+int prove_finish(Ctx* ctx, uint8_t out_commitment[32], ProofData& out) {
+    if (!ctx->job) return ctx->fail(FRIEDA_ERR_ARG, "no proof in flight on this context");
+    std::unique_ptr<ProveJob, ProveJobDeleter> jp = std::move(ctx->job);  // released on every exit path
+    ProveJob& J = *jp;
+    FR_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    const k::Launch LN = ctx->launch();
+    uint8_t* A = ctx->arena;
+    const frieda_pcs_config cfg = J.cfg;
+    const uint32_t n = J.n, last = J.last, n_inner = J.n_inner;
+    const size_t N = J.N;
+    const FriLayerDev& first = J.first;
+    const std::vector<FriLayerDev>& inner = J.inner;
+    Channel& ch = J.ch;
+    std::vector<Hash32>& roots = J.roots;
+    std::vector<QM31>& lastv = J.lastv;
+    uint64_t nonce = J.nonce;
+
+    if (J.dev_channel) {
+        DevTranscript* d_tr = reinterpret_cast<DevTranscript*>(A + J.o_tr);
+        const size_t hdr = offsetof(DevTranscript, last_poly);
+        const size_t n_poly = (size_t)1 << last;
+        const DevTranscript* ht = reinterpret_cast<const DevTranscript*>(ctx->pinned);
+        for (;;) {
+            FR_HIP(ctx, hipStreamSynchronize(s));
+            if (ht->status & 1u) return ctx->fail(FRIEDA_ERR_INVARIANT, "invalid degree");  // assert! upstream
+            if (ht->nonce != ~0ull) break;
+            J.grind_base += J.grind_chunk;
+            if (J.grind_chunk < ((uint64_t)1 << 28)) J.grind_chunk <<= 1;
+            k::grind_dev(LN, d_tr, cfg.pow_bits, J.grind_base, J.grind_chunk);
+            FR_HIP(ctx, hipMemcpyAsync(ctx->pinned, d_tr, hdr + 16 * n_poly, hipMemcpyDeviceToHost, s));
+        }
+        FR_HIP(ctx, hipGetLastError());
+        if (ht->n_roots != 1 + n_inner || ht->n_last_poly != n_poly) return ctx->fail(FRIEDA_ERR_INVARIANT, "internal: transcript out of step");
+        nonce = ht->nonce;
+        ch = ht->ch;
+        for (uint32_t li = 0; li <= n_inner; li++)
+            for (int w = 0; w < 8; w++)
+                for (int bb = 0; bb < 4; bb++) roots[li][4 * w + bb] = (uint8_t)(ht->roots[li][w] >> (8 * bb));
+        lastv.resize(n_poly);
+        for (size_t i = 0; i < n_poly; i++)
+            lastv[i] = {ht->last_poly[4 * i], ht->last_poly[4 * i + 1], ht->last_poly[4 * i + 2], ht->last_poly[4 * i + 3]};
+    }
+    ctx->phase_ms[1] = ms_since(J.t_start);  // commit phase + grind complete on the device (first synchronise)
     ch.mix_u64(nonce);  // src/proof.rs:59
 
     // ---- FriProver::decommit ----
     std::vector<uint32_t> queries = generate_queries(ch, n, cfg.n_queries);
-    ctx->phase_ms[2] = ms_since(t_start);  // queries drawn
+    ctx->phase_ms[2] = ms_since(J.t_start);  // queries drawn
     GatherPlan g;
     // Proof.evaluations (src/proof.rs:62-66)
     for (uint32_t q : queries)
@@ -468,18 +528,18 @@ int prove(Ctx* ctx, const uint8_t* data, size_t len, bool data_on_device, const 
         counts[kx + 1].n_hashes = plan_merkle_decommit(pos, inner[kx], g);
         lq = fold_queries(lq, 1);
     }
-    if (g.word_idx.size() > max_words || g.hash_idx.size() > max_hashes) return ctx->fail(FRIEDA_ERR_INVARIANT, "internal: gather plan overflow");
-    FR_HIP(ctx, hipMemcpyAsync(A + o_widx, g.word_idx.data(), 8 * g.word_idx.size(), hipMemcpyHostToDevice, s));
-    if (!g.hash_idx.empty()) FR_HIP(ctx, hipMemcpyAsync(A + o_hidx, g.hash_idx.data(), 8 * g.hash_idx.size(), hipMemcpyHostToDevice, s));
-    k::gather(LN, reinterpret_cast<const uint32_t*>(A), reinterpret_cast<const uint64_t*>(A + o_widx), g.word_idx.size(),
-              reinterpret_cast<uint32_t*>(A + o_wout), reinterpret_cast<const uint64_t*>(A + o_hidx), g.hash_idx.size(), A + o_hout);
+    if (g.word_idx.size() > J.max_words || g.hash_idx.size() > J.max_hashes) return ctx->fail(FRIEDA_ERR_INVARIANT, "internal: gather plan overflow");
+    FR_HIP(ctx, hipMemcpyAsync(A + J.o_widx, g.word_idx.data(), 8 * g.word_idx.size(), hipMemcpyHostToDevice, s));
+    if (!g.hash_idx.empty()) FR_HIP(ctx, hipMemcpyAsync(A + J.o_hidx, g.hash_idx.data(), 8 * g.hash_idx.size(), hipMemcpyHostToDevice, s));
+    k::gather(LN, reinterpret_cast<const uint32_t*>(A), reinterpret_cast<const uint64_t*>(A + J.o_widx), g.word_idx.size(),
+              reinterpret_cast<uint32_t*>(A + J.o_wout), reinterpret_cast<const uint64_t*>(A + J.o_hidx), g.hash_idx.size(), A + J.o_hout);
     uint8_t* hp = reinterpret_cast<uint8_t*>(ctx->pinned);
     const size_t wbytes = 4 * g.word_idx.size();
-    FR_HIP(ctx, hipMemcpyAsync(hp, A + o_wout, wbytes, hipMemcpyDeviceToHost, s));
-    if (!g.hash_idx.empty()) FR_HIP(ctx, hipMemcpyAsync(hp + wbytes, A + o_hout, 32 * g.hash_idx.size(), hipMemcpyDeviceToHost, s));
+    FR_HIP(ctx, hipMemcpyAsync(hp, A + J.o_wout, wbytes, hipMemcpyDeviceToHost, s));
+    if (!g.hash_idx.empty()) FR_HIP(ctx, hipMemcpyAsync(hp + wbytes, A + J.o_hout, 32 * g.hash_idx.size(), hipMemcpyDeviceToHost, s));
     FR_HIP(ctx, hipStreamSynchronize(s));
     FR_HIP(ctx, hipGetLastError());
-    ctx->phase_ms[3] = ms_since(t_start);  // gather done (second and last synchronise)
+    ctx->phase_ms[3] = ms_since(J.t_start);  // gather done (second and last synchronise)
 
     // ---- assemble Proof (src/proof.rs:67-76) ----
     const uint32_t* wv = reinterpret_cast<const uint32_t*>(hp);
@@ -492,7 +552,7 @@ int prove(Ctx* ctx, const uint8_t* data, size_t len, bool data_on_device, const 
     };
     out = ProofData{};
     out.pcs_config = cfg;
-    out.log_size_bound = sh.L;
+    out.log_size_bound = J.sh.L;
     out.proof_of_work = nonce;
     out.last_layer_poly = lastv;
     out.evaluations.resize(queries.size());
@@ -509,9 +569,16 @@ int prove(Ctx* ctx, const uint8_t* data, size_t len, bool data_on_device, const 
             hi++;
         }
     }
-    ctx->phase_ms[4] = ms_since(t_start);  // proof assembled
+    ctx->phase_ms[4] = ms_since(J.t_start);  // proof assembled
     memcpy(out_commitment, roots[0].data(), 32);
     return FRIEDA_OK;
+}
+
+int prove(Ctx* ctx, const uint8_t* data, size_t len, bool data_on_device, const uint64_t* seed, frieda_pcs_config cfg,
+          uint8_t out_commitment[32], ProofData& out) {
+    int rc = prove_begin(ctx, data, len, data_on_device, seed, cfg);
+    if (rc) return rc;
+    return prove_finish(ctx, out_commitment, out);
 }
 
 }  // namespace frieda

@@ -197,7 +197,7 @@ constexpr int QROT2 = 0x4E;  // lane q reads lane q+2
 constexpr int QROT3 = 0x93;  // lane q reads lane q+3
 
 struct QuadOffsets {
-    uint32_t w[40];  // round r, fetch k (0,1: column step; 2,3: diagonal step): LDS word offset of the message word
+    uint32_t w[40];  // round r, fetch k (0,1: column step; 2,3: diagonal step): LDS byte offset of the message word
 };
 
 __device__ __forceinline__ void quad_offsets_init(QuadOffsets& o, uint32_t q) {
@@ -212,7 +212,7 @@ __device__ __forceinline__ void quad_offsets_init(QuadOffsets& o, uint32_t q) {
             if (q == 2) idx = b2detail::SIGMA[r][(k < 2 ? 0 : 8) + 4 + (k & 1)];
             if (q == 3) idx = b2detail::SIGMA[r][(k < 2 ? 0 : 8) + 6 + (k & 1)];
             (void)pos;
-            o.w[4 * r + k] = idx + (idx >> 3);
+            o.w[4 * r + k] = 4u * (idx + (idx >> 3));  // byte offset
         }
     }
 }
@@ -225,9 +225,11 @@ struct Quad2 {
 __device__ __forceinline__ Quad2 b2_compress_quad(const uint32_t* msg, const QuadOffsets& o, uint32_t ha, uint32_t hb, uint32_t c,
                                                   uint32_t d) {
     uint32_t a = ha, b = hb;
+    const char* mbase = reinterpret_cast<const char*>(msg);
+    auto fetch = [&](int i) { return *reinterpret_cast<const uint32_t*>(mbase + o.w[i]); };
 #pragma unroll
     for (int r = 0; r < 10; r++) {
-        const uint32_t m0 = msg[o.w[4 * r]], m1 = msg[o.w[4 * r + 1]], m2 = msg[o.w[4 * r + 2]], m3 = msg[o.w[4 * r + 3]];
+        const uint32_t m0 = fetch(4 * r), m1 = fetch(4 * r + 1), m2 = fetch(4 * r + 2), m3 = fetch(4 * r + 3);
         FR_B2_G(a, b, c, d, m0, m1);
         b = quad_perm<QROT1>(b);
         c = quad_perm<QROT2>(c);
@@ -609,7 +611,7 @@ __global__ __launch_bounds__(256) void grind_dev_kernel(GrindArgs a) {
 
 // Launches with few level-A nodes cannot fill the chip and are latency-bound: they use 256-node workgroups (one hash per
 // thread and level, four times as many workgroups) instead of 1024-node ones.
-constexpr uint32_t T5_SMALL_LOG = 16;  // level_a below this: 256-node workgroups
+constexpr uint32_t T5_SMALL_LOG = 20;  // level_a below this: 256-node workgroups
 uint32_t tree5_units_log(uint32_t level_a) { return level_a < T5_SMALL_LOG ? 8u : 10u; }
 
 void launch_tree5(const Launch& L, int mode, const TreeArgs& a, const char* name, double alg_bytes) {

@@ -93,6 +93,13 @@ int frieda_commit_and_generate_proof(frieda_ctx* ctx, const uint8_t* data, size_
                                      frieda_pcs_config cfg, uint8_t out_commitment[32], frieda_proof** out);
 int frieda_commit_and_generate_proof_device(frieda_ctx* ctx, const void* d_data, size_t len, const uint64_t* seed,
                                             frieda_pcs_config cfg, uint8_t out_commitment[32], frieda_proof** out);
+/* The same, split in two so that several proofs can overlap on one GPU: _begin enqueues the encode and the whole FRI
+ * commit phase on the ctx stream and returns without synchronising; _finish waits for it, draws the queries, gathers the
+ * openings and builds the proof.  At most one proof in flight per ctx — use one ctx (= one stream + workspace) per
+ * in-flight proof.  A blob passed to _begin_device must stay valid until _finish returns. */
+int frieda_prove_begin(frieda_ctx* ctx, const uint8_t* data, size_t len, const uint64_t* seed, frieda_pcs_config cfg);
+int frieda_prove_begin_device(frieda_ctx* ctx, const void* d_data, size_t len, const uint64_t* seed, frieda_pcs_config cfg);
+int frieda_prove_finish(frieda_ctx* ctx, uint8_t out_commitment[32], frieda_proof** out);
 /* api::generate_proof (src/lib.rs:36) */
 int frieda_generate_proof(frieda_ctx* ctx, const uint8_t* data, size_t len, const uint64_t* seed, frieda_pcs_config cfg,
                           frieda_proof** out);

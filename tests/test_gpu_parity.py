@@ -297,6 +297,39 @@ def test_reference_proof_tests_on_gpu(gpu_ctx, blob):
     assert not frieda_amd.verify(p1, 2) and not frieda_amd.verify(p2, 1)
 
 
+def test_pipelined_proofs_match_sequential(gpu_ctx, oracle):
+    """Several proofs in flight on separate contexts (frieda_prove_begin / _finish) give byte-identical proofs."""
+    import torch
+
+    import frieda_amd
+
+    cfg = _cfg(frieda_amd, 12, 4, 0, 20)
+    blobs = [splitmix64_bytes(300 + i, blob_len_for(14 + (i % 3))) for i in range(7)]
+    dev = [torch.from_numpy(b).cuda() for b in blobs]
+    torch.cuda.synchronize()
+    expect = [gpu_ctx.commit_and_generate_proof(b, 11 + i, cfg) for i, b in enumerate(blobs)]
+    pipe = frieda_amd.ProofPipeline(0, depth=3)
+    got = []
+    for i, d in enumerate(dev):
+        r = pipe.submit_device(d.data_ptr(), d.numel(), 11 + i, cfg)
+        if r is not None:
+            got.append(r)
+    got += pipe.drain()
+    pipe.close()
+    assert len(got) == len(blobs)
+    for (er, ep), (gr, gp) in zip(expect, got):
+        assert er == gr and ep.serialize() == gp.serialize()
+    o_root, o_proof = oracle.commit_and_generate_proof(blobs[0], 11, oracle.make_config(12, 4, 0, 20))
+    assert got[0][0] == o_root and got[0][1].serialize() == o_proof.serialize()
+    # protocol errors: finish without begin, begin twice
+    with pytest.raises(frieda_amd.FriedaError):
+        gpu_ctx.prove_finish()
+    gpu_ctx.prove_begin_device(dev[0].data_ptr(), dev[0].numel(), 1, cfg)
+    with pytest.raises(frieda_amd.FriedaError):
+        gpu_ctx.prove_begin_device(dev[0].data_ptr(), dev[0].numel(), 1, cfg)
+    gpu_ctx.prove_finish()
+
+
 def test_panics_map_to_status(gpu_ctx):
     import frieda_amd
 
