@@ -60,6 +60,19 @@ def algorithmic_bytes(n, workload, log_blowup=4, log_last=0):
     return total
 
 
+def traffic_from_profiles(kernel, n, workload):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE collected
+    in separate runs and corrected as MI355X_MICROARCH.md §HBM prescribes; tools/traffic_from_pmc.py).  Only valid for the
+    configuration the counters were taken on (2^24 domain); None otherwise."""
+    path = os.path.join(ROOT, "profiles", "r01_prove24_traffic.json")
+    if n != 24 or not os.path.exists(path):
+        return None
+    try:
+        return json.load(open(path))["kernels"][kernel]["traffic_bytes_per_launch"]
+    except (KeyError, ValueError):
+        return None
+
+
 def cpu_baseline(sample_log, workload, calls):
     from oracle import oracle as O
 
@@ -107,10 +120,15 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    # FRIEDA_BENCH_FORCE_DIST=1 exercises the collective path (RCCL init, all_gather of roots, barrier, max-reduce) with a
+    # single rank — the only way to validate it on a one-GPU box
+    use_dist = world > 1 or os.environ.get("FRIEDA_BENCH_FORCE_DIST") == "1"
+    if use_dist:
         import torch.distributed as dist
 
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     import frieda_amd
 
@@ -129,21 +147,21 @@ def main():
     def step():
         if args.workload == "prove":
             root, proof = ctx.commit_and_generate_proof_device(blob.data_ptr(), blob_len, seed, cfg)
-            if world > 1:
+            if use_dist:
                 roots_dev.copy_(torch.frombuffer(bytearray(root), dtype=torch.uint8))
             return root, proof
         ctx.commit_device(blob.data_ptr(), blob_len, 4, roots_dev.data_ptr())
-        if world > 1:
+        if use_dist:
             ctx.synchronize()
         return None, None
 
     def gather_roots():
-        if world > 1:
+        if use_dist:
             dist.all_gather_into_tensor(gathered, roots_dev)
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -159,10 +177,13 @@ def main():
         gather_roots()
     fence()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        # every rank now holds every root: rank r's own root must sit in slot r
+        torch.cuda.synchronize()
+        assert bytes(gathered[32 * rank : 32 * rank + 32].cpu().numpy()) == bytes(roots_dev.cpu().numpy()), "root gather mismatch"
 
     # correctness gate on what was just timed: the proof verifies and its first root equals commit()'s
     if args.workload == "prove":
@@ -197,7 +218,7 @@ def main():
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": ach / HBM_PEAK_GBS,
-            "traffic": None,
+            "traffic": traffic_from_profiles(dom["name"], n, args.workload),
             "avg_launch_us": 1e3 * dom["total_ms"] / max(dom["launches"], 1),
             "launches_per_step": dom["launches"] / args.steps,
             "alg_bytes_per_launch": dom["alg_bytes"] / max(dom["launches"], 1),
@@ -282,7 +303,7 @@ def main():
     if rank == 0:
         print(json.dumps(out), flush=True)
     ctx.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
