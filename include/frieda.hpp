@@ -1,0 +1,167 @@
+// frieda.hpp — header-only C++17 mirror of frieda's public Rust API over the C ABI (frieda_hip.h).
+//
+//   frieda::api::commit(data, log_blowup_factor) -> Commitment                         (/root/reference/src/lib.rs:31)
+//   frieda::api::generate_proof(data, seed, pcs_config) -> Proof                       (src/lib.rs:36)
+//   frieda::proof::commit_and_generate_proof(data, seed, pcs_config) -> {Commitment, Proof}   (src/proof.rs:32)
+//   frieda::api::verify(proof, seed) -> bool                                           (src/lib.rs:41)
+//
+// Same names, argument meaning and error behaviour: where the reference panics, frieda::Panic is thrown; verifier
+// rejections return false.  Option<u64> is std::optional<uint64_t>.  A thread-local default context (device 0) backs the
+// free functions; construct frieda::Context for other devices / streams.
+#pragma once
+#include <array>
+#include <cstdint>
+#include <optional>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "frieda_hip.h"
+
+namespace frieda {
+
+using Commitment = std::array<uint8_t, 32>;  // src/commit.rs:9
+
+struct Error : std::runtime_error {
+    int status;
+    Error(int s, const std::string& what) : std::runtime_error(what), status(s) {}
+};
+struct Panic : Error {  // the reference implementation panics here (FRIEDA_ERR_INVARIANT)
+    using Error::Error;
+};
+
+inline void check(int status, const frieda_ctx* ctx = nullptr) {
+    if (status == FRIEDA_OK) return;
+    std::string msg = std::string("frieda_hip: ") + frieda_status_string(status);
+    if (ctx) msg += std::string(": ") + frieda_last_error(ctx);
+    if (status == FRIEDA_ERR_INVARIANT) throw Panic(status, msg);
+    throw Error(status, msg);
+}
+
+// stwo FriConfig / PcsConfig as constructed at src/proof.rs:109-116
+struct FriConfig {
+    uint32_t log_blowup_factor = 4, log_last_layer_degree_bound = 0;
+    size_t n_queries = 20;
+};
+struct PcsConfig {
+    uint32_t pow_bits = 20;
+    FriConfig fri_config;
+    frieda_pcs_config c() const {
+        return {pow_bits, fri_config.log_blowup_factor, fri_config.log_last_layer_degree_bound, (uint32_t)fri_config.n_queries};
+    }
+};
+
+struct QM31 {
+    uint32_t v[4];
+    bool operator==(const QM31& o) const { return v[0] == o.v[0] && v[1] == o.v[1] && v[2] == o.v[2] && v[3] == o.v[3]; }
+    bool operator!=(const QM31& o) const { return !(*this == o); }
+};
+
+// frieda::proof::Proof (src/proof.rs:19-26); the fields the reference's tests mutate are exposed as accessors
+class Proof {
+  public:
+    Proof() = default;
+    explicit Proof(frieda_proof* h) : h_(h) {}
+    Proof(const Proof& o) { check(frieda_proof_clone(o.h_, &h_)); }
+    Proof(Proof&& o) noexcept : h_(o.h_) { o.h_ = nullptr; }
+    Proof& operator=(Proof o) {
+        std::swap(h_, o.h_);
+        return *this;
+    }
+    ~Proof() { frieda_proof_free(h_); }
+
+    uint64_t proof_of_work() const { return frieda_proof_proof_of_work(h_); }
+    void set_proof_of_work(uint64_t v) { frieda_proof_set_proof_of_work(h_, v); }
+    uint32_t log_size_bound() const { return frieda_proof_log_size_bound(h_); }
+    size_t n_inner_layers() const { return frieda_proof_n_inner_layers(h_); }
+    Commitment first_layer_commitment() const {
+        Commitment c;
+        const uint8_t* p = frieda_proof_layer_commitment(h_, 0);
+        for (int i = 0; i < 32; i++) c[i] = p[i];
+        return c;
+    }
+    std::vector<QM31> evaluations() const {
+        size_t n = frieda_proof_n_evaluations(h_);
+        std::vector<QM31> out(n);
+        const uint32_t* p = frieda_proof_evaluations(h_);
+        for (size_t i = 0; i < n; i++)
+            for (int c = 0; c < 4; c++) out[i].v[c] = p[4 * i + c];
+        return out;
+    }
+    void set_evaluations(const std::vector<QM31>& ev) {
+        check(frieda_proof_resize_evaluations(h_, ev.size()));
+        uint32_t* p = frieda_proof_evaluations(h_);
+        for (size_t i = 0; i < ev.size(); i++)
+            for (int c = 0; c < 4; c++) p[4 * i + c] = ev[i].v[c];
+    }
+    std::vector<uint8_t> serialize() const {
+        std::vector<uint8_t> b(frieda_proof_serialize(h_, nullptr, 0));
+        frieda_proof_serialize(h_, b.data(), b.size());
+        return b;
+    }
+    static Proof deserialize(const std::vector<uint8_t>& b) {
+        frieda_proof* h = nullptr;
+        check(frieda_proof_deserialize(b.data(), b.size(), &h));
+        return Proof(h);
+    }
+    const frieda_proof* handle() const { return h_; }
+
+  private:
+    frieda_proof* h_ = nullptr;
+};
+
+class Context {
+  public:
+    explicit Context(int device = 0, void* stream = nullptr) { check(frieda_ctx_create(device, stream, &h_)); }
+    Context(const Context&) = delete;
+    Context& operator=(const Context&) = delete;
+    ~Context() { frieda_ctx_destroy(h_); }
+
+    Commitment commit(const uint8_t* data, size_t len, uint32_t log_blowup_factor) {
+        Commitment root;
+        check(frieda_commit(h_, data, len, log_blowup_factor, root.data()), h_);
+        return root;
+    }
+    std::pair<Commitment, Proof> commit_and_generate_proof(const uint8_t* data, size_t len, std::optional<uint64_t> seed,
+                                                           const PcsConfig& cfg) {
+        Commitment root;
+        frieda_proof* p = nullptr;
+        uint64_t s = seed.value_or(0);
+        check(frieda_commit_and_generate_proof(h_, data, len, seed ? &s : nullptr, cfg.c(), root.data(), &p), h_);
+        return {root, Proof(p)};
+    }
+    frieda_ctx* handle() { return h_; }
+
+  private:
+    frieda_ctx* h_ = nullptr;
+};
+
+inline Context& default_context() {
+    thread_local Context ctx(0);
+    return ctx;
+}
+
+namespace proof {
+inline std::pair<Commitment, Proof> commit_and_generate_proof(const std::vector<uint8_t>& data, std::optional<uint64_t> seed,
+                                                              const PcsConfig& cfg) {
+    return default_context().commit_and_generate_proof(data.data(), data.size(), seed, cfg);
+}
+}  // namespace proof
+
+namespace api {
+inline Commitment commit(const std::vector<uint8_t>& data, uint32_t log_blowup_factor) {
+    return default_context().commit(data.data(), data.size(), log_blowup_factor);
+}
+inline Proof generate_proof(const std::vector<uint8_t>& data, std::optional<uint64_t> seed, const PcsConfig& cfg) {
+    return proof::commit_and_generate_proof(data, seed, cfg).second;
+}
+inline bool verify(const Proof& proof, std::optional<uint64_t> seed) {
+    int ok = 0;
+    uint64_t s = seed.value_or(0);
+    check(frieda_verify(proof.handle(), seed ? &s : nullptr, &ok));
+    return ok != 0;
+}
+}  // namespace api
+
+}  // namespace frieda

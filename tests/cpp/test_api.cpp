@@ -1,0 +1,111 @@
+// test_api.cpp — the reference's own unit tests (/root/reference/src/commit.rs:28-38, src/proof.rs:119-193,
+// src/lib.rs:52-85), transcribed to C++ over include/frieda.hpp.  Built by __graft_entry__.build(), run on the GPU box by
+// tests/test_gpu_parity.py::test_cpp_api_harness.  argv[1] = path of the `blob` fixture.  Exit code 0 = all passed.
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <iterator>
+
+#include "frieda.hpp"
+
+using namespace frieda;
+
+static int failures = 0;
+#define CHECK(cond)                                                  \
+    do {                                                             \
+        if (!(cond)) {                                               \
+            std::printf("FAIL %s:%d  %s\n", __FILE__, __LINE__, #cond); \
+            failures++;                                              \
+        }                                                            \
+    } while (0)
+
+static const PcsConfig PCS_CONFIG{20, FriConfig{4, 1, 20}};  // src/proof.rs:109-116
+
+int main(int argc, char** argv) {
+    if (argc < 2) return 2;
+    std::ifstream f(argv[1], std::ios::binary);
+    std::vector<uint8_t> data((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+    CHECK(data.size() == 262146);
+
+    // test_commit (src/commit.rs:28-38): the golden root
+    const uint8_t golden[32] = {209, 162, 213, 6,  157, 197, 135, 229, 93,  194, 156, 198, 37, 90, 249, 55,
+                                255, 127, 237, 14, 228, 27,  223, 90,  249, 135, 23,  249, 215, 79, 96,  232};
+    Commitment root = api::commit(data, 4);
+    CHECK(std::memcmp(root.data(), golden, 32) == 0);
+
+    // test_generate_proof / test_commit_and_generate_proof (src/proof.rs:119-135)
+    auto [commitment, proof] = proof::commit_and_generate_proof(data, std::nullopt, PCS_CONFIG);
+    CHECK(proof.n_inner_layers() != 0);
+    CHECK(commitment == root);
+    CHECK(proof.first_layer_commitment() == commitment);
+    // test_verify_proof
+    CHECK(api::verify(proof, std::nullopt));
+    {  // invalid pow
+        Proof p = proof;
+        p.set_proof_of_work(p.proof_of_work() + 1);
+        CHECK(!api::verify(p, std::nullopt));
+    }
+    {  // invalid evaluations: evaluations[0] += (1, 1, 1, 1)
+        Proof p = proof;
+        auto ev = p.evaluations();
+        for (int c = 0; c < 4; c++) ev[0].v[c] = (ev[0].v[c] + 1) % 0x7fffffffu;
+        p.set_evaluations(ev);
+        CHECK(!api::verify(p, std::nullopt));
+    }
+    {  // reversed
+        Proof p = proof;
+        auto ev = p.evaluations();
+        std::reverse(ev.begin(), ev.end());
+        p.set_evaluations(ev);
+        CHECK(!api::verify(p, std::nullopt));
+    }
+    {  // popped: #[should_panic]
+        Proof p = proof;
+        auto ev = p.evaluations();
+        ev.pop_back();
+        p.set_evaluations(ev);
+        bool panicked = false;
+        try {
+            api::verify(p, std::nullopt);
+        } catch (const Panic&) {
+            panicked = true;
+        }
+        CHECK(panicked);
+    }
+    {  // swap(0, 1)
+        Proof p = proof;
+        auto ev = p.evaluations();
+        std::swap(ev[0], ev[1]);
+        p.set_evaluations(ev);
+        CHECK(!api::verify(p, std::nullopt));
+    }
+    {  // seeds (src/proof.rs:183-193)
+        Proof p1 = api::generate_proof(data, 1, PCS_CONFIG), p2 = api::generate_proof(data, 2, PCS_CONFIG);
+        CHECK(p1.evaluations() != p2.evaluations());
+        CHECK(api::verify(p1, 1) && api::verify(p2, 2));
+        CHECK(!api::verify(p1, 2) && !api::verify(p2, 1));
+    }
+    {  // test_end_to_end (src/lib.rs:52-85)
+        const char* s = "This is the original data that needs to be made available.";
+        std::vector<uint8_t> d(s, s + std::strlen(s));
+        Commitment c = api::commit(d, 4);
+        Proof p = api::generate_proof(d, std::nullopt, PcsConfig{20, FriConfig{4, 0, 20}});
+        CHECK(api::verify(p, std::nullopt));
+        CHECK(p.first_layer_commitment() == c);
+        Proof q = Proof::deserialize(p.serialize());
+        CHECK(api::verify(q, std::nullopt));
+    }
+    {  // too small a polynomial for the FRI configuration: the reference panics
+        std::vector<uint8_t> tiny = {1, 2, 3};
+        bool panicked = false;
+        try {
+            api::generate_proof(tiny, std::nullopt, PCS_CONFIG);
+        } catch (const Panic&) {
+            panicked = true;
+        }
+        CHECK(panicked);
+    }
+    std::printf("%s (%d failures)\n", failures ? "FAILED" : "ok", failures);
+    return failures ? 1 : 0;
+}

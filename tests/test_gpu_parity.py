@@ -330,6 +330,19 @@ def test_pipelined_proofs_match_sequential(gpu_ctx, oracle):
     gpu_ctx.prove_finish()
 
 
+def test_cpp_api_harness(gpu_ctx):
+    """The reference's unit tests transcribed to C++ over include/frieda.hpp (tests/cpp/test_api.cpp)."""
+    import os
+    import subprocess
+
+    from conftest import GOLDEN, ROOT
+
+    exe = os.path.join(ROOT, "tests", "cpp", "test_api.bin")
+    assert os.path.exists(exe), "run __graft_entry__.build() first"
+    r = subprocess.run([exe, os.path.join(GOLDEN, "blob")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+
+
 def test_panics_map_to_status(gpu_ctx):
     import frieda_amd
 
@@ -367,6 +380,41 @@ def test_full_size_prove_verify_and_tie(gpu_ctx, n):
     assert not frieda_amd.verify(p, seed)
     # serialisation round trip keeps the proof valid
     assert frieda_amd.verify(frieda_amd.Proof.deserialize(proof.serialize()), seed)
+
+
+def test_large_domains_beyond_the_baseline_sizes(gpu_ctx):
+    """2^26 prove -> verify + tie, and commit() at FRIEDA_MAX_LOG_DOMAIN = 2^28 (index arithmetic beyond 2^24; ~45 GB and
+    ~12 GB of workspace).  The 2^28 root is checked against a second, independent device computation: Level B encode +
+    single-layer Merkle kernels instead of the fused path."""
+    import ctypes as C
+
+    import frieda_amd
+
+    data = splitmix64_bytes(7, blob_len_for(26))
+    cfg = _cfg(frieda_amd, 16, 4, 0, 20)
+    commitment, proof = gpu_ctx.commit_and_generate_proof(data, 5, cfg)
+    assert proof.n_inner_layers == 26 - 1 - 4
+    assert commitment == gpu_ctx.commit(data, 4)
+    assert frieda_amd.verify(proof, 5) and not frieda_amd.verify(proof, 6)
+    del proof
+
+    n = 28
+    data = splitmix64_bytes(8, blob_len_for(n))
+    root = gpu_ctx.commit(data, 4)
+    L_ = gpu_ctx._L
+    d_in = DevBuf.from_array(gpu_ctx, data)
+    d_coef, d_ev = DevBuf(gpu_ctx, 16 << (n - 4)), DevBuf(gpu_ctx, 16 << n)
+    _check(gpu_ctx, L_.frieda_unpack30(gpu_ctx._h, d_in.ptr, data.size, d_coef.ptr, 4 << (n - 4)))
+    _check(gpu_ctx, L_.frieda_circle_evaluate(gpu_ctx._h, d_coef.ptr, 4, n - 4, n, d_ev.ptr))
+    # layer-by-layer tree with the trait-granular kernels, ping-ponging two buffers
+    bufs = [DevBuf(gpu_ctx, 32 << n), DevBuf(gpu_ctx, 32 << (n - 1))]
+    cols = (C.c_void_p * 4)(*[C.c_void_p(d_ev.ptr.value + (c << (n + 2))) for c in range(4)])
+    _check(gpu_ctx, L_.frieda_merkle_commit_layer(gpu_ctx._h, n, None, cols, 4, bufs[0].ptr))
+    cur = 0
+    for l in range(n - 1, -1, -1):
+        _check(gpu_ctx, L_.frieda_merkle_commit_layer(gpu_ctx._h, l, bufs[cur].ptr, None, 0, bufs[1 - cur].ptr))
+        cur = 1 - cur
+    assert bytes(bufs[cur].to_array(np.uint8, (32,))) == root
 
 
 def test_full_size_encode_linearity(gpu_ctx):
