@@ -612,7 +612,7 @@ __global__ __launch_bounds__(256) void grind_dev_kernel(GrindArgs a) {
 // Launches with few level-A nodes cannot fill the chip and are latency-bound: they use 256-node workgroups (one hash per
 // thread and level, four times as many workgroups) instead of 1024-node ones.
 constexpr uint32_t T5_SMALL_LOG = 20;  // level_a below this: 256-node workgroups
-uint32_t tree5_units_log(uint32_t level_a) { return level_a < T5_SMALL_LOG ? 8u : 10u; }
+uint32_t tree5_units_log(uint32_t level_a) { return level_a < T5_SMALL_LOG ? 8u : (T5_UNITS == 1024 ? 10u : 9u); }
 
 void launch_tree5(const Launch& L, int mode, const TreeArgs& a, const char* name, double alg_bytes) {
     const size_t total = (size_t)1 << a.level_a;
