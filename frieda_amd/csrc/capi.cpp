@@ -360,6 +360,55 @@ int frieda_circle_evaluate(frieda_ctx* ctx, const uint32_t* d_coef, uint32_t nco
     FR_GUARD_END(ctx)
 }
 
+int frieda_circle_interpolate(frieda_ctx* ctx, const uint32_t* d_block, uint32_t ncols, uint32_t log_coef, uint32_t log_domain,
+                              uint32_t block, uint32_t* d_coef) {
+    if (!ctx || !d_block || !d_coef || ncols == 0 || ncols > 65535) return FRIEDA_ERR_ARG;
+    if (log_domain < 1 || log_domain > FRIEDA_MAX_LOG_DOMAIN || log_coef > log_domain) return FRIEDA_ERR_ARG;
+    if ((uint64_t)block >= ((uint64_t)1 << (log_domain - log_coef))) return FRIEDA_ERR_ARG;
+    FR_GUARD_BEGIN
+    FR_HIP(&ctx->c, hipSetDevice(ctx->c.device));
+    TwiddleSet ts;
+    int rc = ctx->c.get_twiddles(log_domain, ts);
+    if (rc) return rc;
+    k::circle_interpolate_block(ctx->c.launch(), d_block, (size_t)1 << log_coef, ncols, log_coef, log_domain, block, ts.d_itw, ts.ds,
+                                d_coef, (size_t)1 << log_coef);
+    FR_HIP(&ctx->c, hipGetLastError());
+    return FRIEDA_OK;
+    FR_GUARD_END(ctx)
+}
+
+int frieda_pack30(frieda_ctx* ctx, const uint32_t* d_felts, size_t n_felts, void* d_bytes, size_t len) {
+    if (!ctx || (len && (!d_felts || !d_bytes))) return FRIEDA_ERR_ARG;
+    if ((8 * len + 29) / 30 > n_felts) return ctx->c.fail(FRIEDA_ERR_ARG, "len needs more felts than given");
+    FR_HIP(&ctx->c, hipSetDevice(ctx->c.device));
+    k::pack30(ctx->c.launch(), d_felts, n_felts, static_cast<uint8_t*>(d_bytes), len);
+    FR_HIP(&ctx->c, hipGetLastError());
+    return FRIEDA_OK;
+}
+
+int frieda_reconstruct_device(frieda_ctx* ctx, const uint32_t* d_block, uint32_t log_coef, uint32_t log_domain, uint32_t block,
+                              size_t len, void* d_out_bytes) {
+    if (!ctx || !d_block || (len && !d_out_bytes)) return FRIEDA_ERR_ARG;
+    if (log_domain < 1 || log_domain > FRIEDA_MAX_LOG_DOMAIN || log_coef > log_domain) return FRIEDA_ERR_ARG;
+    if ((uint64_t)block >= ((uint64_t)1 << (log_domain - log_coef))) return FRIEDA_ERR_ARG;
+    const size_t n_felts = (size_t)4 << log_coef;
+    if ((8 * len + 29) / 30 > n_felts) return ctx->c.fail(FRIEDA_ERR_ARG, "len does not fit the polynomial");
+    FR_GUARD_BEGIN
+    FR_HIP(&ctx->c, hipSetDevice(ctx->c.device));
+    int rc = ctx->c.ensure_arena(sizeof(uint32_t) * n_felts);
+    if (rc) return rc;
+    TwiddleSet ts;
+    rc = ctx->c.get_twiddles(log_domain, ts);
+    if (rc) return rc;
+    uint32_t* coef = reinterpret_cast<uint32_t*>(ctx->c.arena);
+    k::circle_interpolate_block(ctx->c.launch(), d_block, (size_t)1 << log_coef, 4, log_coef, log_domain, block, ts.d_itw, ts.ds, coef,
+                                (size_t)1 << log_coef);
+    k::pack30(ctx->c.launch(), coef, n_felts, static_cast<uint8_t*>(d_out_bytes), len);
+    FR_HIP(&ctx->c, hipGetLastError());
+    return FRIEDA_OK;
+    FR_GUARD_END(ctx)
+}
+
 int frieda_merkle_commit_layer(frieda_ctx* ctx, uint32_t log_size, const void* d_prev, const uint32_t* const* d_cols, uint32_t ncols,
                                void* d_out) {
     if (!ctx || !d_out || log_size > FRIEDA_MAX_LOG_DOMAIN || (ncols && !d_cols) || ncols > 1024) return FRIEDA_ERR_ARG;

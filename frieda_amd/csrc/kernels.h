@@ -59,6 +59,13 @@ void gen_twiddles(const Launch& L, uint32_t n, const TwiddleSeeds& seeds, uint32
 void circle_evaluate(const Launch& L_, const uint32_t* d_coef, size_t coef_stride, uint32_t ncols, uint32_t L, uint32_t n,
                      const uint32_t* d_tw, DomainScalars ds, uint32_t* d_out, size_t out_stride);
 
+// ---- intt.hip (reconstruction side) ----
+// block `block` (2^L consecutive bit-reversed evaluations per column) -> the 2^L coefficients per column
+void circle_interpolate_block(const Launch& L_, const uint32_t* d_block, size_t in_stride, uint32_t ncols, uint32_t L, uint32_t n,
+                              uint32_t block, const uint32_t* d_itw, DomainScalars ds, uint32_t* d_coef, size_t out_stride);
+// inverse of unpack30: felts (30 significant bits each) -> the first `len` bytes of the LSB-first bit stream
+void pack30(const Launch& L_, const uint32_t* d_felts, size_t n_felts, uint8_t* d_out, size_t len);
+
 // ---- merkle.hip ----
 // leaves of 4 SoA columns: out[i] = H(c0[i], c1[i], c2[i], c3[i], 0 x 12)
 void merkle_leaf4(const Launch& L, const uint32_t* c0, const uint32_t* c1, const uint32_t* c2, const uint32_t* c3, size_t n,

@@ -152,6 +152,19 @@ int frieda_precompute_twiddles(frieda_ctx* ctx, uint32_t log_domain, const uint3
 int frieda_circle_evaluate(frieda_ctx* ctx, const uint32_t* d_coef, uint32_t ncols, uint32_t log_coef,
                            uint32_t log_domain, uint32_t* d_out);
 
+/* ---- reconstruction side (not called by frieda's three functions) ----
+ * PolyOps::interpolate generalised to one aligned block of the codeword: d_block[ncols][2^log_coef] holds entries
+ * block * 2^log_coef .. (block + 1) * 2^log_coef of each column of the bit-reversed evaluation on the 2^log_domain domain
+ * (any block < 2^(log_domain - log_coef), i.e. any 1 / 2^B of the codeword); d_coef[ncols][2^log_coef] receives the
+ * coefficients.  block = 0 with log_coef == log_domain is stwo's CpuBackend::interpolate. */
+int frieda_circle_interpolate(frieda_ctx* ctx, const uint32_t* d_block, uint32_t ncols, uint32_t log_coef, uint32_t log_domain,
+                              uint32_t block, uint32_t* d_coef);
+/* inverse of frieda_unpack30 (src/utils.rs:10-19 read backwards): n_felts 30-bit felts -> the first len bytes */
+int frieda_pack30(frieda_ctx* ctx, const uint32_t* d_felts, size_t n_felts, void* d_bytes, size_t len);
+/* both together for frieda's 4-column layout: a block of the 4 evaluation columns -> the original len bytes */
+int frieda_reconstruct_device(frieda_ctx* ctx, const uint32_t* d_block, uint32_t log_coef, uint32_t log_domain, uint32_t block,
+                              size_t len, void* d_out_bytes);
+
 /* MerkleOps::commit_on_layer(log_size, prev_layer, columns): d_prev is NULL or 2^(log_size+1) hashes;
  * d_cols is a host array of ncols device column pointers (2^log_size words each); d_out gets 2^log_size
  * 32-byte hashes */

@@ -280,6 +280,59 @@ void fo_circle_evaluate(const uint32_t* coef, uint32_t L, uint32_t n, const uint
 }
 
 /* ------------------------------------------------------------------------------------------------
+ * Reconstruction: inverse circle FFT of one aligned block of the codeword, and the 30-bit packer
+ * (stwo backend/cpu/circle.rs::interpolate generalised to the sub-coset that block k of the bit-reversed
+ * evaluation lives on: the same inverse layers, twiddle index offset by the block number)
+ * ---------------------------------------------------------------------------------------------- */
+static inline void ibutterfly(uint32_t* v0, uint32_t* v1, uint32_t itwid) {
+    uint32_t a = *v0, b = *v1;
+    *v0 = m31_add(a, b);
+    *v1 = m31_mul(m31_sub(a, b), itwid);
+}
+void fo_circle_interpolate_block(const uint32_t* block, uint32_t L, uint32_t n, uint32_t k, const uint32_t* itw, uint32_t* coef_out) {
+    size_t M = (size_t)1 << L;
+    memcpy(coef_out, block, M * sizeof(uint32_t));
+    if (L == 0) return;
+    coset h0 = coset_half_odds(n - 1);
+    cpoint init = cp_from_index(h0.initial);
+    /* circle layer (i = 0): pair (2h, 2h+1) with the inverse of Y[(k << (L-1)) | h] */
+    for (uint32_t h = 0; h < (1u << (L - 1)); h++) {
+        uint32_t gh = (k << (L - 1)) | h, t;
+        if (n < 3) {
+            uint32_t iy = m31_inv(init.y);
+            t = (gh & 1) ? m31_neg(iy) : iy;
+        } else {
+            uint32_t j = gh >> 2, r = gh & 3, x = itw[2 * j], y = itw[2 * j + 1];
+            t = r == 0 ? y : r == 1 ? m31_neg(y) : r == 2 ? m31_neg(x) : x;
+        }
+        ibutterfly(&coef_out[2 * h], &coef_out[2 * h + 1], t);
+    }
+    /* line layers i = 1 .. L-1, smallest stride first */
+    for (uint32_t i = 1; i < L; i++) {
+        const uint32_t* lvl = itw + tw_level_offset(n, i - 1);
+        for (uint32_t h = 0; h < (1u << (L - 1 - i)); h++) {
+            uint32_t t = lvl[(k << (L - 1 - i)) | h];
+            for (uint32_t l = 0; l < (1u << i); l++) {
+                uint32_t idx0 = (h << (i + 1)) + l;
+                ibutterfly(&coef_out[idx0], &coef_out[idx0 + (1u << i)], t);
+            }
+        }
+    }
+    uint32_t inv = m31_inv((uint32_t)M % P);
+    for (size_t j = 0; j < M; j++) coef_out[j] = m31_mul(coef_out[j], inv);
+}
+
+void fo_felts_to_bytes(const uint32_t* felts, size_t n_felts, uint8_t* out, size_t len) {
+    memset(out, 0, len);
+    for (size_t kf = 0; kf < n_felts; kf++)
+        for (unsigned j = 0; j < 30; j++) {
+            size_t bit = 30 * kf + j;
+            if ((bit >> 3) >= len) return;
+            out[bit >> 3] |= (uint8_t)(((felts[kf] >> j) & 1u) << (bit & 7));
+        }
+}
+
+/* ------------------------------------------------------------------------------------------------
  * Blake2s compression + Merkle (stwo core/vcs/{blake2s_ref,blake2_merkle,prover}.rs)
  * ---------------------------------------------------------------------------------------------- */
 static const uint32_t B2S_IV[8] = {0x6A09E667u, 0xBB67AE85u, 0x3C6EF372u, 0xA54FF53Au,

@@ -63,6 +63,13 @@ void fo_precompute_twiddles(uint32_t n, uint32_t* tw, uint32_t* itw);
  * coef: 2^L coefficients; out: 2^n evaluations in bit-reversed domain order. */
 void fo_circle_evaluate(const uint32_t* coef, uint32_t L, uint32_t n, const uint32_t* tw, uint32_t* out);
 
+/* ---- reconstruction side (stwo backend/cpu/circle.rs::interpolate, core/fft.rs::ibutterfly) ----
+ * block: the 2^L evaluations out[k * 2^L .. (k+1) * 2^L) of the bit-reversed codeword (any k < 2^(n-L)); coef_out: the 2^L
+ * coefficients.  k = 0 with L == n is exactly CpuBackend::interpolate on the canonic domain. */
+void fo_circle_interpolate_block(const uint32_t* block, uint32_t L, uint32_t n, uint32_t k, const uint32_t* itw, uint32_t* coef_out);
+/* inverse of fo_bytes_to_felt_le: felts (each < 2^30) -> the first `len` bytes of the LSB-first bit stream */
+void fo_felts_to_bytes(const uint32_t* felts, size_t n_felts, uint8_t* out, size_t len);
+
 /* ---- Merkle (stwo core/vcs/blake2_merkle.rs::hash_node, backend/cpu/blake2s.rs::commit_on_layer) ---- */
 void fo_blake2s_compress(const uint32_t h[8], const uint32_t m[16], uint32_t t0, uint32_t t1, uint32_t f0,
                          uint32_t f1, uint32_t out[8]);

@@ -90,6 +90,8 @@ def lib():
         L.fo_polynomial_from_bytes.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, u32p]
         L.fo_precompute_twiddles.argtypes = [C.c_uint32, C.c_void_p, C.c_void_p]
         L.fo_circle_evaluate.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
+        L.fo_circle_interpolate_block.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
+        L.fo_felts_to_bytes.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
         L.fo_merkle_commit_layer.argtypes = [C.c_uint32, C.c_void_p, C.POINTER(C.c_void_p), C.c_uint32, C.c_void_p]
         L.fo_merkle_commit.argtypes = [C.POINTER(C.c_void_p), C.c_uint32, C.c_uint32, C.c_void_p]
         L.fo_merkle_layer_offset.restype = C.c_size_t
@@ -181,6 +183,26 @@ def circle_evaluate(coef, n, tw=None):
     for c in range(k):
         lib().fo_circle_evaluate(coef[c].ctypes.data, L, n, tw.ctypes.data, out[c].ctypes.data)
     return out
+
+
+def circle_interpolate_block(block, n, k, itw=None):
+    """block [ncols, 2^L] = evaluations k*2^L .. (k+1)*2^L of the bit-reversed codeword -> coefficients [ncols, 2^L]."""
+    block = np.ascontiguousarray(block, dtype=np.uint32)
+    ncols, m = block.shape
+    L = m.bit_length() - 1
+    if itw is None:
+        _, itw = precompute_twiddles(n)
+    out = np.zeros_like(block)
+    for c in range(ncols):
+        lib().fo_circle_interpolate_block(block[c].ctypes.data, L, n, k, itw.ctypes.data, out[c].ctypes.data)
+    return out
+
+
+def felts_to_bytes(felts, length):
+    felts = np.ascontiguousarray(felts, dtype=np.uint32).ravel()
+    out = np.zeros(max(length, 1), dtype=np.uint8)
+    lib().fo_felts_to_bytes(felts.ctypes.data, felts.size, out.ctypes.data, length)
+    return out[:length].tobytes()
 
 
 # ---- Merkle --------------------------------------------------------------------------------------

@@ -431,3 +431,58 @@ def test_full_size_encode_linearity(gpu_ctx):
         _check(gpu_ctx, gpu_ctx._L.frieda_circle_evaluate(gpu_ctx._h, d_c.ptr, 4, L, n, d_o.ptr))
         outs.append(d_o.to_array(np.uint32, (4, 1 << n)).astype(np.uint64))
     assert np.array_equal((outs[0] + outs[1]) % P, outs[2])
+
+
+# ------------------------------------------------------------------------------------------------
+# reconstruction side
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("L,n", [(0, 1), (1, 1), (1, 2), (2, 2), (0, 3), (3, 3), (2, 6), (7, 11), (12, 16), (13, 17), (16, 20), (14, 14)])
+def test_circle_interpolate_blocks(gpu_ctx, oracle, L, n):
+    """Every aligned 1/2^B block of the codeword gives back the coefficients; bit-exact against the oracle's restatement of
+    stwo's interpolate (block 0 with L == n is CpuBackend::interpolate itself)."""
+    rng = np.random.default_rng(700 + 31 * n + L)
+    ncols = 4 if n < 20 else 2
+    coef = rand_m31(rng, (ncols, 1 << L))
+    ev = oracle.circle_evaluate(coef, n)
+    _, itw = oracle.precompute_twiddles(n)
+    blocks = sorted(set([0, (1 << (n - L)) - 1, (1 << (n - L)) // 2, 1 % (1 << (n - L))]))
+    for k in blocks:
+        blk = np.ascontiguousarray(ev[:, k << L : (k + 1) << L])
+        exp = oracle.circle_interpolate_block(blk, n, k, itw)
+        assert np.array_equal(exp, coef)
+        d_b, d_c = DevBuf.from_array(gpu_ctx, blk), DevBuf(gpu_ctx, 4 * ncols << L)
+        _check(gpu_ctx, gpu_ctx._L.frieda_circle_interpolate(gpu_ctx._h, d_b.ptr, ncols, L, n, k, d_c.ptr))
+        assert np.array_equal(d_c.to_array(np.uint32, (ncols, 1 << L)), coef), f"block {k}"
+
+
+@pytest.mark.parametrize("n_bytes", [1, 3, 4, 15, 16, 58, 119, 120, 1000, 4097, 65536])
+def test_pack30(gpu_ctx, oracle, n_bytes):
+    data = splitmix64_bytes(13, n_bytes)
+    felts = oracle.bytes_to_felt_le(data)
+    assert oracle.felts_to_bytes(felts, n_bytes) == data.tobytes()
+    d_f, d_o = DevBuf.from_array(gpu_ctx, felts), DevBuf(gpu_ctx, n_bytes + 8)
+    _check(gpu_ctx, gpu_ctx._L.frieda_pack30(gpu_ctx._h, d_f.ptr, felts.size, d_o.ptr, n_bytes))
+    assert d_o.to_array(np.uint8, (n_bytes,)).tobytes() == data.tobytes()
+
+
+@pytest.mark.parametrize("n_bytes,B", [(58, 4), (1024, 4), (70001, 2), (262146, 4), (3932160, 4)])
+def test_encode_erase_reconstruct_round_trip(gpu_ctx, n_bytes, B):
+    """encode -> keep one 1/2^B block (erase everything else) -> reconstruct the original bytes, for every block position
+    tried; at 2^22 this is the size-independent round-trip property."""
+    import ctypes as C
+
+    data = splitmix64_bytes(17, n_bytes)
+    L_ = gpu_ctx._L
+    nf, npad, lg = C.c_size_t(), C.c_size_t(), C.c_uint32()
+    L_.frieda_codec_shape(n_bytes, C.byref(nf), C.byref(npad), C.byref(lg))
+    L, n = lg.value, lg.value + B
+    d_in = DevBuf.from_array(gpu_ctx, data)
+    d_coef, d_ev = DevBuf(gpu_ctx, 4 * npad.value), DevBuf(gpu_ctx, 16 << n)
+    _check(gpu_ctx, L_.frieda_unpack30(gpu_ctx._h, d_in.ptr, n_bytes, d_coef.ptr, npad.value))
+    _check(gpu_ctx, L_.frieda_circle_evaluate(gpu_ctx._h, d_coef.ptr, 4, L, n, d_ev.ptr))
+    ev = d_ev.to_array(np.uint32, (4, 1 << n))
+    for k in sorted(set([0, 1, (1 << B) - 1, (1 << B) // 2])):
+        blk = np.ascontiguousarray(ev[:, k << L : (k + 1) << L])
+        d_b, d_o = DevBuf.from_array(gpu_ctx, blk), DevBuf(gpu_ctx, n_bytes + 8)
+        _check(gpu_ctx, L_.frieda_reconstruct_device(gpu_ctx._h, d_b.ptr, L, n, k, n_bytes, d_o.ptr))
+        assert d_o.to_array(np.uint8, (n_bytes,)).tobytes() == data.tobytes(), f"block {k}"
