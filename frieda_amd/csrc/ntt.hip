@@ -235,7 +235,13 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_tile12_kernel(NttArgs a) {
             } else {
                 const uint32_t* lvl = a.tw + tw_level_offset_dev(a.n, i - 1) + hbase;
 #pragma unroll
-                for (int u = 0; u < (1 << q); u++) twd[s][(1 << q) - 1 + u] = lvl[u];
+                for (int u = 0; u < (1 << q); u++) {
+                    uint32_t v = lvl[u];
+                    // stage 0 acts on tile bits 8..11: its twiddle index has no thread-dependent bits (base >> (b+1) == 0 for
+                    // g < 256), so the 15 values are workgroup-uniform and live in scalar registers
+                    if (s == 0) v = (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+                    twd[s][(1 << q) - 1 + u] = v;
+                }
             }
         }
     }

@@ -187,3 +187,25 @@ def test_product_and_oracle_verifiers_agree_on_random_tampering(oracle, proofs):
         for k, v in enumerate(ev.ravel()):
             o2.c.evaluations[k] = int(v)
         assert frieda_amd.verify(p2, 9) == oracle.verify(o2, 9)
+
+
+def test_rust_bindings_declare_every_symbol():
+    """bindings/rust/frieda-hip-sys cannot be compiled here (no cargo); keep it in lock-step with the header: same function
+    names, same number of parameters."""
+    import os
+    import re
+
+    from frieda_amd import _lib
+
+    hdr = re.sub(r"/\*.*?\*/", "", open(_lib.HEADER_PATH).read(), flags=re.S)
+    decl = {}
+    for m in re.finditer(r"\b(frieda_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", hdr):
+        args = m.group(2).strip()
+        decl[m.group(1)] = 0 if args in ("", "void") else args.count(",") + 1
+    rs = open(os.path.join(os.path.dirname(_lib.HEADER_PATH), "..", "bindings", "rust", "frieda-hip-sys", "src", "lib.rs")).read()
+    rdecl = {}
+    for m in re.finditer(r"pub fn (frieda_[a-z0-9_]+)\s*\(([^)]*)\)", rs):
+        args = m.group(2).strip()
+        rdecl[m.group(1)] = 0 if args == "" else args.count(":")
+    assert sorted(decl) == sorted(rdecl)
+    assert {k: v for k, v in decl.items() if rdecl[k] != v} == {}
