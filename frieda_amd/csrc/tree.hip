@@ -367,6 +367,51 @@ __device__ void channel_after_root_quad(DevTranscript* tr, const uint32_t* root_
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// tree7q: the narrow middle of a tree (<= 32768 level-A nodes) hashed by quads across many workgroups
+// ------------------------------------------------------------------------------------------------
+// One workgroup (64 quads) owns 64 consecutive level-A nodes and produces up to seven levels (64, 32, ..., 1 nodes), every
+// node by the 4-lane compression: ~1.5 us per level instead of ~2.9 us for one-hash-per-lane, and the wide levels spread
+// over many CUs instead of queueing in the single-workgroup top kernel.
+constexpr uint32_t T7Q_UNITS = 64;
+constexpr uint32_t T7Q_LEVELS = 7;
+
+__global__ __launch_bounds__(256) void tree7q_kernel(TreeArgs a) {
+    __shared__ __attribute__((aligned(16))) uint32_t QX[2 * T7Q_UNITS * QS];
+    __shared__ __attribute__((aligned(16))) uint32_t QY[T7Q_UNITS * QS];
+    const uint32_t t = threadIdx.x, q = t & 3;
+    QuadOffsets qo;
+    quad_offsets_init(qo, q);
+    const size_t total_a = (size_t)1 << a.level_a;
+    const size_t wg_base = (size_t)blockIdx.x * T7Q_UNITS;
+    const uint32_t cnt_a = (uint32_t)(total_a - wg_base < T7Q_UNITS ? total_a - wg_base : T7Q_UNITS);
+    uint32_t nl = 1;
+    while (nl < T7Q_LEVELS && (cnt_a >> nl) >= 1) nl++;
+    // the 2 * cnt_a children of this workgroup's level-A nodes: global (array of structs) -> quad layout
+    const uint32_t* inw = reinterpret_cast<const uint32_t*>(a.children) + 16 * wg_base;
+    for (uint32_t e = t; e < 16 * cnt_a; e += 256) QX[QS * (e >> 3) + (e & 7)] = inw[e];
+    __syncthreads();
+    uint32_t* cur = QX;
+    uint32_t* other = QY;
+    for (uint32_t l = 0; l < nl; l++) {
+        const uint32_t cnt = cnt_a >> l;
+        const bool last = l + 1 == nl;
+        uint8_t* gout = a.store_all ? a.layers + layer_off(a.tree_log, a.level_a - l) : (last ? a.last_out : nullptr);
+        for (uint32_t j = t >> 2; j < cnt; j += 64) {
+            Quad2 v = merkle_node_quad(cur + 2 * QS * j, qo, q);
+            if (gout) store_hash_quad(gout, (uint32_t)(wg_base >> l) + j, q, v);
+            if (!last) {
+                other[QS * j + q] = v.lo;
+                other[QS * j + 4 + q] = v.hi;
+            }
+        }
+        __syncthreads();
+        uint32_t* tmp = cur;
+        cur = other;
+        other = tmp;
+    }
+}
+
 struct TopArgs {
     const uint8_t* in;  // 2^l_in hashes (array of structs)
     uint32_t l_in;      // <= 11
@@ -644,7 +689,8 @@ uint32_t tree5_levels(uint32_t level_a) {
     return in_wg + 1 < T5_LEVELS ? in_wg + 1 : T5_LEVELS;
 }
 
-constexpr uint32_t TOP_MAX_LOG = 11;
+constexpr uint32_t TOP_MAX_LOG = 9;           // the top kernel starts from <= 512 hashes: quad levels only
+constexpr uint32_t T7Q_MAX_LEVEL_A = 15;  // level-A sizes up to 2^15 nodes go through tree7q
 
 // algorithmic bytes of `levels` consecutive node levels whose first (largest) has 2^la nodes: 64 B in + 32 B out each
 double node_levels_bytes(uint32_t la, uint32_t levels) {
@@ -680,8 +726,18 @@ void build_tree(const Launch& L, int mode, TreeArgs a, uint32_t m, uint8_t* laye
         b.level_a = cur - 1;
         b.children = cur_ptr;
         b.last_out = (cur_ptr == s0) ? s1 : s0;
-        uint32_t l2 = tree5_levels(cur - 1);
-        launch_tree5(L, T_NODE, b, "tree5_node", node_levels_bytes(cur - 1, l2));
+        uint32_t l2;
+        if (cur - 1 <= T7Q_MAX_LEVEL_A) {
+            // narrow: quads over many workgroups, up to seven levels
+            const uint32_t in_wg = b.level_a < 6 ? b.level_a : 6;
+            l2 = in_wg + 1 < T7Q_LEVELS ? in_wg + 1 : T7Q_LEVELS;
+            Scope scope(L, "tree7q_node", node_levels_bytes(cur - 1, l2));
+            const unsigned grid = (unsigned)((((size_t)1 << b.level_a) + T7Q_UNITS - 1) / T7Q_UNITS);
+            tree7q_kernel<<<grid, 256, 0, L.stream>>>(b);
+        } else {
+            l2 = tree5_levels(cur - 1);
+            launch_tree5(L, T_NODE, b, "tree5_node", node_levels_bytes(cur - 1, l2));
+        }
         cur = cur - l2;
         cur_ptr = layers ? layers + merkle_layer_offset(m, cur) : b.last_out;
     }
