@@ -22,6 +22,7 @@ FAMILY = [
     (r"tree5_kernel<1, ", "tree5_node"),
     (r"tree5_kernel<2, ", "tree5_fold_circle"),
     (r"tree5_kernel<3, ", "tree5_fold_line"),
+    (r"tree7q_kernel", "tree7q_node"),
     (r"top_kernel", "tree_top"),
     (r"tail_kernel", "fri_tail"),
     (r"ntt_tile12_kernel<2, 4>", "ntt_pass_mid"),
