@@ -173,6 +173,7 @@ void Ctx::drop_twiddles() {
     for (auto& kv : twiddles) {
         if (kv.second.d_tw) (void)hipFree(kv.second.d_tw);
         if (kv.second.d_itw) (void)hipFree(kv.second.d_itw);
+        if (kv.second.d_scratch) (void)hipFree(kv.second.d_scratch);
     }
     twiddles.clear();
 }
@@ -190,6 +191,7 @@ int Ctx::get_twiddles(uint32_t n, TwiddleSet& out) {
         size_t bytes = sizeof(uint32_t) << (n - 1);
         FR_HIP(this, hipMalloc((void**)&ts.d_tw, bytes));
         FR_HIP(this, hipMalloc((void**)&ts.d_itw, bytes));
+        FR_HIP(this, hipMalloc((void**)&ts.d_scratch, 8192));
     }
     // seeds: initial point of half_odds(n-1) and the step multiples the kernel combines
     Coset h = Coset::half_odds(n - 1);
@@ -207,7 +209,7 @@ int Ctx::get_twiddles(uint32_t n, TwiddleSet& out) {
     ts.ds.init_y = seeds.p0.y;
     ts.ds.inv_init_x = m31_inv(seeds.p0.x);
     ts.ds.inv_init_y = m31_inv(seeds.p0.y);
-    k::gen_twiddles(launch(), n, seeds, ts.d_tw, ts.d_itw);
+    k::gen_twiddles(launch(), n, seeds, ts.d_tw, ts.d_itw, ts.d_scratch);
     FR_HIP(this, hipGetLastError());
     twiddles[n] = ts;
     out = ts;

@@ -65,6 +65,7 @@ CodecShape codec_shape(size_t len);
 struct TwiddleSet {
     uint32_t* d_tw = nullptr;
     uint32_t* d_itw = nullptr;
+    void* d_scratch = nullptr;  // 8 KiB for the generator's point table
     k::DomainScalars ds{};
 };
 

@@ -52,7 +52,8 @@ struct TwiddleSeeds {
     CPoint step[32];  // point(step << k)
 };
 // fills d_tw / d_itw (2^(n-1) words each) for the circle domain of log size n >= 1
-void gen_twiddles(const Launch& L, uint32_t n, const TwiddleSeeds& seeds, uint32_t* d_tw, uint32_t* d_itw);
+// d_scratch8k: 8 KiB of device scratch for the fast path (n >= 12); may be null (slow path)
+void gen_twiddles(const Launch& L, uint32_t n, const TwiddleSeeds& seeds, uint32_t* d_tw, uint32_t* d_itw, void* d_scratch8k);
 
 // ---- ntt.hip ----
 // d_coef[ncols][coef_stride] (2^L live words per column) -> d_out[ncols][out_stride] (2^n per column)

@@ -19,7 +19,7 @@ def fuzz_binary(tmp_path_factory):
     # the slice of the C ABI the fuzzer needs, without the device-side entry points (which need hipcc)
     stub.write_text(
         '#include <string.h>\n#include <new>\n#include "host.h"\nusing namespace frieda;\n'
-        'namespace frieda { namespace k { void gen_twiddles(const Launch&, uint32_t, const TwiddleSeeds&, uint32_t*, uint32_t*) {} } '
+        'namespace frieda { namespace k { void gen_twiddles(const Launch&, uint32_t, const TwiddleSeeds&, uint32_t*, uint32_t*, void*) {} } '
         "void ProveJobDeleter::operator()(ProveJob*) const {} }\n"
         'extern "C" {\n'
         "int frieda_proof_deserialize(const uint8_t* buf, size_t len, frieda_proof** out) { if (!buf || !out) return 1; *out = nullptr; "
