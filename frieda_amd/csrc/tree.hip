@@ -13,8 +13,10 @@
 //                  FOLD_CIRCLE  / FOLD_LINE  the previous FRI layer: the fold of pair (2g, 2g+1) is computed in registers,
 //                               written to the new layer's columns and hashed at once — the folded layer is never re-read.
 //                Every level is stored (generate_proof needs the layers for decommitment) or only the last (commit).
-// top_kernel     one workgroup finishes a tree from <= 2048 hashes to the root and then, in lane 0, mixes the root into the
-//                device transcript and draws the next folding alpha.
+// tree7q_kernel  the narrow middle of a tree (level-A sizes <= 2^15): 64 nodes per workgroup, up to seven levels, every node
+//                hashed by a quad of lanes (4-lane cooperative Blake2s) — ~1.5 us per level, wide levels spread over many CUs.
+// top_kernel     one workgroup finishes a tree from <= 512 hashes to the root with quad hashing and then, in quad 0, mixes
+//                the root into the device transcript and draws the next folding alpha.
 // tail_kernel    one workgroup runs every remaining FRI layer of <= 2048 points: fold, tree, channel, ... then interpolates
 //                the last layer (line iFFT in LDS), enforces stwo's degree assertion and mixes the polynomial.
 // grind_dev      proof-of-work scan keyed by the digest in the device transcript.
@@ -414,7 +416,7 @@ __global__ __launch_bounds__(256) void tree7q_kernel(TreeArgs a) {
 
 struct TopArgs {
     const uint8_t* in;  // 2^l_in hashes (array of structs)
-    uint32_t l_in;      // <= 11
+    uint32_t l_in;      // <= 11 supported; build_tree hands over at <= 9 (quad levels only)
     uint8_t* layers;    // non-null: store every produced level at its leaves-first offset
     uint32_t tree_log;
     uint8_t* root_out;  // non-null: also store the root here

@@ -230,6 +230,9 @@ PROVE_CASES = [
     ("pattern:9000", None, (9, 6, 3, 10)),
     ("pattern:120", 1, (4, 1, 0, 5)),  # tiny: L = 3, n = 4
     ("pattern:20", None, (4, 2, 0, 3)),  # L = 1, n = 3: no inner layer at all
+    ("pattern:3000", 42, (24, 4, 0, 20)),  # 24-bit proof of work: the grind needs several scan chunks
+    ("pattern:5000", 8, (10, 4, 1, 300)),  # many queries: dense decommitment with shared paths
+    ("pattern:777", None, (6, 5, 2, 64)),
 ]
 
 
