@@ -42,6 +42,7 @@ extern "C" {
     pub fn frieda_ctx_synchronize(ctx: *mut frieda_ctx) -> c_int;
     pub fn frieda_ctx_set_twiddle_cache(ctx: *mut frieda_ctx, enabled: c_int) -> c_int;
     pub fn frieda_ctx_set_host_channel(ctx: *mut frieda_ctx, enabled: c_int) -> c_int;
+    pub fn frieda_ctx_test_set_draw_bound(ctx: *mut frieda_ctx, bound: u32) -> c_int;
     pub fn frieda_ctx_set_kernel_timing(ctx: *mut frieda_ctx, enabled: c_int) -> c_int;
     pub fn frieda_ctx_last_prove_phases(ctx: *const frieda_ctx, out_ms: *mut f64) -> c_int;
     pub fn frieda_ctx_kernel_timing_report(ctx: *mut frieda_ctx, buf: *mut c_char, cap: usize, reset: c_int) -> usize;

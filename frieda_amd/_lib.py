@@ -64,6 +64,7 @@ def lib():
         "frieda_ctx_synchronize": (C.c_int, [vp]),
         "frieda_ctx_set_twiddle_cache": (C.c_int, [vp, C.c_int]),
         "frieda_ctx_set_host_channel": (C.c_int, [vp, C.c_int]),
+        "frieda_ctx_test_set_draw_bound": (C.c_int, [vp, u32]),
         "frieda_ctx_set_kernel_timing": (C.c_int, [vp, C.c_int]),
         "frieda_ctx_last_prove_phases": (C.c_int, [vp, C.POINTER(C.c_double)]),
         "frieda_ctx_kernel_timing_report": (sz, [vp, vp, sz, C.c_int]),

@@ -99,6 +99,12 @@ int frieda_ctx_last_prove_phases(const frieda_ctx* ctx, double out_ms[8]) {
     return FRIEDA_OK;
 }
 
+int frieda_ctx_test_set_draw_bound(frieda_ctx* ctx, uint32_t bound) {
+    if (!ctx || bound > 2u * P31) return FRIEDA_ERR_ARG;
+    ctx->c.test_draw_bound = bound ? bound : 2u * P31;
+    return FRIEDA_OK;
+}
+
 int frieda_ctx_set_kernel_timing(frieda_ctx* ctx, int enabled) {
     if (!ctx) return FRIEDA_ERR_ARG;
     FR_GUARD_BEGIN

@@ -61,12 +61,13 @@ struct Channel {
         b2s256_words(w, 64, out);
     }
     // draw_base_felts retry rule: all eight words < 2P, then reduce; first four form the QM31
-    FR_HD QM31 draw_felt() {
+    // `bound`: acceptance bound, 2P in stwo; only the retry-branch test passes anything else (<= 2P)
+    FR_HD QM31 draw_felt(uint32_t bound = 2u * P31) {
         for (;;) {
             uint32_t w[8];
             draw_random_words(w);
             bool ok = true;
-            for (int i = 0; i < 8; i++) ok = ok && (w[i] < 2u * P31);
+            for (int i = 0; i < 8; i++) ok = ok && (w[i] < bound);
             if (!ok) continue;
             return {m31_reduce_2p(w[0]), m31_reduce_2p(w[1]), m31_reduce_2p(w[2]), m31_reduce_2p(w[3])};
         }

@@ -24,7 +24,8 @@ struct DevTranscript {
     uint32_t roots[DT_MAX_LAYERS][8];
     uint32_t alphas[DT_MAX_LAYERS][4];
     uint32_t n_last_poly;   // QM31 count of last_poly
-    uint32_t pad_[3];
+    uint32_t draw_bound;    // acceptance bound of draw_felt (2P; a test hook may lower it)
+    uint32_t pad_[2];
     uint32_t last_poly[4 * DT_MAX_LAST_POLY];  // LinePoly coefficients, stwo internal order
 };
 

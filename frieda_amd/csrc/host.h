@@ -83,6 +83,7 @@ struct Ctx {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     bool cache_twiddles = true;
+    uint32_t test_draw_bound = 2u * P31;  // test hook: acceptance bound of draw_felt (see frieda_ctx_test_set_draw_bound)
     bool host_channel = false;  // evaluate the Fiat-Shamir channel on the host between layers (diagnostic / fallback path)
     std::map<uint32_t, TwiddleSet> twiddles;
     uint8_t* arena = nullptr;

@@ -350,6 +350,7 @@ int prove_begin(Ctx* ctx, const uint8_t* data, size_t len, bool data_on_device, 
             memset(ht, 0, hdr);
             ht->ch = ch;
             ht->nonce = ~0ull;
+            ht->draw_bound = ctx->test_draw_bound;
             FR_HIP(ctx, hipMemcpyAsync(d_tr, ht, hdr, hipMemcpyHostToDevice, s));
         }
         // FriProver::commit_first_layer
@@ -402,7 +403,7 @@ int prove_begin(Ctx* ctx, const uint8_t* data, size_t len, bool data_on_device, 
         ch.mix_root(rw);
 
         // ---- FriProver::commit_inner_layers ----
-        QM31 alpha = ch.draw_felt();
+        QM31 alpha = ch.draw_felt(ctx->test_draw_bound);
         {
             // LineEvaluation::new_zero then fold_circle_into_line
             uint32_t* dst = (n_inner > 0) ? cols(inner[0], 0) : reinterpret_cast<uint32_t*>(A + o_lastv);
@@ -416,7 +417,7 @@ int prove_begin(Ctx* ctx, const uint8_t* data, size_t len, bool data_on_device, 
             if (rc) return rc;
             hash_to_words(roots[kx + 1].data(), rw);
             ch.mix_root(rw);
-            alpha = ch.draw_felt();
+            alpha = ch.draw_felt(ctx->test_draw_bound);
             uint32_t* dst = (kx + 1 < n_inner) ? cols(inner[kx + 1], 0) : reinterpret_cast<uint32_t*>(A + o_lastv);
             k::fold_line(LN, cols(lay, 0), (size_t)1 << lay.log, lay.log, n, tw.d_itw, tw.ds, k::Alpha{{alpha.a, alpha.b, alpha.c, alpha.d}}, dst,
                          (size_t)1 << (lay.log - 1));

@@ -338,6 +338,7 @@ __device__ void channel_after_root_quad(DevTranscript* tr, const uint32_t* root_
     const uint32_t dflag = (q == 0) ? 64u : (q == 2 ? 0xFFFFFFFFu : 0u);
     Quad2 dg = b2_compress_quad(mb, qo, hq, h4q, iv_sel(q), iv_sel(4 + q) ^ dflag);
     // draw_felt on the new digest
+    const uint32_t bound = tr->draw_bound;
     uint32_t n_sent = 0;
     Quad2 rnd;
     for (;;) {
@@ -347,7 +348,7 @@ __device__ void channel_after_root_quad(DevTranscript* tr, const uint32_t* root_
         mb[QS + 4 + q] = 0u;
         n_sent++;
         rnd = b2_compress_quad(mb, qo, hq, h4q, iv_sel(q), iv_sel(4 + q) ^ dflag);
-        uint32_t ok = (rnd.lo < 2u * P31 && rnd.hi < 2u * P31) ? 1u : 0u;
+        uint32_t ok = (rnd.lo < bound && rnd.hi < bound) ? 1u : 0u;
         ok &= quad_perm<QROT1>(ok);
         ok &= quad_perm<QROT2>(ok);
         if (ok) break;

@@ -70,6 +70,11 @@ int frieda_ctx_set_twiddle_cache(frieda_ctx* ctx, int enabled);
  * configurations whose last FRI layer exceeds 2^11 points always use the host policy. */
 int frieda_ctx_set_host_channel(frieda_ctx* ctx, int enabled);
 
+/* TEST HOOK, not part of the protocol: the acceptance bound of Channel::draw_felt (stwo: every drawn word must be < 2P, else
+ * redraw — a ~4e-9 event).  A lower bound makes the redraw branch fire on most draws so that it can be compared against the
+ * oracle; proofs made with a non-default bound do not verify.  0 restores 2P. */
+int frieda_ctx_test_set_draw_bound(frieda_ctx* ctx, uint32_t bound);
+
 /* measurement aid: when enabled, HIP events are recorded on the ctx stream around every kernel launch.
  * frieda_ctx_kernel_timing_report synchronises the stream and writes a JSON object
  * {"kernels": [{"name", "launches", "total_ms", "alg_bytes"}]} (alg_bytes = algorithmic HBM bytes by the byte model

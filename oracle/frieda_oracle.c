@@ -557,6 +557,11 @@ void fo_channel_draw_random_bytes(fo_channel* c, uint8_t out[32]) {
     c->n_sent += 1;
     fo_blake2s256(buf, 64, out);
 }
+/* TEST HOOK: the acceptance bound of draw_base_felts (2P in stwo).  Lowering it makes the otherwise ~4e-9-rare retry branch
+ * fire on most draws so that the oracle and the product can be compared on it; never changed outside that test. */
+static uint32_t g_draw_bound = 2u * P;
+void fo_test_set_draw_bound(uint32_t bound) { g_draw_bound = bound ? bound : 2u * P; }
+
 void fo_channel_draw_felt(fo_channel* c, uint32_t out[4]) {
     /* draw_base_felts: retry until all eight u32 < 2P, then reduce; the first four form the QM31 */
     for (;;) {
@@ -566,7 +571,7 @@ void fo_channel_draw_felt(fo_channel* c, uint32_t out[4]) {
         fo_channel_draw_random_bytes(c, b);
         for (int i = 0; i < 8; i++) {
             w[i] = ld32(b + 4 * i);
-            if (w[i] >= 2u * P) ok = 0;
+            if (w[i] >= g_draw_bound) ok = 0;
         }
         if (!ok) continue;
         for (int i = 0; i < 4; i++) out[i] = m31_reduce(w[i]);

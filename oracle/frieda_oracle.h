@@ -101,6 +101,8 @@ void fo_channel_mix_root(fo_channel* c, const uint8_t root[32]);
 void fo_channel_mix_felts(fo_channel* c, const uint32_t* qm31s, size_t n_qm31);
 void fo_channel_draw_random_bytes(fo_channel* c, uint8_t out[32]);
 void fo_channel_draw_felt(fo_channel* c, uint32_t out[4]);
+/* test hook: acceptance bound of draw_base_felts (0 restores 2P); must stay <= 2P */
+void fo_test_set_draw_bound(uint32_t bound);
 uint32_t fo_channel_trailing_zeros(const fo_channel* c);
 uint64_t fo_grind(const fo_channel* c, uint32_t pow_bits);
 /* Queries::generate; out must hold n_queries entries; returns the deduplicated count */

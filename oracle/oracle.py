@@ -106,6 +106,7 @@ def lib():
         L.fo_channel_mix_felts.argtypes = [C.POINTER(Channel), C.c_void_p, C.c_size_t]
         L.fo_channel_draw_random_bytes.argtypes = [C.POINTER(Channel), C.c_void_p]
         L.fo_channel_draw_felt.argtypes = [C.POINTER(Channel), C.c_void_p]
+        L.fo_test_set_draw_bound.argtypes = [C.c_uint32]
         L.fo_channel_trailing_zeros.restype = C.c_uint32
         L.fo_channel_trailing_zeros.argtypes = [C.POINTER(Channel)]
         L.fo_grind.restype = C.c_uint64

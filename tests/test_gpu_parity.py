@@ -264,6 +264,31 @@ def test_prove_bit_exact_vs_oracle(gpu_ctx, oracle, blob, spec, seed, cfg, host_
             frieda_amd.verify(g_proof, seed)
 
 
+@pytest.mark.parametrize("host_channel", [False, True], ids=["devchannel", "hostchannel"])
+def test_draw_felt_retry_branch(gpu_ctx, oracle, host_channel):
+    """Channel::draw_felt redraws when a word is >= 2P — once in ~3e8 draws.  With the acceptance bound lowered through the
+    test hooks (same value on both sides) most draws are redrawn several times; the transcripts must still agree."""
+    import frieda_amd
+
+    data = pattern_bytes(6000).tobytes()
+    cfg = (8, 4, 0, 16)
+    bound = 0xE0000000  # each word passes with p = 7/8, all eight with p = 0.34
+    oracle.lib().fo_test_set_draw_bound(bound)
+    _check(gpu_ctx, gpu_ctx._L.frieda_ctx_test_set_draw_bound(gpu_ctx._h, bound))
+    gpu_ctx.set_host_channel(host_channel)
+    try:
+        o_root, o_proof = oracle.commit_and_generate_proof(data, 3, oracle.make_config(*cfg))
+        g_root, g_proof = gpu_ctx.commit_and_generate_proof(data, 3, _cfg(frieda_amd, *cfg))
+    finally:
+        oracle.lib().fo_test_set_draw_bound(0)
+        gpu_ctx._L.frieda_ctx_test_set_draw_bound(gpu_ctx._h, 0)
+        gpu_ctx.set_host_channel(False)
+    assert g_proof.serialize() == o_proof.serialize()
+    # and the branch really fired: the default-bound transcript differs
+    d_root, d_proof = gpu_ctx.commit_and_generate_proof(data, 3, _cfg(frieda_amd, *cfg))
+    assert d_root == g_root and d_proof.serialize() != g_proof.serialize()
+
+
 def test_reference_proof_tests_on_gpu(gpu_ctx, blob):
     """src/proof.rs:119-193 through the GPU prover and the C-ABI verifier."""
     import frieda_amd
