@@ -100,7 +100,7 @@ def cpu_baseline(sample_log, workload, calls):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--steps", type=int, default=60)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--log-domain", type=int, default=24)
     ap.add_argument("--workload", choices=["prove", "commit"], default="prove")

@@ -308,7 +308,7 @@ int prove_begin(Ctx* ctx, const uint8_t* data, size_t len, bool data_on_device, 
     rc = ctx->ensure_arena(plan.off);
     if (rc) return rc;
     const size_t pinned_need = std::max<size_t>(std::max<size_t>(sizeof(DevTranscript), (sizeof(uint32_t) * 4) << last_log),
-                                                4 * J.max_words + 32 * J.max_hashes);
+                                                (4 + 8) * J.max_words + (32 + 8) * J.max_hashes + 512);
     rc = ensure_pinned(ctx, pinned_need);
     if (rc) return rc;
     TwiddleSet tw;
@@ -530,14 +530,19 @@ int prove_finish(Ctx* ctx, uint8_t out_commitment[32], ProofData& out) {
         lq = fold_queries(lq, 1);
     }
     if (g.word_idx.size() > J.max_words || g.hash_idx.size() > J.max_hashes) return ctx->fail(FRIEDA_ERR_INVARIANT, "internal: gather plan overflow");
-    FR_HIP(ctx, hipMemcpyAsync(A + J.o_widx, g.word_idx.data(), 8 * g.word_idx.size(), hipMemcpyHostToDevice, s));
-    if (!g.hash_idx.empty()) FR_HIP(ctx, hipMemcpyAsync(A + J.o_hidx, g.hash_idx.data(), 8 * g.hash_idx.size(), hipMemcpyHostToDevice, s));
-    k::gather(LN, reinterpret_cast<const uint32_t*>(A), reinterpret_cast<const uint64_t*>(A + J.o_widx), g.word_idx.size(),
-              reinterpret_cast<uint32_t*>(A + J.o_wout), reinterpret_cast<const uint64_t*>(A + J.o_hidx), g.hash_idx.size(), A + J.o_hout);
+    // one upload (word indices then hash indices, staged in pinned memory), one launch, one download
+    const size_t nw = g.word_idx.size(), nh = g.hash_idx.size();
+    const size_t wbytes = 4 * nw, out_bytes = wbytes + 32 * nh;
     uint8_t* hp = reinterpret_cast<uint8_t*>(ctx->pinned);
-    const size_t wbytes = 4 * g.word_idx.size();
-    FR_HIP(ctx, hipMemcpyAsync(hp, A + J.o_wout, wbytes, hipMemcpyDeviceToHost, s));
-    if (!g.hash_idx.empty()) FR_HIP(ctx, hipMemcpyAsync(hp + wbytes, A + J.o_hout, 32 * g.hash_idx.size(), hipMemcpyDeviceToHost, s));
+    uint64_t* hidx = reinterpret_cast<uint64_t*>(hp + ((4 * J.max_words + 32 * J.max_hashes + 255) & ~(size_t)255));
+    memcpy(hidx, g.word_idx.data(), 8 * nw);
+    memcpy(hidx + nw, g.hash_idx.data(), 8 * nh);
+    // the index and output regions of the arena are laid out back to back (words region, then hashes region), so the
+    // hash part may start right behind the words actually used
+    FR_HIP(ctx, hipMemcpyAsync(A + J.o_widx, hidx, 8 * (nw + nh), hipMemcpyHostToDevice, s));
+    k::gather(LN, reinterpret_cast<const uint32_t*>(A), reinterpret_cast<const uint64_t*>(A + J.o_widx), nw,
+              reinterpret_cast<uint32_t*>(A + J.o_wout), reinterpret_cast<const uint64_t*>(A + J.o_widx) + nw, nh, A + J.o_wout + wbytes);
+    FR_HIP(ctx, hipMemcpyAsync(hp, A + J.o_wout, out_bytes, hipMemcpyDeviceToHost, s));
     FR_HIP(ctx, hipStreamSynchronize(s));
     FR_HIP(ctx, hipGetLastError());
     ctx->phase_ms[3] = ms_since(J.t_start);  // gather done (second and last synchronise)
