@@ -98,6 +98,11 @@ def cpu_baseline(sample_log, workload, calls):
 
 
 def main():
+    # The contract is ONE JSON line on stdout.  RCCL (and anything else linked in) may write banners to the C stdout, which is
+    # flushed at exit — after our line.  Keep the real stdout for the JSON alone and send every other fd-1 writer to stderr.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=60)
@@ -305,7 +310,7 @@ def main():
     elif rank == 0:
         out["cpu_baseline"] = None
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
     ctx.close()
     if use_dist:
         dist.destroy_process_group()
