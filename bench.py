@@ -123,6 +123,8 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    # one rank per GPU; if the launcher narrowed the visible devices per rank, index what is visible
+    local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     dist = None
     # FRIEDA_BENCH_FORCE_DIST=1 exercises the collective path (RCCL init, all_gather of roots, barrier, max-reduce) with a
