@@ -4,10 +4,10 @@
 // (/root/reference/src/utils.rs:10-24): the input is an LSB-first bit stream cut into 30-bit chunks,
 // the last chunk zero-extended, then zeros up to the padded power-of-two length.
 //
-// Layout: four felts are exactly 120 bits = 15 bytes, so thread t owns bytes [15t, 15t+15) and writes
-// felts 4t..4t+3 as one 16-byte store.  It reads the five aligned dwords that cover its 15 bytes (the
-// neighbouring threads' dwords overlap by one, served from L1) and funnel-shifts.  HBM-bound:
-// 3.75 B read + 4 B written per felt.
+// Layout: four felts are exactly 120 bits = 15 bytes, so thread t owns bytes [15t, 15t+15) and writes felts 4t..4t+3 as one
+// 16-byte store.  A workgroup's 256 windows cover 3840 contiguous bytes = 960 aligned dwords: they are staged through LDS
+// with coalesced dword loads, then every thread funnel-shifts its own 15-byte window out of five consecutive LDS words.
+// HBM-bound: 3.75 B read + 4 B written per felt.
 #include <hip/hip_runtime.h>
 
 #include "kernels.h"

@@ -5,9 +5,11 @@
 //   prove    (/root/reference/src/proof.rs:32-77; stwo core/fri.rs FriProver::{commit, decommit}):
 //            codec -> FFT -> first tree -> [mix root, draw alpha, fold, tree]* -> last layer interpolate ->
 //            grind -> queries -> decommit (one gather launch) -> Proof
-// The blob enters as raw bytes (3.75 B per felt over PCIe) and is unpacked on the device; after that nothing but
-// 32-byte roots, the final 16/32-point layer, the nonce and the gathered openings ever cross PCIe.
-// The Fiat–Shamir channel is evaluated on the host between layers (one 32-byte D2H per layer).
+// The blob enters as raw bytes (3.75 B per felt over PCIe) and is unpacked on the device; after that nothing but the
+// 2 KB transcript summary (roots, last-layer polynomial, nonce, channel state) and the gathered openings ever cross PCIe.
+// The Fiat–Shamir channel runs inside the commit-phase kernels (dev_transcript.h); the host synchronises twice per proof:
+// after the grind and after the gather.  prove_begin / prove_finish expose that split so several proofs can overlap.
+// (Host-side channel between layers is kept as a policy: frieda_ctx_set_host_channel, and for last layers above 2^11 points.)
 #include <string.h>
 
 #include <algorithm>
