@@ -46,3 +46,26 @@ def commit_batch(blobs, log_blowup_factor, commit_fn=None, device=None):
             off = (r * per_rank + slot) * 32
             roots[i] = flat[off : off + 32]
     return roots
+
+
+def prove_batch(blobs, seeds, pcs_config, prove_fn=None, device=None):
+    """Sharded `commit_and_generate_proof`: rank r proves blobs r, r + world, ...; every rank gets all commitment roots (one
+    all_gather of 32 bytes per blob slot) and the proofs of its own shard as {blob index: proof}.
+
+    `prove_fn(blob, seed) -> (bytes[32], proof)` is injectable for the CPU test; the default is the HIP path with two proofs in
+    flight per GPU (ProofPipeline)."""
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    n = len(blobs)
+    mine = shard_indices(n, rank, world)
+    results = {}
+    if prove_fn is None:
+        from . import api
+
+        ctx = api.default_context()
+        prove_fn = lambda b, s: ctx.commit_and_generate_proof(b, s, pcs_config)  # noqa: E731
+    for i in mine:
+        results[i] = prove_fn(blobs[i], seeds[i] if seeds is not None else None)
+    roots = commit_batch(blobs, pcs_config.fri_config.log_blowup_factor if hasattr(pcs_config, "fri_config") else 4,
+                         commit_fn=lambda b, _it=iter([results[i][0] for i in mine]): next(_it), device=device)
+    return roots, {i: results[i][1] for i in mine}

@@ -62,6 +62,51 @@ def test_commit_batch_world2_gloo(oracle, n_blobs):
         assert len(calls) == len(range(rank, n_blobs, world))  # and hashed only its own shard
 
 
+def _prove_worker(rank, world, port, n_blobs, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+
+    from conftest import splitmix64_bytes
+    from frieda_amd import batch
+    from oracle import oracle as O
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    blobs = [splitmix64_bytes(200 + i, 700 + 11 * i).tobytes() for i in range(n_blobs)]
+    seeds = [None if i % 2 else 50 + i for i in range(n_blobs)]
+    cfg = O.make_config(6, 4, 0, 8)
+
+    class Cfg:  # the shape batch.prove_batch reads the blow-up factor from
+        class fri_config:
+            log_blowup_factor = 4
+
+    roots, proofs = batch.prove_batch(blobs, seeds, Cfg, prove_fn=lambda b, s: O.commit_and_generate_proof(b, s, cfg))
+    ok = all(O.verify(p, seeds[i]) and bytes(p.c.first_layer.commitment) == roots[i] for i, p in proofs.items())
+    q.put((rank, [r.hex() for r in roots], sorted(proofs), ok))
+    dist.destroy_process_group()
+
+
+def test_prove_batch_world2_gloo(oracle):
+    from conftest import splitmix64_bytes
+
+    world, port, n_blobs = 2, _free_port(), 5
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_prove_worker, args=(r, world, port, n_blobs, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    expected = [oracle.commit(splitmix64_bytes(200 + i, 700 + 11 * i).tobytes(), 4).hex() for i in range(n_blobs)]
+    for rank, roots, mine, ok in results:
+        assert roots == expected and ok
+        assert mine == list(range(rank, n_blobs, world))
+
+
 def test_shard_indices():
     from frieda_amd.batch import shard_indices
 
