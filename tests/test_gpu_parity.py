@@ -387,6 +387,18 @@ def test_config3_commit_2p22_matches_oracle(gpu_ctx, oracle):
     assert gpu_ctx.commit(data, 4) == oracle.commit(data, 4)
 
 
+def test_config3_prove_2p22_matches_oracle(gpu_ctx, oracle):
+    """BASELINE.json configs[2]/[3]: the whole 2^22-domain proof (17 inner layers, every root, nonce, openings) byte-identical to
+    the oracle's, on the blob bench.py gives rank 0 (generator seed 100, seed = Some(len), benches/proof.rs:5-23 config)."""
+    import frieda_amd
+
+    data = splitmix64_bytes(100, blob_len_for(22))
+    o_root, o_proof = oracle.commit_and_generate_proof(data, data.size, oracle.make_config(20, 4, 0, 20))
+    g_root, g_proof = gpu_ctx.commit_and_generate_proof(data, data.size, _cfg(frieda_amd, 20, 4, 0, 20))
+    assert g_root == o_root and g_proof.n_inner_layers == 17
+    assert g_proof.serialize() == o_proof.serialize()
+
+
 @pytest.mark.parametrize("n", [22, 24])
 def test_full_size_prove_verify_and_tie(gpu_ctx, n):
     """configs[2]/[4]: prove -> verify round trip, first FRI root == commit() root (src/proof.rs:126-135), the last
