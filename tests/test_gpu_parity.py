@@ -399,6 +399,19 @@ def test_config3_prove_2p22_matches_oracle(gpu_ctx, oracle):
     assert g_proof.serialize() == o_proof.serialize()
 
 
+def test_config5_prove_2p24_matches_oracle(gpu_ctx, oracle):
+    """BASELINE.json configs[4], the bench workload itself: the 2^24-domain proof of bench.py's rank-0 blob is byte-identical
+    to the oracle's (about half a minute of single-thread CPU for the oracle)."""
+    import frieda_amd
+
+    data = splitmix64_bytes(100, blob_len_for(24))
+    g_root, g_proof = gpu_ctx.commit_and_generate_proof(data, data.size, _cfg(frieda_amd, 20, 4, 0, 20))
+    o_root, o_proof = oracle.commit_and_generate_proof(data, data.size, oracle.make_config(20, 4, 0, 20))
+    assert g_root == o_root and g_proof.n_inner_layers == 19
+    assert g_proof.serialize() == o_proof.serialize()
+    assert frieda_amd.verify(g_proof, data.size)
+
+
 @pytest.mark.parametrize("n", [22, 24])
 def test_full_size_prove_verify_and_tie(gpu_ctx, n):
     """configs[2]/[4]: prove -> verify round trip, first FRI root == commit() root (src/proof.rs:126-135), the last
