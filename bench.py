@@ -267,6 +267,25 @@ def main():
         }
         pipe.close()
 
+    # secondary ceiling: the path is bound by the integer VALU rate of Blake2s, not by HBM.  For the first-tree
+    # kernel (16.8 M leaf + 15.7 M node compressions at n = 24) compare with the chip's measured pure-compute rate
+    # (profiles/r01_blake2s_rate_mi355x.txt: 40.9 G leaf / 39.8 G node compressions per second).
+    valu = None
+    leaf = next((k for k in kern if k["name"] == "tree5_leaf"), None)
+    if leaf and leaf["total_ms"] > 0:
+        n_leaf = float(1 << n)
+        n_node = n_leaf * (1 / 2 + 1 / 4 + 1 / 8 + 1 / 16) if n >= 10 else 0.0
+        t_launch = leaf["total_ms"] * 1e-3 / leaf["launches"]
+        ideal = n_leaf / 40.9e9 + n_node / 39.8e9
+        valu = {
+            "kernel": "tree5_leaf",
+            "bound": "int32 VALU (Blake2s compression)",
+            "achieved": (n_leaf + n_node) / t_launch / 1e9,
+            "peak": (n_leaf + n_node) / ideal / 1e9,
+            "unit": "G compressions/s",
+            "frac": ideal / t_launch,
+        }
+
     path_bytes = algorithmic_bytes(n, args.workload)
     gpu_ms = sum(k["total_ms"] for k in kern) / args.steps
 
@@ -293,6 +312,9 @@ def main():
             "twiddles": "regenerated per call" if args.no_twiddle_cache else "cached per context",
         },
         "roofline": roofline,
+        "roofline_valu": valu,
+        "seconds_per_blob": dt / args.steps,
+        "input_felts_per_s": world * float(4 << (n - 4)) * args.steps / dt,
         "path": {
             "algorithmic_bytes_per_step": path_bytes,
             "achieved_GBps_wall": path_bytes / (dt / args.steps) / 1e9,

@@ -14,6 +14,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <cstdlib>
 
 #include <stddef.h>
 
@@ -361,7 +362,14 @@ int prove_begin(Ctx* ctx, const uint8_t* data, size_t len, bool data_on_device, 
         const FriLayerDev* cur = &first;
         bool circle = true;
         uint32_t kx = 0;
-        while (kx < n_inner && inner[kx].log > k::TAIL_LOG) {
+        // layers of more than 2^TAIL_RUN_LOG points go through the multi-workgroup kernels (a 2^11 layer is faster there than in
+        // the one-workgroup tail); FRIEDA_TAIL_RUN_LOG is a tuning knob
+        static const uint32_t tail_run_log = [] {
+            const char* e = getenv("FRIEDA_TAIL_RUN_LOG");
+            uint32_t v = e ? (uint32_t)atoi(e) : 9u;
+            return v >= 4 && v <= k::TAIL_LOG ? v : 9u;
+        }();
+        while (kx < n_inner && inner[kx].log > tail_run_log) {
             k::fold_and_tree(LN, circle, cols(*cur, 0), (size_t)1 << cur->log, cur->log, n, tw.d_itw, tw.ds, cols(inner[kx], 0),
                              A + inner[kx].o_tree, d_tr);
             cur = &inner[kx];
