@@ -91,6 +91,39 @@ FR_HD QM31 qm_mul(QM31 x, QM31 y) {
     CM31 hi = cm_add(cm_mul(x0, y1), cm_mul(x1, y0));
     return {lo.a, lo.b, hi.a, hi.b};
 }
+// Multiplication by a fixed s in QM31 is M31-linear: a 4x4 matrix on the coordinates (row = output coordinate).  With
+// R = u^2 = 2 + i:  (A + B u)(C + D u) = AC + R BD + (AD + BC) u.
+struct QM31Mat {
+    uint32_t m[4][4];
+};
+FR_HD QM31Mat qm_matrix(QM31 s) {
+    const uint32_t nb = m31_neg(s.b), nd = m31_neg(s.d);
+    const uint32_t t = m31_sub(m31_add(s.c, s.c), s.d);  // Re(R B) = 2c - d
+    const uint32_t u = m31_add(m31_add(s.d, s.d), s.c);  // Im(R B) = c + 2d
+    return {{{s.a, nb, t, m31_neg(u)}, {s.b, s.a, u, t}, {s.c, nd, s.a, nb}, {s.d, s.c, s.b, s.a}}};
+}
+// any 64-bit value mod P, canonical: v = hi 2^32 + lo == 2 hi + lo (2^31 == 1), a 34-bit number, folded once more
+FR_HD uint32_t m31_reduce64(uint64_t v) {
+    const uint64_t w = (uint64_t)(uint32_t)(v >> 32) * 2u + (uint32_t)v;
+    const uint32_t s = ((uint32_t)w & P31) + (uint32_t)(w >> 31);  // <= P + 7
+    return umin32(s, s - P31);
+}
+// FRI fold of one pair of QM31 values: (x + y) + s * ((x - y) * it), `sm` = qm_matrix(s).  Each output coordinate is a sum of
+// four 62-bit products plus a 32-bit term — it fits 64 bits exactly (4 (P-1)^2 + 2P < 2^64) — reduced once: 20 multiply-adds
+// and 8 reductions instead of the 20 multiplications, 20 reductions and ~30 modular add/subs of the textbook sequence.
+FR_HD QM31 qm_fold_pair(QM31 x, QM31 y, uint32_t it, const QM31Mat& sm) {
+    const uint32_t e[4] = {m31_reduce64((uint64_t)(x.a + (P31 - y.a)) * it), m31_reduce64((uint64_t)(x.b + (P31 - y.b)) * it),
+                           m31_reduce64((uint64_t)(x.c + (P31 - y.c)) * it), m31_reduce64((uint64_t)(x.d + (P31 - y.d)) * it)};
+    const uint32_t f0[4] = {x.a + y.a, x.b + y.b, x.c + y.c, x.d + y.d};  // < 2P, unreduced
+    uint32_t r[4];
+    for (int k = 0; k < 4; k++) {
+        uint64_t acc = f0[k];
+        for (int j = 0; j < 4; j++) acc += (uint64_t)sm.m[k][j] * e[j];
+        r[k] = m31_reduce64(acc);
+    }
+    return {r[0], r[1], r[2], r[3]};
+}
+
 FR_HD bool qm_eq(QM31 x, QM31 y) { return x.a == y.a && x.b == y.b && x.c == y.c && x.d == y.d; }
 FR_HD bool qm_is_zero(QM31 x) { return (x.a | x.b | x.c | x.d) == 0; }
 

@@ -84,14 +84,13 @@ __device__ __forceinline__ uint32_t inv_circle_twiddle(const uint32_t* __restric
 }
 
 // fold of the adjacent pair (2g, 2g+1) of a 4-column SoA layer: f0 + alpha * f1 with (f0, f1) = (a + b, (a - b) * itw)
-__device__ __forceinline__ QM31 fold_pair(const uint32_t* __restrict__ src, size_t stride, size_t g, uint32_t it, const QM31& alpha) {
+__device__ __forceinline__ QM31 fold_pair(const uint32_t* __restrict__ src, size_t stride, size_t g, uint32_t it, const QM31Mat& alpha_m) {
     uint2 a = reinterpret_cast<const uint2*>(src)[g];
     uint2 b = reinterpret_cast<const uint2*>(src + stride)[g];
     uint2 c = reinterpret_cast<const uint2*>(src + 2 * stride)[g];
     uint2 d = reinterpret_cast<const uint2*>(src + 3 * stride)[g];
     QM31 x = {a.x, b.x, c.x, d.x}, y = {a.y, b.y, c.y, d.y};
-    QM31 f0 = qm_add(x, y), f1 = qm_scale(qm_sub(x, y), it);
-    return qm_add(f0, qm_mul(alpha, f1));
+    return qm_fold_pair(x, y, it, alpha_m);
 }
 
 }  // namespace
@@ -131,8 +130,8 @@ __global__ __launch_bounds__(T5_THREADS) void tree5_kernel(TreeArgs a) {
     uint32_t nl = 1;
     while (nl < T5_LEVELS && (cnt_a >> nl) >= 1) nl++;
 
-    QM31 alpha = {0, 0, 0, 0};
-    if (MODE == T_FOLD_CIRCLE || MODE == T_FOLD_LINE) alpha = {a.tr->alpha[0], a.tr->alpha[1], a.tr->alpha[2], a.tr->alpha[3]};
+    QM31Mat alpha = {};  // multiplication by the layer's folding challenge (uniform: lives in scalar registers)
+    if (MODE == T_FOLD_CIRCLE || MODE == T_FOLD_LINE) alpha = qm_matrix({a.tr->alpha[0], a.tr->alpha[1], a.tr->alpha[2], a.tr->alpha[3]});
 
     // ---- level A ----
     {
@@ -519,7 +518,7 @@ __global__ __launch_bounds__(WG1_THREADS) void tail_kernel(TailArgs a) {
         const bool is_last = kx + 1 == a.n_layers;
         if (t < 4) s_alpha[t] = tr->alpha[t];
         __syncthreads();
-        const QM31 alpha = {s_alpha[0], s_alpha[1], s_alpha[2], s_alpha[3]};
+        const QM31Mat alpha = qm_matrix({s_alpha[0], s_alpha[1], s_alpha[2], s_alpha[3]});
         // line layer of log size src_log sits on twiddle level n - 1 - src_log
         const uint32_t* itw_level = circle ? a.itw : a.itw + tw_level_offset_dev(a.n, a.n - 1 - src_log);
         uint32_t* dstv = a.vals[kx];

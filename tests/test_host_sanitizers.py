@@ -51,3 +51,15 @@ def test_parser_and_verifier_under_asan(fuzz_binary, oracle, blob, tmp_path, cas
     r = subprocess.run([fuzz_binary, str(img), "-" if seed is None else str(seed), "3000"], capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode == 0, (r.stdout + r.stderr)[-2000:]
     assert "accepted_mutants 0" in r.stdout
+
+
+def test_lazy_field_arithmetic_matches_textbook(tmp_path):
+    """field.h's lazily reduced fold (one 64-bit accumulator per coordinate) equals the textbook QM31 sequence, under UBSan,
+    including the operands that attain the accumulator bound."""
+    exe = tmp_path / "test_field"
+    cmd = ["g++", "-std=c++17", "-O2", "-fsanitize=undefined", "-fno-sanitize-recover=undefined", "-I" + CSRC,
+           os.path.join(ROOT, "tests", "cpp", "test_field.cpp"), "-o", str(exe)]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-800:]
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and r.stdout.startswith("OK"), r.stdout + r.stderr
