@@ -5,9 +5,13 @@
 // `MerkleChannel::mix_root` + `Channel::draw_felt`, `FriProver::commit_last_layer`, `GrindOps::grind`
 // (/root/reference/src/commit.rs:17-21, src/proof.rs:52-59; stwo core/fri.rs, core/vcs/prover.rs).
 //
-// tree5_kernel   one workgroup owns 1024 consecutive level-A nodes and produces up to five tree levels (1024, 512,
-//                256, 128, 64 nodes), the intermediate levels living in LDS as struct-of-arrays (one 4-byte column per
-//                hash word, so ds_write_b32 / ds_read_b64 are bank-conflict free).  Level A is produced, by mode, from
+// tree5r_kernel  (launches of >= 2^20 level-A nodes) one workgroup owns 1024 consecutive level-A nodes and produces five tree
+//                levels (1024, 512, 256, 128, 64 nodes).  A thread owns four adjacent level-A nodes and hashes them, their two
+//                parents and their grandparent in registers; only the last two levels cross threads (LDS, struct-of-arrays:
+//                one 4-byte column per hash word, so ds_write_b32 / ds_read_b64 are bank-conflict free).
+// tree5_kernel   (smaller launches) 256 level-A nodes per workgroup, one per thread, all levels through LDS: more, smaller
+//                workgroups and a shorter dependent chain when the launch cannot fill the chip.
+//                Level A is produced, by mode, from
 //                  LEAF4        the 4 SoA columns of a layer (leaf = H(c0,c1,c2,c3, 0 x 12)),
 //                  NODE         the hashes of the level below (node = H(left || right)),
 //                  FOLD_CIRCLE  / FOLD_LINE  the previous FRI layer: the fold of pair (2g, 2g+1) is computed in registers,
@@ -25,6 +29,8 @@
 // half rate on gfx950 (profiles/r01_valu_rate_mi355x.txt): ~1456 full-rate slots per 64 B hashed, i.e. the kernels are
 // bound by the integer VALU pipe (~38 G compressions/s chip-wide), not by HBM.
 #include <hip/hip_runtime.h>
+
+#include <cstdlib>
 
 #include "blake2s.h"
 #include "dev_transcript.h"
@@ -175,6 +181,122 @@ __global__ __launch_bounds__(T5_THREADS) void tree5_kernel(TreeArgs a) {
             if (!last) lds_put(dst, cnt + 4, j, h);
         }
         __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// tree5r: the same five levels for the large launches, with the three lowest levels in registers
+// ------------------------------------------------------------------------------------------------
+// A thread owns FOUR ADJACENT level-A nodes (4t .. 4t+3 of the workgroup's 1024): it produces them, their two parents and
+// their grandparent — seven compressions — without LDS or a barrier; inputs are one 16-byte load per column (or two for a
+// fold).  Only the 256 grandparents of the workgroup go through LDS for the last two levels (128 and 64 nodes), so a workgroup
+// needs 12 KB instead of 48 KB of LDS and the CU holds eight of them: while one is in its narrow levels the others fill the VALU.
+template <int MODE>
+__global__ __launch_bounds__(T5_THREADS) void tree5r_kernel(TreeArgs a) {
+    __shared__ __attribute__((aligned(16))) uint32_t RC[8 * (256 + 4)];
+    __shared__ __attribute__((aligned(16))) uint32_t RD[8 * (128 + 4)];
+    const uint32_t t = threadIdx.x;
+    const size_t wg_base = (size_t)blockIdx.x * 1024;  // the launcher guarantees 2^level_a >= 1024
+    const size_t g0 = wg_base + 4 * t;
+    uint8_t* out_a = a.store_all ? a.layers + layer_off(a.tree_log, a.level_a) : nullptr;
+    uint8_t* out_b = a.store_all ? a.layers + layer_off(a.tree_log, a.level_a - 1) : nullptr;
+    uint8_t* out_c = a.store_all ? a.layers + layer_off(a.tree_log, a.level_a - 2) : nullptr;
+    uint8_t* out_d = a.store_all ? a.layers + layer_off(a.tree_log, a.level_a - 3) : nullptr;
+    uint8_t* out_e = a.store_all ? a.layers + layer_off(a.tree_log, a.level_a - 4) : a.last_out;
+
+    // the four level-A inputs of this thread, one uint4 per column: loaded (LEAF4) or folded from the previous layer (FOLD)
+    uint4 lc0 = {}, lc1 = {}, lc2 = {}, lc3 = {};
+    if (MODE == T_LEAF4) {
+        lc0 = *reinterpret_cast<const uint4*>(a.cols + g0);
+        lc1 = *reinterpret_cast<const uint4*>(a.cols + a.col_stride + g0);
+        lc2 = *reinterpret_cast<const uint4*>(a.cols + 2 * a.col_stride + g0);
+        lc3 = *reinterpret_cast<const uint4*>(a.cols + 3 * a.col_stride + g0);
+    } else if (MODE == T_FOLD_CIRCLE || MODE == T_FOLD_LINE) {
+        const QM31Mat alpha = qm_matrix({a.tr->alpha[0], a.tr->alpha[1], a.tr->alpha[2], a.tr->alpha[3]});
+        uint32_t it[4];
+        if (MODE == T_FOLD_CIRCLE) {
+            // inverse circle twiddles of pairs 4j .. 4j+3 are [y, -y, -x, x] of the table pair j (n >= 3 here)
+            const uint2 xy = *reinterpret_cast<const uint2*>(a.itw + 2 * (g0 >> 2));
+            it[0] = xy.y, it[1] = m31_neg(xy.y), it[2] = m31_neg(xy.x), it[3] = xy.x;
+        } else {
+            const uint4 w = *reinterpret_cast<const uint4*>(a.itw + g0);
+            it[0] = w.x, it[1] = w.y, it[2] = w.z, it[3] = w.w;
+        }
+        // source values 2 g0 .. 2 g0 + 7 of every column (32 contiguous bytes per lane): the pairs (2g, 2g+1), g = g0 .. g0+3
+        uint4 s[4][2];
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            s[c][0] = *reinterpret_cast<const uint4*>(a.cols + c * a.col_stride + 2 * g0);
+            s[c][1] = *reinterpret_cast<const uint4*>(a.cols + c * a.col_stride + 2 * g0 + 4);
+        }
+        const QM31 r0 = qm_fold_pair({s[0][0].x, s[1][0].x, s[2][0].x, s[3][0].x}, {s[0][0].y, s[1][0].y, s[2][0].y, s[3][0].y}, it[0], alpha);
+        const QM31 r1 = qm_fold_pair({s[0][0].z, s[1][0].z, s[2][0].z, s[3][0].z}, {s[0][0].w, s[1][0].w, s[2][0].w, s[3][0].w}, it[1], alpha);
+        const QM31 r2 = qm_fold_pair({s[0][1].x, s[1][1].x, s[2][1].x, s[3][1].x}, {s[0][1].y, s[1][1].y, s[2][1].y, s[3][1].y}, it[2], alpha);
+        const QM31 r3 = qm_fold_pair({s[0][1].z, s[1][1].z, s[2][1].z, s[3][1].z}, {s[0][1].w, s[1][1].w, s[2][1].w, s[3][1].w}, it[3], alpha);
+        lc0 = make_uint4(r0.a, r1.a, r2.a, r3.a);
+        lc1 = make_uint4(r0.b, r1.b, r2.b, r3.b);
+        lc2 = make_uint4(r0.c, r1.c, r2.c, r3.c);
+        lc3 = make_uint4(r0.d, r1.d, r2.d, r3.d);
+        *reinterpret_cast<uint4*>(a.out_vals + g0) = lc0;  // the folded layer, full 16-byte stores
+        *reinterpret_cast<uint4*>(a.out_vals + a.out_stride + g0) = lc1;
+        *reinterpret_cast<uint4*>(a.out_vals + 2 * a.out_stride + g0) = lc2;
+        *reinterpret_cast<uint4*>(a.out_vals + 3 * a.out_stride + g0) = lc3;
+    }
+    uint32_t hb[2][8];
+#pragma unroll
+    for (int half = 0; half < 2; half++) {
+        uint32_t ha[2][8];
+        const size_t g = g0 + 2 * half;  // level-A nodes g, g + 1
+        if (MODE == T_NODE) {
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                uint32_t m[16];
+                load_children(a.children, g + k, m);
+                b2_merkle_block(m, ha[k]);
+            }
+        } else if (half == 0) {
+            leaf_hash(lc0.x, lc1.x, lc2.x, lc3.x, ha[0]);
+            leaf_hash(lc0.y, lc1.y, lc2.y, lc3.y, ha[1]);
+        } else {
+            leaf_hash(lc0.z, lc1.z, lc2.z, lc3.z, ha[0]);
+            leaf_hash(lc0.w, lc1.w, lc2.w, lc3.w, ha[1]);
+        }
+        if (out_a) {
+            store_hash(out_a, g, ha[0]);
+            store_hash(out_a, g + 1, ha[1]);
+        }
+        uint32_t m[16];
+#pragma unroll
+        for (int w = 0; w < 8; w++) m[w] = ha[0][w], m[8 + w] = ha[1][w];
+        b2_merkle_block(m, hb[half]);
+    }
+    if (out_b) {
+        store_hash(out_b, (g0 >> 1), hb[0]);
+        store_hash(out_b, (g0 >> 1) + 1, hb[1]);
+    }
+    uint32_t hc[8];
+    {
+        uint32_t m[16];
+#pragma unroll
+        for (int w = 0; w < 8; w++) m[w] = hb[0][w], m[8 + w] = hb[1][w];
+        b2_merkle_block(m, hc);
+    }
+    if (out_c) store_hash(out_c, g0 >> 2, hc);
+    lds_put(RC, 256 + 4, t, hc);
+    __syncthreads();
+    if (t < 128) {
+        uint32_t m[16], h[8];
+        lds_children(RC, 256 + 4, t, m);
+        b2_merkle_block(m, h);
+        if (out_d) store_hash(out_d, (wg_base >> 3) + t, h);
+        lds_put(RD, 128 + 4, t, h);
+    }
+    __syncthreads();
+    if (t < 64) {
+        uint32_t m[16], h[8];
+        lds_children(RD, 128 + 4, t, m);
+        b2_merkle_block(m, h);
+        store_hash(out_e, (wg_base >> 4) + t, h);
     }
 }
 
@@ -658,12 +780,16 @@ __global__ __launch_bounds__(256) void grind_dev_kernel(GrindArgs a) {
 
 // Launches with few level-A nodes cannot fill the chip and are latency-bound: they use 256-node workgroups (one hash per
 // thread and level, four times as many workgroups) instead of 1024-node ones.
-constexpr uint32_t T5_SMALL_LOG = 20;  // level_a below this: 256-node workgroups
+constexpr uint32_t T5_SMALL_LOG = 20;  // level_a below this: 256-node workgroups (measured: 17..19 are no faster)
 uint32_t tree5_units_log(uint32_t level_a) { return level_a < T5_SMALL_LOG ? 8u : (T5_UNITS == 1024 ? 10u : 9u); }
 
 void launch_tree5(const Launch& L, int mode, const TreeArgs& a, const char* name, double alg_bytes) {
     const size_t total = (size_t)1 << a.level_a;
-    const bool small = tree5_units_log(a.level_a) == 8;
+    // the register-subtree kernel uses 16-byte column accesses; anything unaligned (Level B callers may pass any pointers)
+    // takes the 256-unit kernel, which produces the same levels
+    const bool aligned16 = ((reinterpret_cast<uintptr_t>(a.cols) | reinterpret_cast<uintptr_t>(a.out_vals) | reinterpret_cast<uintptr_t>(a.itw) |
+                             (a.col_stride * 4) | (a.out_stride * 4)) & 15) == 0;
+    const bool small = tree5_units_log(a.level_a) == 8 || !aligned16;
     const uint32_t units = small ? 256u : T5_UNITS;
     const unsigned grid = (unsigned)((total + units - 1) / units);
     Scope scope(L, name, alg_bytes);
@@ -676,10 +802,10 @@ void launch_tree5(const Launch& L, int mode, const TreeArgs& a, const char* name
         }
     } else {
         switch (mode) {
-            case T_LEAF4: tree5_kernel<T_LEAF4, T5_UNITS><<<grid, T5_THREADS, 0, L.stream>>>(a); break;
-            case T_NODE: tree5_kernel<T_NODE, T5_UNITS><<<grid, T5_THREADS, 0, L.stream>>>(a); break;
-            case T_FOLD_CIRCLE: tree5_kernel<T_FOLD_CIRCLE, T5_UNITS><<<grid, T5_THREADS, 0, L.stream>>>(a); break;
-            default: tree5_kernel<T_FOLD_LINE, T5_UNITS><<<grid, T5_THREADS, 0, L.stream>>>(a); break;
+            case T_LEAF4: tree5r_kernel<T_LEAF4><<<grid, T5_THREADS, 0, L.stream>>>(a); break;
+            case T_NODE: tree5r_kernel<T_NODE><<<grid, T5_THREADS, 0, L.stream>>>(a); break;
+            case T_FOLD_CIRCLE: tree5r_kernel<T_FOLD_CIRCLE><<<grid, T5_THREADS, 0, L.stream>>>(a); break;
+            default: tree5r_kernel<T_FOLD_LINE><<<grid, T5_THREADS, 0, L.stream>>>(a); break;
         }
     }
 }

@@ -1,14 +1,11 @@
 """Builds profiles/<tag>_traffic.json from two rocprofv3 PMC runs of bench.py (one --pmc FETCH_SIZE, one --pmc WRITE_SIZE,
 each with --kernel-trace only, as MI355X_MICROARCH.md §HBM prescribes).
 
-Per kernel family (the names bench.py's HIP-event timer uses) and per step: FETCH_SIZE and WRITE_SIZE in KiB, and
+Per kernel family (the names bench.py's HIP-event timer uses), averaged per launch: FETCH_SIZE and WRITE_SIZE in KiB, and
     traffic_bytes = 1024 * (fetch_correction * FETCH_SIZE + WRITE_SIZE)
-with fetch_correction = 2 where the guide's gfx950 rule applies (FETCH_SIZE reports exactly half the bytes of a wide
-coalesced streaming read) — verified here on kernels whose read volume is known exactly (tree5_leaf reads 16 N bytes of
-columns: FETCH_SIZE * 1024 = 8.0 N; the contiguous NTT pass reads 16 N: FETCH_SIZE * 1024 = 9.1 N incl. twiddles).
-The strided NTT pass re-reads the 16.8 MB coefficient array 16 times mostly from L2/MALL, so its counter is not doubled.
+with the correction calibrated per kernel symbol on known byte counts (RULES below), as the guide prescribes.
 
-usage: python tools/traffic_from_pmc.py <fetch_dir> <write_dir> <out.json>
+usage: python tools/traffic_from_pmc.py <fetch_dir | counter_collection.csv> <write_dir | counter_collection.csv> <out.json>
 """
 import collections
 import csv
@@ -17,56 +14,70 @@ import json
 import re
 import sys
 
-FAMILY = [
-    (r"tree5_kernel<0, ", "tree5_leaf"),
-    (r"tree5_kernel<1, ", "tree5_node"),
-    (r"tree5_kernel<2, ", "tree5_fold_circle"),
-    (r"tree5_kernel<3, ", "tree5_fold_line"),
-    (r"tree7q_kernel", "tree7q_node"),
-    (r"top_kernel", "tree_top"),
-    (r"tail_kernel", "fri_tail"),
-    (r"ntt_tile12_kernel<2, 4>", "ntt_pass_mid"),
-    (r"ntt_tile12_kernel<3, 0>", "ntt_pass_last"),
-    (r"unpack30", "unpack30"),
-    (r"grind_dev_kernel", "grind"),
-    (r"gather_kernel", "gather"),
+# (kernel symbol substring, family, FETCH_SIZE correction).  The correction is 2 where the counter is known to report half the
+# bytes (16-byte-per-lane fully coalesced streaming reads: checked on tree5_leaf, 16 N bytes of columns read, counter 8.0 N; the
+# contiguous NTT pass, 16 N read, counter 9.1 N incl. twiddles; the fold kernels, 32 N' + twiddles read as two 16-byte loads per
+# lane and column, counter 17.7 N') and 1 for the strided NTT pass, which re-reads the 16.8 MB coefficient array 16 times, mostly
+# from L2/MALL.  (A variant of the fold kernel that read the same bytes as 16-byte loads 32 bytes apart was counted in full,
+# 34 N' — the halving really is a property of the access pattern, as the guide says.)
+RULES = [
+    (r"tree5r_kernel<0>", "tree5_leaf", 2.0),
+    (r"tree5r_kernel<1>", "tree5_node", 2.0),
+    (r"tree5r_kernel<2>", "tree5_fold_circle", 2.0),
+    (r"tree5r_kernel<3>", "tree5_fold_line", 2.0),
+    (r"tree5_kernel<0, ", "tree5_leaf", 2.0),
+    (r"tree5_kernel<1, ", "tree5_node", 2.0),
+    (r"tree5_kernel<2, ", "tree5_fold_circle", 2.0),
+    (r"tree5_kernel<3, ", "tree5_fold_line", 2.0),
+    (r"tree7q_kernel", "tree7q_node", 2.0),
+    (r"top_kernel", "tree_top", 2.0),
+    (r"tail_kernel", "fri_tail", 2.0),
+    (r"ntt_tile12_kernel<2, 4>", "ntt_pass_mid", 1.0),
+    (r"ntt_tile12_kernel<3, 0>", "ntt_pass_last", 2.0),
+    (r"unpack30", "unpack30", 2.0),
+    (r"grind_dev_kernel", "grind", 2.0),
+    (r"gather_kernel", "gather", 2.0),
 ]
-NO_DOUBLE = {"ntt_pass_mid"}
 
 
 def family(name):
-    for pat, fam in FAMILY:
+    for pat, fam, corr in RULES:
         if pat in name:
-            return fam
-    return None
+            return fam, corr
+    return None, 1.0
 
 
-def collect(d):
-    f = glob.glob(d + "/*/*counter_collection.csv")[0]
+def collect(d, correct):
+    """per family: (sum over launches of corrected counter in KiB, launches)"""
+    f = d if d.endswith(".csv") else glob.glob(d + "/*/*counter_collection.csv")[0]
     agg = collections.defaultdict(float)
+    raw = collections.defaultdict(float)
     cnt = collections.defaultdict(int)
     for r in csv.DictReader(open(f)):
-        fam = family(r["Kernel_Name"])
+        fam, corr = family(r["Kernel_Name"])
         if fam:
-            agg[fam] += float(r["Counter_Value"])
+            v = float(r["Counter_Value"])
+            raw[fam] += v
+            agg[fam] += v * (corr if correct else 1.0)
             cnt[fam] += 1
-    return agg, cnt
+    return agg, raw, cnt
 
 
 def main():
     fetch_dir, write_dir, out = sys.argv[1], sys.argv[2], sys.argv[3]
-    fa, fc = collect(fetch_dir)
-    wa, wc = collect(write_dir)
-    res = {"_units": "averages per launch of the kernel family over the profiled run; traffic_bytes_per_launch in bytes", "kernels": {}}
+    fa, fraw, fc = collect(fetch_dir, True)
+    wa, _, wc = collect(write_dir, False)
+    res = {"_units": "averages per launch of the kernel family over the profiled run; traffic_bytes_per_launch in bytes; "
+                     "FETCH_SIZE corrected per kernel symbol (RULES in tools/traffic_from_pmc.py)", "kernels": {}}
     for fam in sorted(set(fa) | set(wa)):
-        corr = 1.0 if fam in NO_DOUBLE else 2.0
-        f, w = fa.get(fam, 0.0) / max(fc.get(fam, 0), 1), wa.get(fam, 0.0) / max(wc.get(fam, 0), 1)
+        nf, nw = max(fc.get(fam, 0), 1), max(wc.get(fam, 0), 1)
+        f, w = fa.get(fam, 0.0) / nf, wa.get(fam, 0.0) / nw
         res["kernels"][fam] = {
             "launches_profiled": fc.get(fam, 0),
-            "FETCH_SIZE_KiB_per_launch": f,
+            "FETCH_SIZE_KiB_per_launch": fraw.get(fam, 0.0) / nf,
+            "FETCH_corrected_KiB_per_launch": f,
             "WRITE_SIZE_KiB_per_launch": w,
-            "fetch_correction": corr,
-            "traffic_bytes_per_launch": 1024.0 * (corr * f + w),
+            "traffic_bytes_per_launch": 1024.0 * (f + w),
         }
     json.dump(res, open(out, "w"), indent=1)
     for k, v in res["kernels"].items():
