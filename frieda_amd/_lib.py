@@ -76,6 +76,10 @@ def lib():
         "frieda_prove_begin": (C.c_int, [vp, vp, sz, u64p, PcsConfigC]),
         "frieda_prove_begin_device": (C.c_int, [vp, vp, sz, u64p, PcsConfigC]),
         "frieda_prove_finish": (C.c_int, [vp, vp, pp]),
+        "frieda_commit_and_generate_proof_batch": (C.c_int, [vp, vp, sz, sz, u32, u64p, PcsConfigC, vp, pp]),
+        "frieda_commit_and_generate_proof_batch_device": (C.c_int, [vp, vp, sz, sz, u32, u64p, PcsConfigC, vp, pp]),
+        "frieda_commit_batch": (C.c_int, [vp, vp, sz, sz, u32, u32, vp]),
+        "frieda_commit_batch_device": (C.c_int, [vp, vp, sz, sz, u32, u32, vp]),
         "frieda_verify": (C.c_int, [vp, u64p, C.POINTER(C.c_int)]),
         "frieda_proof_free": (None, [vp]),
         "frieda_proof_clone": (C.c_int, [vp, pp]),

@@ -162,6 +162,56 @@ class Context:
     def prove_begin_device(self, d_ptr, length, seed, pcs_config):
         _check(self._L.frieda_prove_begin_device(self._h, d_ptr, length, _seed_ptr(seed), pcs_config._c()), self._h)
 
+    # ---- batches of equal-length blobs: every kernel handles the whole batch (include/frieda_hip.h) ----
+    def _seeds_array(self, seeds, count):
+        if seeds is None:
+            return None
+        if len(seeds) != count:
+            raise ValueError("one seed per blob")
+        return (C.c_uint64 * count)(*[int(s) for s in seeds])
+
+    def commit_and_generate_proof_batch(self, blobs, seeds, pcs_config):
+        """blobs: equal-length bytes-like objects; seeds: None or one int per blob.  Returns [(commitment, Proof), ...]."""
+        count = len(blobs)
+        if count == 0:
+            return []
+        length = len(blobs[0])
+        if any(len(b) != length for b in blobs):
+            raise ValueError("a batch holds blobs of one length")
+        flat = b"".join(bytes(b) for b in blobs)
+        buf = (C.c_uint8 * max(len(flat), 1)).from_buffer_copy(flat or b"\0")
+        return self._prove_batch(self._L.frieda_commit_and_generate_proof_batch, buf, length, length, count, seeds, pcs_config)
+
+    def commit_and_generate_proof_batch_device(self, d_ptr, stride, length, count, seeds, pcs_config):
+        return self._prove_batch(self._L.frieda_commit_and_generate_proof_batch_device, d_ptr, stride, length, count, seeds, pcs_config)
+
+    def _prove_batch(self, fn, data, stride, length, count, seeds, pcs_config):
+        roots = (C.c_uint8 * (32 * count))()
+        outs = (C.c_void_p * count)()
+        _check(fn(self._h, data, stride, length, count, self._seeds_array(seeds, count), pcs_config._c(), roots, outs), self._h)
+        rb = bytes(roots)
+        return [(rb[32 * i : 32 * i + 32], Proof(C.c_void_p(outs[i]))) for i in range(count)]
+
+    def commit_batch(self, blobs, log_blowup_factor):
+        count = len(blobs)
+        if count == 0:
+            return []
+        length = len(blobs[0])
+        if any(len(b) != length for b in blobs):
+            raise ValueError("a batch holds blobs of one length")
+        flat = b"".join(bytes(b) for b in blobs)
+        buf = (C.c_uint8 * max(len(flat), 1)).from_buffer_copy(flat or b"\0")
+        roots = (C.c_uint8 * (32 * count))()
+        _check(self._L.frieda_commit_batch(self._h, buf, length, length, count, log_blowup_factor, roots), self._h)
+        rb = bytes(roots)
+        return [rb[32 * i : 32 * i + 32] for i in range(count)]
+
+    def commit_batch_device(self, d_ptr, stride, length, count, log_blowup_factor):
+        roots = (C.c_uint8 * (32 * count))()
+        _check(self._L.frieda_commit_batch_device(self._h, d_ptr, stride, length, count, log_blowup_factor, roots), self._h)
+        rb = bytes(roots)
+        return [rb[32 * i : 32 * i + 32] for i in range(count)]
+
     def prove_finish(self):
         root = (C.c_uint8 * 32)()
         out = C.c_void_p()

@@ -200,6 +200,63 @@ int frieda_prove_finish(frieda_ctx* ctx, uint8_t out_commitment[32], frieda_proo
     FR_GUARD_END(ctx)
 }
 
+// ---- batches ----
+namespace {
+int batch_prove(frieda_ctx* ctx, const uint8_t* data, size_t stride, size_t len, uint32_t count, bool on_device, const uint64_t* seeds,
+                frieda_pcs_config cfg, uint8_t* out_commitments, frieda_proof** out_proofs) {
+    if (!ctx || !out_proofs || !out_commitments || (!data && len) || count == 0) return FRIEDA_ERR_ARG;
+    for (uint32_t i = 0; i < count; i++) out_proofs[i] = nullptr;
+    FR_GUARD_BEGIN
+    int rc = prove_begin_batch(&ctx->c, data, stride, len, count, on_device, seeds, cfg);
+    if (rc != FRIEDA_OK) return rc;
+    std::vector<ProofData> outs;
+    rc = prove_finish_batch(&ctx->c, out_commitments, outs);
+    if (rc != FRIEDA_OK) return rc;
+    for (uint32_t i = 0; i < count; i++) {
+        frieda_proof* p = new (std::nothrow) frieda_proof();
+        if (!p) {
+            for (uint32_t j = 0; j < i; j++) {
+                delete out_proofs[j];
+                out_proofs[j] = nullptr;
+            }
+            return ctx->c.fail(FRIEDA_ERR_NOMEM, "out of host memory");
+        }
+        p->p = std::move(outs[i]);
+        out_proofs[i] = p;
+    }
+    return FRIEDA_OK;
+    FR_GUARD_END(ctx)
+}
+}  // namespace
+
+int frieda_commit_and_generate_proof_batch(frieda_ctx* ctx, const uint8_t* data, size_t stride, size_t len, uint32_t count,
+                                           const uint64_t* seeds, frieda_pcs_config cfg, uint8_t* out_commitments,
+                                           frieda_proof** out_proofs) {
+    return batch_prove(ctx, data, stride, len, count, false, seeds, cfg, out_commitments, out_proofs);
+}
+
+int frieda_commit_and_generate_proof_batch_device(frieda_ctx* ctx, const void* d_data, size_t stride, size_t len, uint32_t count,
+                                                  const uint64_t* seeds, frieda_pcs_config cfg, uint8_t* out_commitments,
+                                                  frieda_proof** out_proofs) {
+    return batch_prove(ctx, static_cast<const uint8_t*>(d_data), stride, len, count, true, seeds, cfg, out_commitments, out_proofs);
+}
+
+int frieda_commit_batch(frieda_ctx* ctx, const uint8_t* data, size_t stride, size_t len, uint32_t count, uint32_t log_blowup_factor,
+                        uint8_t* out_roots) {
+    if (!ctx || !out_roots || (!data && len) || count == 0) return FRIEDA_ERR_ARG;
+    FR_GUARD_BEGIN
+    return commit_batch(&ctx->c, data, stride, len, count, false, log_blowup_factor, out_roots);
+    FR_GUARD_END(ctx)
+}
+
+int frieda_commit_batch_device(frieda_ctx* ctx, const void* d_data, size_t stride, size_t len, uint32_t count, uint32_t log_blowup_factor,
+                               uint8_t* out_roots) {
+    if (!ctx || !out_roots || (!d_data && len) || count == 0) return FRIEDA_ERR_ARG;
+    FR_GUARD_BEGIN
+    return commit_batch(&ctx->c, static_cast<const uint8_t*>(d_data), stride, len, count, true, log_blowup_factor, out_roots);
+    FR_GUARD_END(ctx)
+}
+
 int frieda_verify(const frieda_proof* proof, const uint64_t* seed, int* ok) {
     if (!proof || !ok) return FRIEDA_ERR_ARG;
     frieda_ctx* none = nullptr;

@@ -40,7 +40,10 @@ __device__ __forceinline__ uint4 extract4(const uint32_t (&w)[5]) {
 }
 
 __global__ __launch_bounds__(256) void unpack30_aligned_kernel(const uint8_t* __restrict__ in, size_t len,
-                                                               uint32_t* __restrict__ out, size_t n_quads) {
+                                                               uint32_t* __restrict__ out, size_t n_quads, size_t in_bstride,
+                                                               size_t out_bstride) {
+    in += blockIdx.y * in_bstride;  // blob of a batch
+    out = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(out) + blockIdx.y * out_bstride);
     // the workgroup's 256 quads cover bytes [3840 b, 3840 (b + 1)) = 960 aligned dwords: stage them through LDS with
     // coalesced loads, then every thread funnel-shifts its own 15-byte window
     __shared__ uint32_t stage[964];
@@ -66,7 +69,10 @@ __global__ __launch_bounds__(256) void unpack30_aligned_kernel(const uint8_t* __
 
 // any alignment: one felt per thread from byte loads
 __global__ __launch_bounds__(256) void unpack30_bytes_kernel(const uint8_t* __restrict__ in, size_t len,
-                                                             uint32_t* __restrict__ out, size_t n_out) {
+                                                             uint32_t* __restrict__ out, size_t n_out, size_t in_bstride,
+                                                             size_t out_bstride) {
+    in += blockIdx.y * in_bstride;
+    out = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(out) + blockIdx.y * out_bstride);
     size_t kf = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (kf >= n_out) return;
     size_t bit0 = 30 * kf, byte0 = bit0 >> 3;
@@ -79,19 +85,19 @@ __global__ __launch_bounds__(256) void unpack30_bytes_kernel(const uint8_t* __re
 
 }  // namespace
 
-void unpack30(const Launch& L, const uint8_t* d_bytes, size_t len, uint32_t* d_out, size_t n_out) {
+void unpack30(const Launch& L, const uint8_t* d_bytes, size_t len, uint32_t* d_out, size_t n_out, size_t src_bstride) {
     if (n_out == 0) return;
     hipStream_t s = L.stream;
     Scope scope(L, "unpack30", (double)len + 4.0 * (double)n_out);
     bool aligned = ((reinterpret_cast<uintptr_t>(d_bytes) & 3) == 0) && ((reinterpret_cast<uintptr_t>(d_out) & 15) == 0) &&
-                   (n_out % 4 == 0);
+                   (n_out % 4 == 0) && (src_bstride % 4 == 0) && (L.bstride % 16 == 0);
     if (aligned) {
         size_t quads = n_out / 4;
-        unsigned grid = (unsigned)((quads + 255) / 256);
-        unpack30_aligned_kernel<<<grid, 256, 0, s>>>(d_bytes, len, d_out, quads);
+        dim3 grid((unsigned)((quads + 255) / 256), L.batch);
+        unpack30_aligned_kernel<<<grid, 256, 0, s>>>(d_bytes, len, d_out, quads, src_bstride, L.bstride);
     } else {
-        unsigned grid = (unsigned)((n_out + 255) / 256);
-        unpack30_bytes_kernel<<<grid, 256, 0, s>>>(d_bytes, len, d_out, n_out);
+        dim3 grid((unsigned)((n_out + 255) / 256), L.batch);
+        unpack30_bytes_kernel<<<grid, 256, 0, s>>>(d_bytes, len, d_out, n_out, src_bstride, L.bstride);
     }
 }
 

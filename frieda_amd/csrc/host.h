@@ -132,6 +132,14 @@ int prove(Ctx* ctx, const uint8_t* data, size_t len, bool data_on_device, const 
 // opens the queries and assembles the proof.  One proof in flight per ctx; use several ctxs to overlap proofs.
 int prove_begin(Ctx* ctx, const uint8_t* data, size_t len, bool data_on_device, const uint64_t* seed, frieda_pcs_config cfg);
 int prove_finish(Ctx* ctx, uint8_t out_commitment[32], ProofData& out);
+// batches: `count` blobs of `len` bytes each (blob b at data + b * data_stride), one seed per blob or null; every kernel of the
+// commit phase processes all blobs in one launch (Fiat-Shamir and launch latency are paid once per batch).  Needs the device
+// channel (last layer <= 2^11 points).  prove_finish_batch writes count * 32 bytes of commitments.
+int prove_begin_batch(Ctx* ctx, const uint8_t* data, size_t data_stride, size_t len, uint32_t count, bool data_on_device,
+                      const uint64_t* seeds, frieda_pcs_config cfg);
+int prove_finish_batch(Ctx* ctx, uint8_t* out_commitments, std::vector<ProofData>& outs);
+int commit_batch(Ctx* ctx, const uint8_t* data, size_t data_stride, size_t len, uint32_t count, bool data_on_device, uint32_t log_blowup,
+                 uint8_t* out_roots);
 // returns FRIEDA_OK with *ok set, or FRIEDA_ERR_INVARIANT where the reference panics
 int verify(const ProofData& proof, const uint64_t* seed, int* ok);
 

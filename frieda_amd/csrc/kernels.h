@@ -19,17 +19,24 @@ __device__ __forceinline__ size_t tw_level_offset_dev(uint32_t n, uint32_t lv) {
 // Launch context: the stream plus an optional per-kernel timer (HIP events recorded on that same stream around
 // every launch; off unless frieda_ctx_set_kernel_timing enabled it).  alg_bytes = the algorithmic (compulsory)
 // HBM bytes of the launch by the byte model of SURVEY.md §8d / DESIGN.md §5.
+//
+// Batches: the commit-phase launchers process `batch` independent blobs of one shape per launch.  Blob b's workspace is the
+// single-blob workspace shifted by b * bstride bytes (every device pointer a launcher receives is blob 0's; the kernels add
+// blockIdx.y — blockIdx.z in the transforms — times bstride); the DevTranscripts form a contiguous array indexed by b;
+// twiddle tables are shared.  batch == 1, bstride == 0 is the single-blob case.
 struct KernelTimer;
 struct Launch {
     hipStream_t stream;
     KernelTimer* timer;
+    uint32_t batch = 1;
+    size_t bstride = 0;
 };
 void timer_begin(KernelTimer* t, hipStream_t s, const char* name, double alg_bytes);
 void timer_end(KernelTimer* t, hipStream_t s);
 struct Scope {
     const Launch& l;
     Scope(const Launch& l_, const char* name, double alg_bytes) : l(l_) {
-        if (l.timer) timer_begin(l.timer, l.stream, name, alg_bytes);
+        if (l.timer) timer_begin(l.timer, l.stream, name, alg_bytes * l.batch);
     }
     ~Scope() {
         if (l.timer) timer_end(l.timer, l.stream);
@@ -43,8 +50,9 @@ struct DomainScalars {
 };
 
 // ---- codec.hip ----
-// src/utils.rs:10-33: bytes -> 30-bit felts, zero padded up to n_out (multiple of 4)
-void unpack30(const Launch& L, const uint8_t* d_bytes, size_t len, uint32_t* d_out, size_t n_out);
+// src/utils.rs:10-33: bytes -> 30-bit felts, zero padded up to n_out (multiple of 4).  In a batch, blob b's bytes start at
+// d_bytes + b * src_bstride (the caller's layout); its felts go to d_out shifted by b * L.bstride bytes.
+void unpack30(const Launch& L, const uint8_t* d_bytes, size_t len, uint32_t* d_out, size_t n_out, size_t src_bstride = 0);
 
 // ---- twiddle.hip ----
 struct TwiddleSeeds {

@@ -63,6 +63,7 @@ struct NttArgs {
     uint32_t ncols;       // columns handled by one workgroup (<= 4); grid.y strides over groups of this many
     uint32_t n_stages;    // <= 3
     uint32_t stage_r[3];  // layers per stage, top stage first
+    size_t bstride_w;     // batch: words between consecutive blobs' buffers (both in and out); blob = blockIdx.z
 };
 
 // One stage of R layers on tile bits [lo, lo + R): every thread processes groups of 2^R elements.
@@ -127,12 +128,13 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_tile_kernel(NttArgs a) {
     const uint32_t hblk = blockIdx.x >> nwb_log;
     const uint32_t gbase = (hblk << (a.i_hi + 1)) | (wblk << a.log_w);
     const size_t col0 = (size_t)blockIdx.y * a.ncols;
-    const uint32_t* in = a.in + col0 * a.in_stride;
-    uint32_t* out = a.out + col0 * a.out_stride;
+    const uint32_t* in = a.in + col0 * a.in_stride + blockIdx.z * a.bstride_w;
+    uint32_t* out = a.out + col0 * a.out_stride + blockIdx.z * a.bstride_w;
     // 16-byte global accesses need 4-word runs: tiles of >= 4 words whose low run (2^log_w, or the whole tile when
     // log_w == 0) is a multiple of 4, and 16-byte aligned column bases
     const bool vec = tb >= 2 && (a.log_w == 0 || a.log_w >= 2) && ((a.in_stride | a.out_stride) & 3) == 0 &&
-                     ((reinterpret_cast<uintptr_t>(a.in) | reinterpret_cast<uintptr_t>(a.out)) & 15) == 0 && (a.in_mask & 3u) == 3u;
+                     ((reinterpret_cast<uintptr_t>(a.in) | reinterpret_cast<uintptr_t>(a.out)) & 15) == 0 && (a.in_mask & 3u) == 3u &&
+                     (a.bstride_w & 3) == 0;
 
     for (uint32_t c = 0; c < a.ncols; c++) {
         uint32_t* col = lds + c * TILE_WORDS;
@@ -213,8 +215,8 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_tile12_kernel(NttArgs a) {
     const uint32_t gbase = (hblk << (a.i_hi + 1)) | (wblk << LOG_W);
     constexpr uint32_t wmask = (1u << LOG_W) - 1;
     const size_t col0 = (size_t)blockIdx.y * a.ncols;
-    const uint32_t* in = a.in + col0 * a.in_stride;
-    uint32_t* out = a.out + col0 * a.out_stride;
+    const uint32_t* in = a.in + col0 * a.in_stride + blockIdx.z * a.bstride_w;
+    uint32_t* out = a.out + col0 * a.out_stride + blockIdx.z * a.bstride_w;
 
     // per-stage group base (padded) and twiddles
     uint32_t pbase[NS];
@@ -317,9 +319,9 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_tile12_kernel(NttArgs a) {
 
 // pure replication (L == 0: a constant polynomial has no real layers)
 __global__ void ntt_broadcast_kernel(const uint32_t* __restrict__ in, size_t in_stride, uint32_t* __restrict__ out,
-                                     size_t out_stride, size_t n_out) {
+                                     size_t out_stride, size_t n_out, size_t bstride_w) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n_out) out[(size_t)blockIdx.y * out_stride + i] = in[(size_t)blockIdx.y * in_stride];
+    if (i < n_out) out[blockIdx.z * bstride_w + (size_t)blockIdx.y * out_stride + i] = in[blockIdx.z * bstride_w + (size_t)blockIdx.y * in_stride];
 }
 
 void set_stages(NttArgs& a, uint32_t t) {
@@ -345,8 +347,8 @@ void circle_evaluate(const Launch& L_, const uint32_t* d_coef, size_t coef_strid
     const double enc_bytes = 4.0 * ncols * ((double)N + (double)((size_t)1 << L));
     if (L == 0) {
         Scope scope(L_, "ntt_broadcast", enc_bytes);
-        dim3 grid((unsigned)((N + 255) / 256), ncols);
-        ntt_broadcast_kernel<<<grid, 256, 0, s>>>(d_coef, coef_stride, d_out, out_stride, N);
+        dim3 grid((unsigned)((N + 255) / 256), ncols, L_.batch);
+        ntt_broadcast_kernel<<<grid, 256, 0, s>>>(d_coef, coef_stride, d_out, out_stride, N, L_.bstride / 4);
         return;
     }
     // columns per workgroup: the largest divisor of ncols that is <= 4 (the 4 coordinate columns share every twiddle)
@@ -379,16 +381,17 @@ void circle_evaluate(const Launch& L_, const uint32_t* d_coef, size_t coef_strid
     a.tw = d_tw;
     a.n = n;
     a.init_y = ds.init_y;
+    a.bstride_w = L_.bstride / 4;
     uint32_t cpw4 = MAX_COLS_PER_WG;
     while (ncols % cpw4) cpw4--;
     // one pass over layers a.i_hi .. a.i_lo
     auto launch_pass = [&](uint32_t t, const char* name) {
         const bool aligned = ((a.in_stride | a.out_stride) & 3) == 0 && (a.in_mask & 3u) == 3u &&
-                             ((reinterpret_cast<uintptr_t>(a.in) | reinterpret_cast<uintptr_t>(a.out)) & 15) == 0;
+                             ((reinterpret_cast<uintptr_t>(a.in) | reinterpret_cast<uintptr_t>(a.out) | L_.bstride) & 15) == 0;
         Scope scope(L_, name, enc_bytes / (n_mid + 1));
         if (aligned && t + a.log_w == TILE_LOG && (t == 12 || t == 8)) {
             a.ncols = cpw4;
-            dim3 grid((unsigned)(N >> TILE_LOG), ncols / cpw4);
+            dim3 grid((unsigned)(N >> TILE_LOG), ncols / cpw4, L_.batch);
             if (a.log_w == 0)
                 ntt_tile12_kernel<3, 0><<<grid, NTT_THREADS, 0, s>>>(a);
             else
@@ -396,7 +399,7 @@ void circle_evaluate(const Launch& L_, const uint32_t* d_coef, size_t coef_strid
         } else {
             a.ncols = cpw;
             set_stages(a, t);
-            dim3 grid((unsigned)(N >> (t + a.log_w)), ncols / cpw);
+            dim3 grid((unsigned)(N >> (t + a.log_w)), ncols / cpw, L_.batch);
             ntt_tile_kernel<<<grid, NTT_THREADS, lds_bytes, s>>>(a);
         }
     };

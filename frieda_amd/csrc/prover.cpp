@@ -155,6 +155,53 @@ int commit_host(Ctx* ctx, const uint8_t* data, size_t len, uint32_t log_blowup, 
     return FRIEDA_OK;
 }
 
+// commit() of `count` blobs of one length in one pass of launches (blob b at data + b * data_stride); roots to host memory
+int commit_batch(Ctx* ctx, const uint8_t* data, size_t data_stride, size_t len, uint32_t count, bool data_on_device, uint32_t log_blowup,
+                 uint8_t* out_roots) {
+    if (count == 0 || count > 65535) return ctx->fail(FRIEDA_ERR_ARG, "batch count out of range");
+    if (count > 1 && data_stride < len) return ctx->fail(FRIEDA_ERR_ARG, "batch stride smaller than the blob length");
+    Shape sh;
+    int rc = make_shape(ctx, len, log_blowup, sh);
+    if (rc) return rc;
+    FR_HIP(ctx, hipSetDevice(ctx->device));
+    ArenaPlan plan;
+    const size_t o_data = plan.take(data_on_device ? 0 : len);
+    const size_t o_coef = plan.take(sizeof(uint32_t) * sh.cs.n_padded);
+    const size_t o_eval = plan.take(sizeof(uint32_t) * 4 * sh.N);
+    const size_t o_scr = plan.take(k::merkle_root_scratch_bytes(sh.n));
+    const size_t o_root = plan.take(32);
+    const size_t bstride = plan.off;
+    rc = ctx->ensure_arena(bstride * count);
+    if (rc) return rc;
+    rc = ensure_pinned(ctx, 32 * (size_t)count + 4096);
+    if (rc) return rc;
+    TwiddleSet tw;
+    rc = ctx->get_twiddles(sh.n, tw);
+    if (rc) return rc;
+    hipStream_t s = ctx->stream;
+    uint8_t* A = ctx->arena;
+    k::Launch LN = ctx->launch();
+    LN.batch = count;
+    LN.bstride = count > 1 ? bstride : 0;
+    const uint8_t* d_data = data;
+    size_t d_stride = data_stride;
+    if (!data_on_device) {
+        if (len) FR_HIP(ctx, hipMemcpy2DAsync(A + o_data, bstride, data, count > 1 ? data_stride : len, len, count, hipMemcpyHostToDevice, s));
+        d_data = A + o_data;
+        d_stride = bstride;
+    }
+    uint32_t* coef = reinterpret_cast<uint32_t*>(A + o_coef);
+    uint32_t* eval = reinterpret_cast<uint32_t*>(A + o_eval);
+    k::unpack30(LN, d_data, len, coef, sh.cs.n_padded, d_stride);
+    k::circle_evaluate(LN, coef, (size_t)1 << sh.L, 4, sh.L, sh.n, tw.d_tw, tw.ds, eval, sh.N);
+    k::merkle_root4(LN, eval, eval + sh.N, eval + 2 * sh.N, eval + 3 * sh.N, sh.n, A + o_scr, A + o_root);
+    FR_HIP(ctx, hipMemcpy2DAsync(ctx->pinned, 32, A + o_root, bstride, 32, count, hipMemcpyDeviceToHost, s));
+    FR_HIP(ctx, hipStreamSynchronize(s));
+    FR_HIP(ctx, hipGetLastError());
+    memcpy(out_roots, ctx->pinned, 32 * (size_t)count);
+    return FRIEDA_OK;
+}
+
 // -------------------------------------------------------------------------------------------------
 // commit_and_generate_proof
 // -------------------------------------------------------------------------------------------------
@@ -247,12 +294,20 @@ struct ProveJob {
     FriLayerDev first{};
     std::vector<FriLayerDev> inner;
     size_t o_lastv = 0, o_nonce = 0, o_tr = 0, o_widx = 0, o_hidx = 0, o_wout = 0, o_hout = 0;
-    size_t max_words = 0, max_hashes = 0;
-    Channel ch{};
+    size_t max_words = 0, max_hashes = 0, tr_host_pitch = 0;
     bool dev_channel = false;
-    std::vector<Hash32> roots;
-    std::vector<QM31> lastv;
-    uint64_t nonce = ~0ull, grind_base = 0, grind_chunk = 0;
+    // a batch of `count` blobs of one shape: blob b's workspace is blob 0's shifted by b * bstride bytes; the transcripts
+    // (o_tr) and the gather regions sit behind the workspaces
+    uint32_t count = 1;
+    size_t bstride = 0;
+    struct Blob {
+        Channel ch{};
+        std::vector<Hash32> roots;
+        std::vector<QM31> lastv;
+        uint64_t nonce = ~0ull;
+    };
+    std::vector<Blob> blobs;
+    uint64_t grind_base = 0, grind_chunk = 0;
     std::chrono::steady_clock::time_point t_start;
 };
 
@@ -262,8 +317,28 @@ static double ms_since(std::chrono::steady_clock::time_point t0) {
     return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
 }
 
+// transcript summaries (header + last-layer polynomial) of all blobs -> pinned memory, blob b at b * tr_host_pitch
+static int download_transcripts(Ctx* ctx, const ProveJob& J) {
+    const size_t bytes = offsetof(DevTranscript, last_poly) + ((size_t)16 << J.last);
+    const uint8_t* d_tr = ctx->arena + J.o_tr;
+    if (J.count == 1) {
+        FR_HIP(ctx, hipMemcpyAsync(ctx->pinned, d_tr, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    } else {
+        FR_HIP(ctx, hipMemcpy2DAsync(ctx->pinned, J.tr_host_pitch, d_tr, sizeof(DevTranscript), bytes, J.count, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    return FRIEDA_OK;
+}
+
 int prove_begin(Ctx* ctx, const uint8_t* data, size_t len, bool data_on_device, const uint64_t* seed, frieda_pcs_config cfg) {
+    return prove_begin_batch(ctx, data, 0, len, 1, data_on_device, seed, cfg);
+}
+
+// `count` blobs of `len` bytes each, blob b at data + b * data_stride; seeds: null or one per blob
+int prove_begin_batch(Ctx* ctx, const uint8_t* data, size_t data_stride, size_t len, uint32_t count, bool data_on_device,
+                      const uint64_t* seeds, frieda_pcs_config cfg) {
     if (ctx->job) return ctx->fail(FRIEDA_ERR_ARG, "a proof is already in flight on this context");
+    if (count == 0 || count > 65535) return ctx->fail(FRIEDA_ERR_ARG, "batch count out of range");
+    if (count > 1 && data_stride < len) return ctx->fail(FRIEDA_ERR_ARG, "batch stride smaller than the blob length");
     const uint32_t B = cfg.log_blowup_factor, last = cfg.log_last_layer_degree_bound;
     std::unique_ptr<ProveJob, ProveJobDeleter> jp(new ProveJob());
     ProveJob& J = *jp;
@@ -279,6 +354,8 @@ int prove_begin(Ctx* ctx, const uint8_t* data, size_t len, bool data_on_device, 
     FR_HIP(ctx, hipSetDevice(ctx->device));
     J.cfg = cfg;
     J.last = last;
+    J.count = count;
+    J.blobs.resize(count);
     const uint32_t n = J.n = sh.n, last_log = J.last_log = last + B;
     const size_t N = J.N = sh.N;
     const uint32_t n_inner = J.n_inner = (n - 1) - last_log;
@@ -300,17 +377,23 @@ int prove_begin(Ctx* ctx, const uint8_t* data, size_t len, bool data_on_device, 
     }
     const size_t o_lastv = J.o_lastv = plan.take(sizeof(uint32_t) * 4 << last_log);
     const size_t o_nonce = J.o_nonce = plan.take(8);
-    const size_t o_tr = J.o_tr = plan.take(sizeof(DevTranscript));
+    // everything above is per blob; what follows is shared by the batch
+    const size_t bstride = J.bstride = plan.off;  // a multiple of 256
+    plan.off = bstride * count;
+    const size_t o_tr = J.o_tr = plan.take(sizeof(DevTranscript) * count);
     // decommit gather: per layer <= 2 positions per query; hashes <= 2 * queries * log per layer
-    J.max_words = (size_t)cfg.n_queries * 4 * (1 + (n_inner + 1));
-    J.max_hashes = (size_t)cfg.n_queries * 2 * (size_t)(n + 1) * (n_inner + 1);
+    J.max_words = (size_t)cfg.n_queries * 4 * (1 + (n_inner + 1)) * count;
+    J.max_hashes = (size_t)cfg.n_queries * 2 * (size_t)(n + 1) * (n_inner + 1) * count;
     J.o_widx = plan.take(8 * J.max_words);
     J.o_hidx = plan.take(8 * J.max_hashes);
     J.o_wout = plan.take(4 * J.max_words);
     J.o_hout = plan.take(32 * J.max_hashes);
     rc = ctx->ensure_arena(plan.off);
     if (rc) return rc;
-    const size_t pinned_need = std::max<size_t>(std::max<size_t>(sizeof(DevTranscript), (sizeof(uint32_t) * 4) << last_log),
+    // pinned staging: the transcript summaries of all blobs (header + last-layer polynomial each), or the last layer itself on
+    // the host-channel path, or the gather lists and results
+    const size_t tr_host_pitch = J.tr_host_pitch = (offsetof(DevTranscript, last_poly) + ((size_t)16 << last) + 63) & ~(size_t)63;
+    const size_t pinned_need = std::max<size_t>(std::max<size_t>(tr_host_pitch * count, (sizeof(uint32_t) * 4) << last_log),
                                                 (4 + 8) * J.max_words + (32 + 8) * J.max_hashes + 512);
     rc = ensure_pinned(ctx, pinned_need);
     if (rc) return rc;
@@ -320,41 +403,58 @@ int prove_begin(Ctx* ctx, const uint8_t* data, size_t len, bool data_on_device, 
     hipStream_t s = ctx->stream;
     J.t_start = std::chrono::steady_clock::now();
     for (double& v : ctx->phase_ms) v = 0.0;
-    const k::Launch LN = ctx->launch();
+    k::Launch LN = ctx->launch();  // every launch below covers the whole batch
+    LN.batch = count;
+    LN.bstride = count > 1 ? bstride : 0;
     uint8_t* A = ctx->arena;
-
-    // ---- encode (src/proof.rs:38,44-50) ----
-    const uint8_t* d_data = data;
-    if (!data_on_device) {
-        if (len) FR_HIP(ctx, hipMemcpyAsync(A + o_data, data, len, hipMemcpyHostToDevice, s));
-        d_data = A + o_data;
-    }
-    uint32_t* coef = reinterpret_cast<uint32_t*>(A + o_coef);
-    uint32_t* eval = reinterpret_cast<uint32_t*>(A + first.o_vals);
-    k::unpack30(LN, d_data, len, coef, sh.cs.n_padded);
-    k::circle_evaluate(LN, coef, (size_t)1 << sh.L, 4, sh.L, n, tw.d_tw, tw.ds, eval, N);
-
-    Channel& ch = J.ch;
-    ch.init();
-    if (seed) ch.mix_u64(*seed);  // src/proof.rs:40-42
-
-    auto cols = [&](const FriLayerDev& lay, int c) { return reinterpret_cast<uint32_t*>(A + lay.o_vals) + ((size_t)c << lay.log); };
-    std::vector<Hash32>& roots = J.roots;
-    roots.assign(1 + n_inner, Hash32{});
-    std::vector<QM31>& lastv = J.lastv;
     // The whole commit phase runs on the device (transcript included) when the last layer fits the single-workgroup tail;
     // otherwise (log_last_layer_degree_bound + log_blowup_factor > 11) the channel is evaluated on the host between layers.
     const bool dev_channel = J.dev_channel = last_log <= k::TAIL_LOG && !ctx->host_channel;
+    if (count > 1 && !dev_channel)
+        return ctx->fail(FRIEDA_ERR_ARG, "batches need the device channel (last layer <= 2^11 points, host channel policy off)");
+
+    // ---- encode (src/proof.rs:38,44-50) ----
+    const uint8_t* d_data = data;
+    size_t d_data_stride = data_stride;
+    if (!data_on_device) {
+        if (len && count == 1) FR_HIP(ctx, hipMemcpyAsync(A + o_data, data, len, hipMemcpyHostToDevice, s));
+        if (len && count > 1) FR_HIP(ctx, hipMemcpy2DAsync(A + o_data, bstride, data, data_stride, len, count, hipMemcpyHostToDevice, s));
+        d_data = A + o_data;
+        d_data_stride = bstride;
+    }
+    uint32_t* coef = reinterpret_cast<uint32_t*>(A + o_coef);
+    uint32_t* eval = reinterpret_cast<uint32_t*>(A + first.o_vals);
+    k::unpack30(LN, d_data, len, coef, sh.cs.n_padded, d_data_stride);
+    k::circle_evaluate(LN, coef, (size_t)1 << sh.L, 4, sh.L, n, tw.d_tw, tw.ds, eval, N);
+
+    for (uint32_t b = 0; b < count; b++) {
+        J.blobs[b].ch.init();
+        if (seeds) J.blobs[b].ch.mix_u64(seeds[b]);  // src/proof.rs:40-42
+        J.blobs[b].roots.assign(1 + n_inner, Hash32{});
+    }
+    Channel& ch = J.blobs[0].ch;  // (the host-channel path below is single-blob)
+    const uint64_t* seed = seeds;
+    (void)seed;
+
+    auto cols = [&](const FriLayerDev& lay, int c) { return reinterpret_cast<uint32_t*>(A + lay.o_vals) + ((size_t)c << lay.log); };
+    std::vector<Hash32>& roots = J.blobs[0].roots;
+    std::vector<QM31>& lastv = J.blobs[0].lastv;
     if (dev_channel) {
         DevTranscript* d_tr = reinterpret_cast<DevTranscript*>(A + o_tr);
         const size_t hdr = offsetof(DevTranscript, last_poly);
         {
-            DevTranscript* ht = reinterpret_cast<DevTranscript*>(ctx->pinned);
-            memset(ht, 0, hdr);
-            ht->ch = ch;
-            ht->nonce = ~0ull;
-            ht->draw_bound = ctx->test_draw_bound;
-            FR_HIP(ctx, hipMemcpyAsync(d_tr, ht, hdr, hipMemcpyHostToDevice, s));
+            // initial transcripts, staged back to back at tr_host_pitch and copied into the device array in one go
+            for (uint32_t b = 0; b < count; b++) {
+                DevTranscript* ht = reinterpret_cast<DevTranscript*>(static_cast<uint8_t*>(ctx->pinned) + b * tr_host_pitch);
+                memset(ht, 0, hdr);
+                ht->ch = J.blobs[b].ch;
+                ht->nonce = ~0ull;
+                ht->draw_bound = ctx->test_draw_bound;
+            }
+            if (count == 1)
+                FR_HIP(ctx, hipMemcpyAsync(d_tr, ctx->pinned, hdr, hipMemcpyHostToDevice, s));
+            else
+                FR_HIP(ctx, hipMemcpy2DAsync(d_tr, sizeof(DevTranscript), ctx->pinned, tr_host_pitch, hdr, count, hipMemcpyHostToDevice, s));
         }
         // FriProver::commit_first_layer
         k::tree_first_layer(LN, eval, N, n, A + first.o_tree, d_tr);
@@ -393,7 +493,8 @@ int prove_begin(Ctx* ctx, const uint8_t* data, size_t len, bool data_on_device, 
         J.grind_base = 0;
         J.grind_chunk = (uint64_t)1 << 22;
         k::grind_dev(LN, d_tr, cfg.pow_bits, J.grind_base, J.grind_chunk);
-        FR_HIP(ctx, hipMemcpyAsync(ctx->pinned, d_tr, hdr + ((size_t)16 << last), hipMemcpyDeviceToHost, s));
+        rc = download_transcripts(ctx, J);
+        if (rc) return rc;
         FR_HIP(ctx, hipGetLastError());
         ctx->phase_ms[0] = ms_since(J.t_start);  // commit phase fully enqueued
     } else {
@@ -460,8 +561,8 @@ int prove_begin(Ctx* ctx, const uint8_t* data, size_t len, bool data_on_device, 
                 k::grind_scan(LN, ch.digest, cfg.pow_bits, base, chunk, d_nonce);
                 FR_HIP(ctx, hipMemcpyAsync(ctx->pinned, d_nonce, 8, hipMemcpyDeviceToHost, s));
                 FR_HIP(ctx, hipStreamSynchronize(s));
-                memcpy(&J.nonce, ctx->pinned, 8);
-                if (J.nonce != ~0ull) break;
+                memcpy(&J.blobs[0].nonce, ctx->pinned, 8);
+                if (J.blobs[0].nonce != ~0ull) break;
                 base += chunk;
                 if (chunk < ((uint64_t)1 << 28)) chunk <<= 1;
             }
@@ -473,72 +574,101 @@ int prove_begin(Ctx* ctx, const uint8_t* data, size_t len, bool data_on_device, 
 }
 
 int prove_finish(Ctx* ctx, uint8_t out_commitment[32], ProofData& out) {
+    if (ctx->job && ctx->job->count != 1) return ctx->fail(FRIEDA_ERR_ARG, "the proof in flight is a batch: use the batch finish");
+    std::vector<ProofData> outs;
+    int rc = prove_finish_batch(ctx, out_commitment, outs);
+    if (rc) return rc;
+    out = std::move(outs[0]);
+    return FRIEDA_OK;
+}
+
+int prove_finish_batch(Ctx* ctx, uint8_t* out_commitments, std::vector<ProofData>& outs) {
     if (!ctx->job) return ctx->fail(FRIEDA_ERR_ARG, "no proof in flight on this context");
     std::unique_ptr<ProveJob, ProveJobDeleter> jp = std::move(ctx->job);  // released on every exit path
     ProveJob& J = *jp;
     FR_HIP(ctx, hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
-    const k::Launch LN = ctx->launch();
+    k::Launch LN = ctx->launch();
+    LN.batch = J.count;
+    LN.bstride = J.count > 1 ? J.bstride : 0;
     uint8_t* A = ctx->arena;
     const frieda_pcs_config cfg = J.cfg;
-    const uint32_t n = J.n, last = J.last, n_inner = J.n_inner;
+    const uint32_t n = J.n, last = J.last, n_inner = J.n_inner, count = J.count;
     const size_t N = J.N;
     const FriLayerDev& first = J.first;
     const std::vector<FriLayerDev>& inner = J.inner;
-    Channel& ch = J.ch;
-    std::vector<Hash32>& roots = J.roots;
-    std::vector<QM31>& lastv = J.lastv;
-    uint64_t nonce = J.nonce;
 
     if (J.dev_channel) {
         DevTranscript* d_tr = reinterpret_cast<DevTranscript*>(A + J.o_tr);
-        const size_t hdr = offsetof(DevTranscript, last_poly);
         const size_t n_poly = (size_t)1 << last;
-        const DevTranscript* ht = reinterpret_cast<const DevTranscript*>(ctx->pinned);
+        auto host_tr = [&](uint32_t b) { return reinterpret_cast<const DevTranscript*>(static_cast<const uint8_t*>(ctx->pinned) + b * J.tr_host_pitch); };
         for (;;) {
             FR_HIP(ctx, hipStreamSynchronize(s));
-            if (ht->status & 1u) return ctx->fail(FRIEDA_ERR_INVARIANT, "invalid degree");  // assert! upstream
-            if (ht->nonce != ~0ull) break;
+            bool all_found = true;
+            for (uint32_t b = 0; b < count; b++) {
+                if (host_tr(b)->status & 1u) return ctx->fail(FRIEDA_ERR_INVARIANT, "invalid degree");  // assert! upstream
+                all_found &= host_tr(b)->nonce != ~0ull;
+            }
+            if (all_found) break;
+            // next range for the blobs still searching (the others leave at once: their minimum is below every new nonce)
             J.grind_base += J.grind_chunk;
             if (J.grind_chunk < ((uint64_t)1 << 28)) J.grind_chunk <<= 1;
             k::grind_dev(LN, d_tr, cfg.pow_bits, J.grind_base, J.grind_chunk);
-            FR_HIP(ctx, hipMemcpyAsync(ctx->pinned, d_tr, hdr + 16 * n_poly, hipMemcpyDeviceToHost, s));
+            int rc = download_transcripts(ctx, J);
+            if (rc) return rc;
         }
         FR_HIP(ctx, hipGetLastError());
-        if (ht->n_roots != 1 + n_inner || ht->n_last_poly != n_poly) return ctx->fail(FRIEDA_ERR_INVARIANT, "internal: transcript out of step");
-        nonce = ht->nonce;
-        ch = ht->ch;
-        for (uint32_t li = 0; li <= n_inner; li++)
-            for (int w = 0; w < 8; w++)
-                for (int bb = 0; bb < 4; bb++) roots[li][4 * w + bb] = (uint8_t)(ht->roots[li][w] >> (8 * bb));
-        lastv.resize(n_poly);
-        for (size_t i = 0; i < n_poly; i++)
-            lastv[i] = {ht->last_poly[4 * i], ht->last_poly[4 * i + 1], ht->last_poly[4 * i + 2], ht->last_poly[4 * i + 3]};
+        for (uint32_t b = 0; b < count; b++) {
+            const DevTranscript* ht = host_tr(b);
+            ProveJob::Blob& bl = J.blobs[b];
+            if (ht->n_roots != 1 + n_inner || ht->n_last_poly != n_poly) return ctx->fail(FRIEDA_ERR_INVARIANT, "internal: transcript out of step");
+            bl.nonce = ht->nonce;
+            bl.ch = ht->ch;
+            for (uint32_t li = 0; li <= n_inner; li++)
+                for (int w = 0; w < 8; w++)
+                    for (int bb = 0; bb < 4; bb++) bl.roots[li][4 * w + bb] = (uint8_t)(ht->roots[li][w] >> (8 * bb));
+            bl.lastv.resize(n_poly);
+            for (size_t i = 0; i < n_poly; i++)
+                bl.lastv[i] = {ht->last_poly[4 * i], ht->last_poly[4 * i + 1], ht->last_poly[4 * i + 2], ht->last_poly[4 * i + 3]};
+        }
     }
     ctx->phase_ms[1] = ms_since(J.t_start);  // commit phase + grind complete on the device (first synchronise)
-    ch.mix_u64(nonce);  // src/proof.rs:59
 
-    // ---- FriProver::decommit ----
-    std::vector<uint32_t> queries = generate_queries(ch, n, cfg.n_queries);
-    ctx->phase_ms[2] = ms_since(J.t_start);  // queries drawn
+    // ---- FriProver::decommit: plan the openings of every blob, one gather launch for all ----
     GatherPlan g;
-    // Proof.evaluations (src/proof.rs:62-66)
-    for (uint32_t q : queries)
-        for (int c = 0; c < 4; c++) g.word_idx.push_back(first.o_vals / 4 + (size_t)c * N + q);
     struct LayerCounts {
         size_t n_witness, n_hashes;
     };
-    std::vector<LayerCounts> counts(1 + n_inner);
-    {
-        std::vector<uint32_t> pos = plan_witness(queries, first, g, counts[0].n_witness);
-        counts[0].n_hashes = plan_merkle_decommit(pos, first, g);
+    std::vector<std::vector<uint32_t>> all_queries(count);
+    std::vector<LayerCounts> counts((size_t)count * (1 + n_inner));
+    for (uint32_t b = 0; b < count; b++) {
+        ProveJob::Blob& bl = J.blobs[b];
+        bl.ch.mix_u64(bl.nonce);  // src/proof.rs:59
+        std::vector<uint32_t>& queries = all_queries[b] = generate_queries(bl.ch, n, cfg.n_queries);
+        const size_t boff = (size_t)b * J.bstride;  // this blob's workspace (a multiple of 256 bytes)
+        auto shifted = [&](FriLayerDev lay) {
+            lay.o_vals += boff;
+            lay.o_tree += boff;
+            return lay;
+        };
+        LayerCounts* cnt = &counts[(size_t)b * (1 + n_inner)];
+        // Proof.evaluations (src/proof.rs:62-66)
+        for (uint32_t q : queries)
+            for (int c = 0; c < 4; c++) g.word_idx.push_back((first.o_vals + boff) / 4 + (size_t)c * N + q);
+        {
+            const FriLayerDev lay = shifted(first);
+            std::vector<uint32_t> pos = plan_witness(queries, lay, g, cnt[0].n_witness);
+            cnt[0].n_hashes = plan_merkle_decommit(pos, lay, g);
+        }
+        std::vector<uint32_t> lq = fold_queries(queries, 1);
+        for (uint32_t kx = 0; kx < n_inner; kx++) {
+            const FriLayerDev lay = shifted(inner[kx]);
+            std::vector<uint32_t> pos = plan_witness(lq, lay, g, cnt[kx + 1].n_witness);
+            cnt[kx + 1].n_hashes = plan_merkle_decommit(pos, lay, g);
+            lq = fold_queries(lq, 1);
+        }
     }
-    std::vector<uint32_t> lq = fold_queries(queries, 1);
-    for (uint32_t kx = 0; kx < n_inner; kx++) {
-        std::vector<uint32_t> pos = plan_witness(lq, inner[kx], g, counts[kx + 1].n_witness);
-        counts[kx + 1].n_hashes = plan_merkle_decommit(pos, inner[kx], g);
-        lq = fold_queries(lq, 1);
-    }
+    ctx->phase_ms[2] = ms_since(J.t_start);  // queries drawn, openings planned
     if (g.word_idx.size() > J.max_words || g.hash_idx.size() > J.max_hashes) return ctx->fail(FRIEDA_ERR_INVARIANT, "internal: gather plan overflow");
     // one upload (word indices then hash indices, staged in pinned memory), one launch, one download
     const size_t nw = g.word_idx.size(), nh = g.hash_idx.size();
@@ -549,15 +679,16 @@ int prove_finish(Ctx* ctx, uint8_t out_commitment[32], ProofData& out) {
     memcpy(hidx + nw, g.hash_idx.data(), 8 * nh);
     // the index and output regions of the arena are laid out back to back (words region, then hashes region), so the
     // hash part may start right behind the words actually used
+    k::Launch L1 = ctx->launch();  // the gather works on absolute indices: a single-blob launch
     FR_HIP(ctx, hipMemcpyAsync(A + J.o_widx, hidx, 8 * (nw + nh), hipMemcpyHostToDevice, s));
-    k::gather(LN, reinterpret_cast<const uint32_t*>(A), reinterpret_cast<const uint64_t*>(A + J.o_widx), nw,
+    k::gather(L1, reinterpret_cast<const uint32_t*>(A), reinterpret_cast<const uint64_t*>(A + J.o_widx), nw,
               reinterpret_cast<uint32_t*>(A + J.o_wout), reinterpret_cast<const uint64_t*>(A + J.o_widx) + nw, nh, A + J.o_wout + wbytes);
     FR_HIP(ctx, hipMemcpyAsync(hp, A + J.o_wout, out_bytes, hipMemcpyDeviceToHost, s));
     FR_HIP(ctx, hipStreamSynchronize(s));
     FR_HIP(ctx, hipGetLastError());
     ctx->phase_ms[3] = ms_since(J.t_start);  // gather done (second and last synchronise)
 
-    // ---- assemble Proof (src/proof.rs:67-76) ----
+    // ---- assemble the Proofs (src/proof.rs:67-76) ----
     const uint32_t* wv = reinterpret_cast<const uint32_t*>(hp);
     const uint8_t* hv = hp + wbytes;
     size_t wi = 0, hi = 0;
@@ -566,27 +697,32 @@ int prove_finish(Ctx* ctx, uint8_t out_commitment[32], ProofData& out) {
         wi += 4;
         return q;
     };
-    out = ProofData{};
-    out.pcs_config = cfg;
-    out.log_size_bound = J.sh.L;
-    out.proof_of_work = nonce;
-    out.last_layer_poly = lastv;
-    out.evaluations.resize(queries.size());
-    for (auto& q : out.evaluations) q = take_qm();
-    out.inner_layers.resize(n_inner);
-    for (uint32_t li = 0; li <= n_inner; li++) {
-        LayerProof& lp = li == 0 ? out.first_layer : out.inner_layers[li - 1];
-        lp.commitment = roots[li];
-        lp.fri_witness.resize(counts[li].n_witness);
-        for (auto& q : lp.fri_witness) q = take_qm();
-        lp.hash_witness.resize(counts[li].n_hashes);
-        for (auto& h : lp.hash_witness) {
-            memcpy(h.data(), hv + 32 * hi, 32);
-            hi++;
+    outs.assign(count, ProofData{});
+    for (uint32_t b = 0; b < count; b++) {
+        ProveJob::Blob& bl = J.blobs[b];
+        ProofData& out = outs[b];
+        const LayerCounts* cnt = &counts[(size_t)b * (1 + n_inner)];
+        out.pcs_config = cfg;
+        out.log_size_bound = J.sh.L;
+        out.proof_of_work = bl.nonce;
+        out.last_layer_poly = std::move(bl.lastv);
+        out.evaluations.resize(all_queries[b].size());
+        for (auto& q : out.evaluations) q = take_qm();
+        out.inner_layers.resize(n_inner);
+        for (uint32_t li = 0; li <= n_inner; li++) {
+            LayerProof& lp = li == 0 ? out.first_layer : out.inner_layers[li - 1];
+            lp.commitment = bl.roots[li];
+            lp.fri_witness.resize(cnt[li].n_witness);
+            for (auto& q : lp.fri_witness) q = take_qm();
+            lp.hash_witness.resize(cnt[li].n_hashes);
+            for (auto& h : lp.hash_witness) {
+                memcpy(h.data(), hv + 32 * hi, 32);
+                hi++;
+            }
         }
+        memcpy(out_commitments + 32 * (size_t)b, bl.roots[0].data(), 32);
     }
-    ctx->phase_ms[4] = ms_since(J.t_start);  // proof assembled
-    memcpy(out_commitment, roots[0].data(), 32);
+    ctx->phase_ms[4] = ms_since(J.t_start);  // proofs assembled
     return FRIEDA_OK;
 }
 

@@ -121,7 +121,19 @@ struct TreeArgs {
     uint8_t* layers;          // store_all: tree storage base
     uint8_t* last_out;        // !store_all: destination of the last produced level (indexed by global node index)
     int store_all;
+    size_t bstride;           // batch: bytes between consecutive blobs' workspaces (blob = blockIdx.y); tr is an array
 };
+
+// the arguments of the blob this workgroup works on
+__device__ __forceinline__ void tree_args_of_blob(TreeArgs& a) {
+    const size_t off = (size_t)blockIdx.y * a.bstride;
+    a.cols = reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(a.cols) + off);
+    a.children = a.children + off;
+    a.out_vals = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(a.out_vals) + off);
+    a.layers = a.layers + off;
+    a.last_out = a.last_out + off;
+    a.tr = a.tr + blockIdx.y;
+}
 
 namespace {
 
@@ -129,6 +141,7 @@ template <int MODE, uint32_t UNITS>
 __global__ __launch_bounds__(T5_THREADS) void tree5_kernel(TreeArgs a) {
     __shared__ __attribute__((aligned(16))) uint32_t RA[8 * (UNITS + 4)];
     __shared__ __attribute__((aligned(16))) uint32_t RB[8 * (UNITS / 2 + 4)];
+    tree_args_of_blob(a);
     const uint32_t t = threadIdx.x;
     const size_t total_a = (size_t)1 << a.level_a;
     const size_t wg_base = (size_t)blockIdx.x * UNITS;
@@ -195,6 +208,7 @@ template <int MODE>
 __global__ __launch_bounds__(T5_THREADS) void tree5r_kernel(TreeArgs a) {
     __shared__ __attribute__((aligned(16))) uint32_t RC[8 * (256 + 4)];
     __shared__ __attribute__((aligned(16))) uint32_t RD[8 * (128 + 4)];
+    tree_args_of_blob(a);
     const uint32_t t = threadIdx.x;
     const size_t wg_base = (size_t)blockIdx.x * 1024;  // the launcher guarantees 2^level_a >= 1024
     const size_t g0 = wg_base + 4 * t;
@@ -503,6 +517,7 @@ constexpr uint32_t T7Q_LEVELS = 7;
 __global__ __launch_bounds__(256) void tree7q_kernel(TreeArgs a) {
     __shared__ __attribute__((aligned(16))) uint32_t QX[2 * T7Q_UNITS * QS];
     __shared__ __attribute__((aligned(16))) uint32_t QY[T7Q_UNITS * QS];
+    tree_args_of_blob(a);
     const uint32_t t = threadIdx.x, q = t & 3;
     QuadOffsets qo;
     quad_offsets_init(qo, q);
@@ -543,6 +558,7 @@ struct TopArgs {
     uint32_t tree_log;
     uint8_t* root_out;  // non-null: also store the root here
     DevTranscript* tr;  // non-null: mix the root and draw the next alpha
+    size_t bstride;     // batch: bytes between blobs' workspaces (blob = blockIdx.y); tr is an array
 };
 
 __global__ __launch_bounds__(WG1_THREADS) void top_kernel(TopArgs a) {
@@ -551,6 +567,13 @@ __global__ __launch_bounds__(WG1_THREADS) void top_kernel(TopArgs a) {
     __shared__ __attribute__((aligned(16))) uint32_t QA[QA_WORDS];
     __shared__ __attribute__((aligned(16))) uint32_t QB[QB_WORDS];
     __shared__ uint32_t MB[2 * QS];
+    {
+        const size_t off = (size_t)blockIdx.y * a.bstride;
+        a.in += off;
+        if (a.layers) a.layers += off;
+        if (a.root_out) a.root_out += off;
+        if (a.tr) a.tr += blockIdx.y;
+    }
     const uint32_t t = threadIdx.x, q = t & 3;
     QuadOffsets qo;
     quad_offsets_init(qo, q);
@@ -614,6 +637,7 @@ struct TailArgs {
     uint32_t* vals[TAIL_MAX_LAYERS];
     uint8_t* trees[TAIL_MAX_LAYERS];
     DevTranscript* tr;
+    size_t bstride;  // batch: bytes between blobs' workspaces (blob = blockIdx.y); tr is an array
 };
 
 __global__ __launch_bounds__(WG1_THREADS) void tail_kernel(TailArgs a) {
@@ -625,12 +649,13 @@ __global__ __launch_bounds__(WG1_THREADS) void tail_kernel(TailArgs a) {
     __shared__ uint32_t s_alpha[4];
     uint32_t* const MSG = S0 + 4 * TAIL_CAP + 8;  // the upper half of S0 is free once the last layer is reached
     const uint32_t t = threadIdx.x, q = t & 3;
-    DevTranscript* tr = a.tr;
+    const size_t boff = (size_t)blockIdx.y * a.bstride;  // this workgroup's blob
+    DevTranscript* tr = a.tr + blockIdx.y;
     QuadOffsets qo;
     quad_offsets_init(qo, q);
     WgRegions R{S0, S1, QA, QB};
 
-    const uint32_t* src = a.src;
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(a.src) + boff);
     size_t src_stride = a.src_stride;
     uint32_t src_log = a.src_log;
     bool circle = a.src_is_circle != 0;
@@ -643,7 +668,7 @@ __global__ __launch_bounds__(WG1_THREADS) void tail_kernel(TailArgs a) {
         const QM31Mat alpha = qm_matrix({s_alpha[0], s_alpha[1], s_alpha[2], s_alpha[3]});
         // line layer of log size src_log sits on twiddle level n - 1 - src_log
         const uint32_t* itw_level = circle ? a.itw : a.itw + tw_level_offset_dev(a.n, a.n - 1 - src_log);
-        uint32_t* dstv = a.vals[kx];
+        uint32_t* dstv = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(a.vals[kx]) + boff);
         for (uint32_t j = t; j < cnt; j += WG1_THREADS) {
             uint32_t it = circle ? inv_circle_twiddle(a.itw, a.n, j, a.inv_init_y) : itw_level[j];
             QM31 r = fold_pair(src, src_stride, j, it, alpha);
@@ -654,7 +679,7 @@ __global__ __launch_bounds__(WG1_THREADS) void tail_kernel(TailArgs a) {
             if (!is_last) {
                 uint32_t h[8];
                 leaf_hash(r.a, r.b, r.c, r.d, h);
-                store_hash(a.trees[kx], j, h);  // leaf layer sits at offset 0
+                store_hash(a.trees[kx] + boff, j, h);  // leaf layer sits at offset 0
                 if (cnt >= 1024)
                     lds_put(S0, cnt + 4, j, h);
                 else
@@ -669,7 +694,7 @@ __global__ __launch_bounds__(WG1_THREADS) void tail_kernel(TailArgs a) {
         }
         __syncthreads();
         if (is_last) break;
-        const uint32_t* root_lds = wg_reduce(R, S0, S1, QA, QB, m_new, a.trees[kx], m_new, qo);
+        const uint32_t* root_lds = wg_reduce(R, S0, S1, QA, QB, m_new, a.trees[kx] + boff, m_new, qo);
         if (t < 4) channel_after_root_quad(tr, root_lds, MB, qo);
         __syncthreads();
         src = dstv;
@@ -747,35 +772,41 @@ __global__ __launch_bounds__(WG1_THREADS) void tail_kernel(TailArgs a) {
 }
 
 struct GrindArgs {
-    DevTranscript* tr;
+    DevTranscript* tr;  // array over the blobs of a batch (blob = blockIdx.y)
     uint32_t pow_bits;
     unsigned long long base, count;
 };
 
+// Workgroup w of a blob scans the nonces base + (i * gridDim.x + w) * 256 + lane, i = 0, 1, ...: round i of the whole grid
+// covers one contiguous window, in increasing order.  A lane stops as soon as a qualifying nonce below its own is known
+// (nothing it can find lowers the minimum) or its nonce passes base + count, so every wave leaves after a bounded number of
+// rounds and the scan ends within one round of the first hit.  The result is the MINIMUM qualifying nonce of the range, as in
+// the reference's sequential search.
 __global__ __launch_bounds__(256) void grind_dev_kernel(GrindArgs a) {
-    unsigned long long t = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
-    if (t >= a.count) return;
-    unsigned long long nonce = a.base + t;
-    // a smaller qualifying nonce is already known: nothing this lane finds can lower the minimum (workgroups are
-    // dispatched roughly in index order, so the scan stops soon after the first hit instead of finishing the chunk)
-    if (__hip_atomic_load(&a.tr->nonce, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < nonce) return;
-    uint32_t m[16] = {(uint32_t)nonce, (uint32_t)(nonce >> 32), 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    uint32_t h[8], r[8];
+    DevTranscript* tr = a.tr + blockIdx.y;
+    uint32_t h[8];
 #pragma unroll
-    for (int i = 0; i < 8; i++) h[i] = a.tr->ch.digest[i];
-    b2_compress(h, m, 0, 0, 0, 0, r);
-    uint32_t tz;
-    if (r[0])
-        tz = __ffs(r[0]) - 1;
-    else if (r[1])
-        tz = 32 + __ffs(r[1]) - 1;
-    else if (r[2])
-        tz = 64 + __ffs(r[2]) - 1;
-    else if (r[3])
-        tz = 96 + __ffs(r[3]) - 1;
-    else
-        tz = 128;
-    if (tz >= a.pow_bits) atomicMin(&a.tr->nonce, nonce);
+    for (int i = 0; i < 8; i++) h[i] = tr->ch.digest[i];
+    const unsigned long long step = (unsigned long long)gridDim.x * 256;
+    for (unsigned long long off = (unsigned long long)blockIdx.x * 256 + threadIdx.x; off < a.count; off += step) {
+        const unsigned long long nonce = a.base + off;
+        if (__hip_atomic_load(&tr->nonce, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < nonce) return;
+        const uint32_t m[16] = {(uint32_t)nonce, (uint32_t)(nonce >> 32), 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        uint32_t r[8];
+        b2_compress(h, m, 0, 0, 0, 0, r);
+        uint32_t tz;
+        if (r[0])
+            tz = __ffs(r[0]) - 1;
+        else if (r[1])
+            tz = 32 + __ffs(r[1]) - 1;
+        else if (r[2])
+            tz = 64 + __ffs(r[2]) - 1;
+        else if (r[3])
+            tz = 96 + __ffs(r[3]) - 1;
+        else
+            tz = 128;
+        if (tz >= a.pow_bits) atomicMin(&tr->nonce, nonce);
+    }
 }
 
 // Launches with few level-A nodes cannot fill the chip and are latency-bound: they use 256-node workgroups (one hash per
@@ -791,7 +822,7 @@ void launch_tree5(const Launch& L, int mode, const TreeArgs& a, const char* name
                              (a.col_stride * 4) | (a.out_stride * 4)) & 15) == 0;
     const bool small = tree5_units_log(a.level_a) == 8 || !aligned16;
     const uint32_t units = small ? 256u : T5_UNITS;
-    const unsigned grid = (unsigned)((total + units - 1) / units);
+    const dim3 grid((unsigned)((total + units - 1) / units), L.batch);
     Scope scope(L, name, alg_bytes);
     if (small) {
         switch (mode) {
@@ -837,6 +868,7 @@ void build_tree(const Launch& L, int mode, TreeArgs a, uint32_t m, uint8_t* laye
     a.tree_log = m;
     a.layers = layers;
     a.store_all = layers != nullptr;
+    a.bstride = L.bstride;
     uint8_t* s0 = scratch;
     uint8_t* s1 = scratch ? scratch + ((size_t)32 << (m > 4 ? m - 4 : 0)) : nullptr;
     a.last_out = s0;
@@ -860,7 +892,7 @@ void build_tree(const Launch& L, int mode, TreeArgs a, uint32_t m, uint8_t* laye
             const uint32_t in_wg = b.level_a < 6 ? b.level_a : 6;
             l2 = in_wg + 1 < T7Q_LEVELS ? in_wg + 1 : T7Q_LEVELS;
             Scope scope(L, "tree7q_node", node_levels_bytes(cur - 1, l2));
-            const unsigned grid = (unsigned)((((size_t)1 << b.level_a) + T7Q_UNITS - 1) / T7Q_UNITS);
+            const dim3 grid((unsigned)((((size_t)1 << b.level_a) + T7Q_UNITS - 1) / T7Q_UNITS), L.batch);
             tree7q_kernel<<<grid, 256, 0, L.stream>>>(b);
         } else {
             l2 = tree5_levels(cur - 1);
@@ -876,9 +908,10 @@ void build_tree(const Launch& L, int mode, TreeArgs a, uint32_t m, uint8_t* laye
     tp.tree_log = m;
     tp.root_out = root_out;
     tp.tr = tr;
+    tp.bstride = L.bstride;
     {
         Scope scope(L, "tree_top", node_levels_bytes(cur > 0 ? cur - 1 : 0, cur));
-        top_kernel<<<1, WG1_THREADS, 0, L.stream>>>(tp);
+        top_kernel<<<dim3(1, L.batch), WG1_THREADS, 0, L.stream>>>(tp);
     }
 }
 
@@ -946,16 +979,23 @@ void fri_tail(const Launch& L, const uint32_t* src, size_t src_stride, uint32_t 
         a.trees[i] = trees[i];
     }
     a.tr = tr;
+    a.bstride = L.bstride;
     double bytes = 0;
     for (uint32_t i = 0; i < n_layers; i++) bytes += 168.0 * (double)((size_t)1 << (src_log - 1 - i));
     Scope scope(L, "fri_tail", bytes);
-    tail_kernel<<<1, WG1_THREADS, 0, L.stream>>>(a);
+    tail_kernel<<<dim3(1, L.batch), WG1_THREADS, 0, L.stream>>>(a);
 }
 
 void grind_dev(const Launch& L, DevTranscript* tr, uint32_t pow_bits, uint64_t base, uint64_t count) {
     GrindArgs a{tr, pow_bits, base, count};
     Scope scope(L, "grind", 0.0);
-    grind_dev_kernel<<<(unsigned)((count + 255) / 256), 256, 0, L.stream>>>(a);
+    // 2048 workgroups (8 per CU) share the chip between the blobs of the batch; at least 16 per blob
+    unsigned wgs = 2048u / L.batch;
+    if (wgs < 16) wgs = 16;
+    const unsigned long long need = (count + 255) / 256;
+    if (wgs > need) wgs = (unsigned)need;
+    if (wgs == 0) return;
+    grind_dev_kernel<<<dim3(wgs, L.batch), 256, 0, L.stream>>>(a);
 }
 
 }  // namespace k

@@ -105,6 +105,23 @@ int frieda_commit_and_generate_proof_device(frieda_ctx* ctx, const void* d_data,
 int frieda_prove_begin(frieda_ctx* ctx, const uint8_t* data, size_t len, const uint64_t* seed, frieda_pcs_config cfg);
 int frieda_prove_begin_device(frieda_ctx* ctx, const void* d_data, size_t len, const uint64_t* seed, frieda_pcs_config cfg);
 int frieda_prove_finish(frieda_ctx* ctx, uint8_t out_commitment[32], frieda_proof** out);
+/* Batches of small blobs (the reference's own bench sizes, benches/commit.rs:6-10, benches/proof.rs:14-21,
+ * are 1 KiB .. 64 KiB blobs, where one proof is a chain of ~50 dependent launches on an almost idle chip).  `count` blobs of
+ * `len` bytes each, blob i at data + i * stride (stride >= len); seeds == NULL is None for all, else seeds[i] is Some for blob i.
+ * Every kernel of the path handles the whole batch in one launch, so the launch and Fiat-Shamir latency is paid once per batch;
+ * results are exactly those of `count` separate calls.  out_commitments / out_roots: count * 32 bytes (host);
+ * out_proofs: count handles, each released with frieda_proof_free.  Proof batches need the last FRI layer to have <= 2^11
+ * points (log_last_layer_degree_bound + log_blowup_factor <= 11) and the default (device) transcript policy. */
+int frieda_commit_and_generate_proof_batch(frieda_ctx* ctx, const uint8_t* data, size_t stride, size_t len, uint32_t count,
+                                           const uint64_t* seeds, frieda_pcs_config cfg, uint8_t* out_commitments,
+                                           frieda_proof** out_proofs);
+int frieda_commit_and_generate_proof_batch_device(frieda_ctx* ctx, const void* d_data, size_t stride, size_t len, uint32_t count,
+                                                  const uint64_t* seeds, frieda_pcs_config cfg, uint8_t* out_commitments,
+                                                  frieda_proof** out_proofs);
+int frieda_commit_batch(frieda_ctx* ctx, const uint8_t* data, size_t stride, size_t len, uint32_t count, uint32_t log_blowup_factor,
+                        uint8_t* out_roots);
+int frieda_commit_batch_device(frieda_ctx* ctx, const void* d_data, size_t stride, size_t len, uint32_t count,
+                               uint32_t log_blowup_factor, uint8_t* out_roots);
 /* api::generate_proof (src/lib.rs:36) */
 int frieda_generate_proof(frieda_ctx* ctx, const uint8_t* data, size_t len, const uint64_t* seed, frieda_pcs_config cfg,
                           frieda_proof** out);

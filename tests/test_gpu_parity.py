@@ -539,3 +539,83 @@ def test_encode_erase_reconstruct_round_trip(gpu_ctx, n_bytes, B):
         d_b, d_o = DevBuf.from_array(gpu_ctx, blk), DevBuf(gpu_ctx, n_bytes + 8)
         _check(gpu_ctx, L_.frieda_reconstruct_device(gpu_ctx._h, d_b.ptr, L, n, k, n_bytes, d_o.ptr))
         assert d_o.to_array(np.uint8, (n_bytes,)).tobytes() == data.tobytes(), f"block {k}"
+
+
+# ---- batches of small blobs: every kernel handles the whole batch; results = separate calls ----
+@pytest.mark.parametrize("length,count,seeded", [(1024, 1, True), (1024, 7, False), (4096, 33, True), (16384, 16, True), (65536, 5, True),
+                                                 (262144, 3, False), (58, 4, True), (16, 3, True)])
+def test_batched_proofs_equal_separate_proofs(gpu_ctx, oracle, length, count, seeded):
+    import frieda_amd
+
+    cfg = _cfg(frieda_amd, 10, 4, 0, 20)
+    blobs = [splitmix64_bytes(7000 + 13 * i + length, length).tobytes() for i in range(count)]
+    seeds = [1000 + i for i in range(count)] if seeded else None
+    got = gpu_ctx.commit_and_generate_proof_batch(blobs, seeds, cfg)
+    assert len(got) == count
+    for i, (root, proof) in enumerate(got):
+        er, ep = gpu_ctx.commit_and_generate_proof(blobs[i], seeds[i] if seeded else None, cfg)
+        assert root == er and proof.serialize() == ep.serialize()
+        if length >= 58:
+            assert frieda_amd.verify(proof, seeds[i] if seeded else None)
+        else:  # a 2^5 domain: the restated verifier hits one of stwo's assertions (the oracle does the same)
+            with pytest.raises(frieda_amd.FriedaPanic):
+                frieda_amd.verify(proof, seeds[i])
+            with pytest.raises(RuntimeError):
+                oracle.verify(oracle.commit_and_generate_proof(blobs[i], seeds[i], oracle.make_config(10, 4, 0, 20))[1], seeds[i])
+    # the oracle on the first and last blob
+    for i in {0, count - 1}:
+        o_root, o_proof = oracle.commit_and_generate_proof(blobs[i], seeds[i] if seeded else None, oracle.make_config(10, 4, 0, 20))
+        assert got[i][0] == o_root and got[i][1].serialize() == o_proof.serialize()
+    roots = gpu_ctx.commit_batch(blobs, 4)
+    assert roots == [g[0] for g in got]
+
+
+def test_batched_proofs_other_configs_and_device_input(gpu_ctx, oracle):
+    import torch
+
+    import frieda_amd
+
+    # last-layer degree bound 2, blowup 2, fewer queries; strided device-resident input
+    cfg = _cfg(frieda_amd, 6, 2, 2, 9)
+    length, stride, count = 3000, 3072, 6
+    host = np.zeros(stride * count, dtype=np.uint8)
+    blobs = []
+    for i in range(count):
+        b = splitmix64_bytes(8100 + i, length)
+        host[i * stride : i * stride + length] = b
+        host[i * stride + length : (i + 1) * stride] = 0xA5  # padding between blobs must be ignored
+        blobs.append(b.tobytes())
+    dev = torch.from_numpy(host).cuda()
+    torch.cuda.synchronize()
+    seeds = [5 * i + 1 for i in range(count)]
+    got = gpu_ctx.commit_and_generate_proof_batch_device(dev.data_ptr(), stride, length, count, seeds, cfg)
+    for i, (root, proof) in enumerate(got):
+        o_root, o_proof = oracle.commit_and_generate_proof(blobs[i], seeds[i], oracle.make_config(6, 2, 2, 9))
+        assert root == o_root and proof.serialize() == o_proof.serialize()
+    assert gpu_ctx.commit_batch_device(dev.data_ptr(), stride, length, count, 2) == [oracle.commit(b, 2) for b in blobs]
+    # a batch whose grind needs more than the first chunk for some blob: 26 bits of work
+    cfg26 = _cfg(frieda_amd, 24, 4, 0, 4)
+    got = gpu_ctx.commit_and_generate_proof_batch(blobs[:3], None, cfg26)
+    for b, (root, proof) in zip(blobs[:3], got):
+        er, ep = gpu_ctx.commit_and_generate_proof(b, None, cfg26)
+        assert root == er and proof.serialize() == ep.serialize() and frieda_amd.verify(proof, None)
+
+
+def test_batch_argument_errors(gpu_ctx):
+    import frieda_amd
+
+    cfg = _cfg(frieda_amd, 4, 4, 0, 5)
+    with pytest.raises(ValueError):
+        gpu_ctx.commit_and_generate_proof_batch([b"abc", b"abcd"], None, cfg)
+    assert gpu_ctx.commit_and_generate_proof_batch([], None, cfg) == []
+    buf = (C.c_uint8 * 64)()
+    with pytest.raises(frieda_amd.FriedaError):  # stride smaller than the blob length
+        gpu_ctx._prove_batch(gpu_ctx._L.frieda_commit_and_generate_proof_batch, buf, 16, 32, 2, None, cfg)
+    # last layer of 2^12 points: the single-proof API falls back to the host channel, a batch is refused
+    big_last = _cfg(frieda_amd, 4, 4, 8, 5)
+    blob = splitmix64_bytes(1, 65536).tobytes()
+    gpu_ctx.commit_and_generate_proof(blob, None, big_last)
+    with pytest.raises(frieda_amd.FriedaError):
+        gpu_ctx.commit_and_generate_proof_batch([blob, blob], None, big_last)
+    # the context is usable afterwards
+    assert len(gpu_ctx.commit_and_generate_proof_batch([blob, blob], None, cfg)) == 2
