@@ -57,6 +57,9 @@ extern "C" {
     pub fn frieda_prove_finish(ctx: *mut frieda_ctx, out_commitment: *mut u8, out: *mut *mut frieda_proof) -> c_int;
     pub fn frieda_commit_and_generate_proof_batch(ctx: *mut frieda_ctx, data: *const u8, stride: usize, len: usize, count: u32, seeds: *const u64, cfg: frieda_pcs_config, out_commitments: *mut u8, out_proofs: *mut *mut frieda_proof) -> c_int;
     pub fn frieda_commit_and_generate_proof_batch_device(ctx: *mut frieda_ctx, d_data: *const c_void, stride: usize, len: usize, count: u32, seeds: *const u64, cfg: frieda_pcs_config, out_commitments: *mut u8, out_proofs: *mut *mut frieda_proof) -> c_int;
+    pub fn frieda_prove_batch_begin(ctx: *mut frieda_ctx, data: *const u8, stride: usize, len: usize, count: u32, seeds: *const u64, cfg: frieda_pcs_config) -> c_int;
+    pub fn frieda_prove_batch_begin_device(ctx: *mut frieda_ctx, d_data: *const c_void, stride: usize, len: usize, count: u32, seeds: *const u64, cfg: frieda_pcs_config) -> c_int;
+    pub fn frieda_prove_batch_finish(ctx: *mut frieda_ctx, count: u32, out_commitments: *mut u8, out_proofs: *mut *mut frieda_proof) -> c_int;
     pub fn frieda_commit_batch(ctx: *mut frieda_ctx, data: *const u8, stride: usize, len: usize, count: u32, log_blowup_factor: u32, out_roots: *mut u8) -> c_int;
     pub fn frieda_commit_batch_device(ctx: *mut frieda_ctx, d_data: *const c_void, stride: usize, len: usize, count: u32, log_blowup_factor: u32, out_roots: *mut u8) -> c_int;
     pub fn frieda_generate_proof(ctx: *mut frieda_ctx, data: *const u8, len: usize, seed: *const u64, cfg: frieda_pcs_config, out: *mut *mut frieda_proof) -> c_int;

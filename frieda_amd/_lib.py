@@ -78,6 +78,9 @@ def lib():
         "frieda_prove_finish": (C.c_int, [vp, vp, pp]),
         "frieda_commit_and_generate_proof_batch": (C.c_int, [vp, vp, sz, sz, u32, u64p, PcsConfigC, vp, pp]),
         "frieda_commit_and_generate_proof_batch_device": (C.c_int, [vp, vp, sz, sz, u32, u64p, PcsConfigC, vp, pp]),
+        "frieda_prove_batch_begin": (C.c_int, [vp, vp, sz, sz, u32, u64p, PcsConfigC]),
+        "frieda_prove_batch_begin_device": (C.c_int, [vp, vp, sz, sz, u32, u64p, PcsConfigC]),
+        "frieda_prove_batch_finish": (C.c_int, [vp, u32, vp, pp]),
         "frieda_commit_batch": (C.c_int, [vp, vp, sz, sz, u32, u32, vp]),
         "frieda_commit_batch_device": (C.c_int, [vp, vp, sz, sz, u32, u32, vp]),
         "frieda_verify": (C.c_int, [vp, u64p, C.POINTER(C.c_int)]),

@@ -185,6 +185,17 @@ class Context:
     def commit_and_generate_proof_batch_device(self, d_ptr, stride, length, count, seeds, pcs_config):
         return self._prove_batch(self._L.frieda_commit_and_generate_proof_batch_device, d_ptr, stride, length, count, seeds, pcs_config)
 
+    def prove_batch_begin_device(self, d_ptr, stride, length, count, seeds, pcs_config):
+        """Enqueue the commit phase of a batch; the blobs must stay valid until prove_batch_finish(count) returns."""
+        _check(self._L.frieda_prove_batch_begin_device(self._h, d_ptr, stride, length, count, self._seeds_array(seeds, count), pcs_config._c()), self._h)
+
+    def prove_batch_finish(self, count):
+        roots = (C.c_uint8 * (32 * count))()
+        outs = (C.c_void_p * count)()
+        _check(self._L.frieda_prove_batch_finish(self._h, count, roots, outs), self._h)
+        rb = bytes(roots)
+        return [(rb[32 * i : 32 * i + 32], Proof(C.c_void_p(outs[i]))) for i in range(count)]
+
     def _prove_batch(self, fn, data, stride, length, count, seeds, pcs_config):
         roots = (C.c_uint8 * (32 * count))()
         outs = (C.c_void_p * count)()

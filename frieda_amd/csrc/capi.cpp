@@ -202,15 +202,20 @@ int frieda_prove_finish(frieda_ctx* ctx, uint8_t out_commitment[32], frieda_proo
 
 // ---- batches ----
 namespace {
-int batch_prove(frieda_ctx* ctx, const uint8_t* data, size_t stride, size_t len, uint32_t count, bool on_device, const uint64_t* seeds,
-                frieda_pcs_config cfg, uint8_t* out_commitments, frieda_proof** out_proofs) {
-    if (!ctx || !out_proofs || !out_commitments || (!data && len) || count == 0) return FRIEDA_ERR_ARG;
+int batch_begin(frieda_ctx* ctx, const uint8_t* data, size_t stride, size_t len, uint32_t count, bool on_device, const uint64_t* seeds,
+                frieda_pcs_config cfg) {
+    if (!ctx || (!data && len) || count == 0) return FRIEDA_ERR_ARG;
+    FR_GUARD_BEGIN
+    return prove_begin_batch(&ctx->c, data, stride, len, count, on_device, seeds, cfg);
+    FR_GUARD_END(ctx)
+}
+int batch_finish(frieda_ctx* ctx, uint32_t count, uint8_t* out_commitments, frieda_proof** out_proofs) {
+    if (!ctx || !out_proofs || !out_commitments || count == 0) return FRIEDA_ERR_ARG;
     for (uint32_t i = 0; i < count; i++) out_proofs[i] = nullptr;
     FR_GUARD_BEGIN
-    int rc = prove_begin_batch(&ctx->c, data, stride, len, count, on_device, seeds, cfg);
-    if (rc != FRIEDA_OK) return rc;
+    if (ctx->c.job && job_count(&ctx->c) != count) return ctx->c.fail(FRIEDA_ERR_ARG, "count differs from the batch in flight");
     std::vector<ProofData> outs;
-    rc = prove_finish_batch(&ctx->c, out_commitments, outs);
+    int rc = prove_finish_batch(&ctx->c, out_commitments, outs);
     if (rc != FRIEDA_OK) return rc;
     for (uint32_t i = 0; i < count; i++) {
         frieda_proof* p = new (std::nothrow) frieda_proof();
@@ -229,16 +234,32 @@ int batch_prove(frieda_ctx* ctx, const uint8_t* data, size_t stride, size_t len,
 }
 }  // namespace
 
+int frieda_prove_batch_begin(frieda_ctx* ctx, const uint8_t* data, size_t stride, size_t len, uint32_t count, const uint64_t* seeds,
+                             frieda_pcs_config cfg) {
+    return batch_begin(ctx, data, stride, len, count, false, seeds, cfg);
+}
+int frieda_prove_batch_begin_device(frieda_ctx* ctx, const void* d_data, size_t stride, size_t len, uint32_t count, const uint64_t* seeds,
+                                    frieda_pcs_config cfg) {
+    return batch_begin(ctx, static_cast<const uint8_t*>(d_data), stride, len, count, true, seeds, cfg);
+}
+int frieda_prove_batch_finish(frieda_ctx* ctx, uint32_t count, uint8_t* out_commitments, frieda_proof** out_proofs) {
+    return batch_finish(ctx, count, out_commitments, out_proofs);
+}
+
 int frieda_commit_and_generate_proof_batch(frieda_ctx* ctx, const uint8_t* data, size_t stride, size_t len, uint32_t count,
                                            const uint64_t* seeds, frieda_pcs_config cfg, uint8_t* out_commitments,
                                            frieda_proof** out_proofs) {
-    return batch_prove(ctx, data, stride, len, count, false, seeds, cfg, out_commitments, out_proofs);
+    if (!out_proofs || !out_commitments) return FRIEDA_ERR_ARG;
+    int rc = batch_begin(ctx, data, stride, len, count, false, seeds, cfg);
+    return rc != FRIEDA_OK ? rc : batch_finish(ctx, count, out_commitments, out_proofs);
 }
 
 int frieda_commit_and_generate_proof_batch_device(frieda_ctx* ctx, const void* d_data, size_t stride, size_t len, uint32_t count,
                                                   const uint64_t* seeds, frieda_pcs_config cfg, uint8_t* out_commitments,
                                                   frieda_proof** out_proofs) {
-    return batch_prove(ctx, static_cast<const uint8_t*>(d_data), stride, len, count, true, seeds, cfg, out_commitments, out_proofs);
+    if (!out_proofs || !out_commitments) return FRIEDA_ERR_ARG;
+    int rc = batch_begin(ctx, static_cast<const uint8_t*>(d_data), stride, len, count, true, seeds, cfg);
+    return rc != FRIEDA_OK ? rc : batch_finish(ctx, count, out_commitments, out_proofs);
 }
 
 int frieda_commit_batch(frieda_ctx* ctx, const uint8_t* data, size_t stride, size_t len, uint32_t count, uint32_t log_blowup_factor,

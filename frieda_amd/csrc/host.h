@@ -138,6 +138,7 @@ int prove_finish(Ctx* ctx, uint8_t out_commitment[32], ProofData& out);
 int prove_begin_batch(Ctx* ctx, const uint8_t* data, size_t data_stride, size_t len, uint32_t count, bool data_on_device,
                       const uint64_t* seeds, frieda_pcs_config cfg);
 int prove_finish_batch(Ctx* ctx, uint8_t* out_commitments, std::vector<ProofData>& outs);
+uint32_t job_count(const Ctx* ctx);  // blobs of the job in flight (0: none)
 int commit_batch(Ctx* ctx, const uint8_t* data, size_t data_stride, size_t len, uint32_t count, bool data_on_device, uint32_t log_blowup,
                  uint8_t* out_roots);
 // returns FRIEDA_OK with *ok set, or FRIEDA_ERR_INVARIANT where the reference panics

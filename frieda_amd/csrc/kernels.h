@@ -113,7 +113,8 @@ void fri_tail(const Launch& L, const uint32_t* src, size_t src_stride, uint32_t 
               const uint32_t* d_itw, DomainScalars ds, uint32_t last_log, uint32_t last, uint32_t n_layers, uint32_t* const* vals,
               uint8_t* const* trees, DevTranscript* tr);
 // proof-of-work scan keyed by tr->ch.digest; atomicMin into tr->nonce
-void grind_dev(const Launch& L, DevTranscript* tr, uint32_t pow_bits, uint64_t base, uint64_t count);
+// d_next: L.batch words of scratch (the per-blob window counters; zeroed here)
+void grind_dev(const Launch& L, DevTranscript* tr, uint32_t* d_next, uint32_t pow_bits, uint64_t base, uint64_t count);
 
 // ---- fri.hip ----
 struct Alpha {

@@ -408,7 +408,9 @@ void circle_evaluate(const Launch& L_, const uint32_t* d_coef, size_t coef_strid
         uint32_t t = (rest + (n_mid - p) - 1) / (n_mid - p);
         a.i_hi = i_hi;
         a.i_lo = i_hi + 1 - t;
-        a.log_w = MID_LOG_W;  // i_lo >= last_t = 12 >= log_w whenever a strided pass exists
+        // runs of 2^log_w consecutive words: 64 bytes for a full pass of 8 layers; a pass of fewer layers takes longer runs so
+        // that its tile still has 4096 words (i_lo >= last_t = 12 >= log_w whenever a strided pass exists)
+        a.log_w = t >= mid_max ? MID_LOG_W : TILE_LOG - t;
         launch_pass(t, "ntt_pass_mid");
         a.in = d_out;
         a.in_stride = out_stride;

@@ -293,7 +293,7 @@ struct ProveJob {
     size_t N = 0;
     FriLayerDev first{};
     std::vector<FriLayerDev> inner;
-    size_t o_lastv = 0, o_nonce = 0, o_tr = 0, o_widx = 0, o_hidx = 0, o_wout = 0, o_hout = 0;
+    size_t o_lastv = 0, o_nonce = 0, o_tr = 0, o_gnext = 0, o_widx = 0, o_hidx = 0, o_wout = 0, o_hout = 0;
     size_t max_words = 0, max_hashes = 0, tr_host_pitch = 0;
     bool dev_channel = false;
     // a batch of `count` blobs of one shape: blob b's workspace is blob 0's shifted by b * bstride bytes; the transcripts
@@ -381,6 +381,7 @@ int prove_begin_batch(Ctx* ctx, const uint8_t* data, size_t data_stride, size_t 
     const size_t bstride = J.bstride = plan.off;  // a multiple of 256
     plan.off = bstride * count;
     const size_t o_tr = J.o_tr = plan.take(sizeof(DevTranscript) * count);
+    J.o_gnext = plan.take(sizeof(uint32_t) * count);  // grind window counters
     // decommit gather: per layer <= 2 positions per query; hashes <= 2 * queries * log per layer
     J.max_words = (size_t)cfg.n_queries * 4 * (1 + (n_inner + 1)) * count;
     J.max_hashes = (size_t)cfg.n_queries * 2 * (size_t)(n + 1) * (n_inner + 1) * count;
@@ -491,8 +492,9 @@ int prove_begin_batch(Ctx* ctx, const uint8_t* data, size_t data_stride, size_t 
                     d_tr);
         // grind (src/proof.rs:58), keyed by the digest now sitting in the device transcript: first chunk + transcript download
         J.grind_base = 0;
-        J.grind_chunk = (uint64_t)1 << 22;
-        k::grind_dev(LN, d_tr, cfg.pow_bits, J.grind_base, J.grind_chunk);
+        // first range: 16x the expected search (a miss has probability e^-16; workgroups without work leave at once)
+        J.grind_chunk = (uint64_t)1 << std::max<uint32_t>(22, std::min<uint32_t>(cfg.pow_bits, 36) + 4);
+        k::grind_dev(LN, d_tr, reinterpret_cast<uint32_t*>(A + J.o_gnext), cfg.pow_bits, J.grind_base, J.grind_chunk);
         rc = download_transcripts(ctx, J);
         if (rc) return rc;
         FR_HIP(ctx, hipGetLastError());
@@ -582,6 +584,8 @@ int prove_finish(Ctx* ctx, uint8_t out_commitment[32], ProofData& out) {
     return FRIEDA_OK;
 }
 
+uint32_t job_count(const Ctx* ctx) { return ctx->job ? ctx->job->count : 0; }
+
 int prove_finish_batch(Ctx* ctx, uint8_t* out_commitments, std::vector<ProofData>& outs) {
     if (!ctx->job) return ctx->fail(FRIEDA_ERR_ARG, "no proof in flight on this context");
     std::unique_ptr<ProveJob, ProveJobDeleter> jp = std::move(ctx->job);  // released on every exit path
@@ -613,7 +617,7 @@ int prove_finish_batch(Ctx* ctx, uint8_t* out_commitments, std::vector<ProofData
             // next range for the blobs still searching (the others leave at once: their minimum is below every new nonce)
             J.grind_base += J.grind_chunk;
             if (J.grind_chunk < ((uint64_t)1 << 28)) J.grind_chunk <<= 1;
-            k::grind_dev(LN, d_tr, cfg.pow_bits, J.grind_base, J.grind_chunk);
+            k::grind_dev(LN, d_tr, reinterpret_cast<uint32_t*>(A + J.o_gnext), cfg.pow_bits, J.grind_base, J.grind_chunk);
             int rc = download_transcripts(ctx, J);
             if (rc) return rc;
         }

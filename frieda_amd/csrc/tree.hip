@@ -771,41 +771,95 @@ __global__ __launch_bounds__(WG1_THREADS) void tail_kernel(TailArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// grind: proof of work over the digests in the device transcripts, one work queue per blob
+// ------------------------------------------------------------------------------------------------
+// The nonces base .. base + n_windows * GRIND_WINDOW of every blob are cut into windows that workgroups claim in increasing
+// order from the blob's counter (`next`, zeroed before the launch).  A workgroup walks round-robin over the blobs that are
+// still searching (wave 0 tests 64 blobs per step), claims the next window of one, scans it (one compression per nonce,
+// atomicMin on a hit) and moves on; it leaves once no blob has work.  Windows are claimed in order and always scanned to the
+// point where a smaller hit is known, so tr->nonce ends as the MINIMUM qualifying nonce of the range, as in the reference's
+// sequential search; blobs that finish early release their workgroups to the others (in a batch the slowest blob needs
+// several times the mean).  Every loop is bounded: a claim consumes one of n_windows * batch windows, a fruitless walk over
+// all blobs ends the workgroup.
+constexpr uint32_t GRIND_WINDOW = 1024;  // nonces per claim: 4 per lane
+
 struct GrindArgs {
-    DevTranscript* tr;  // array over the blobs of a batch (blob = blockIdx.y)
-    uint32_t pow_bits;
-    unsigned long long base, count;
+    DevTranscript* tr;  // array over the blobs of the batch
+    uint32_t* next;     // [batch] next unclaimed window of each blob
+    uint32_t pow_bits, batch;
+    unsigned long long base;
+    uint32_t n_windows;  // per blob
 };
 
-// Workgroup w of a blob scans the nonces base + (i * gridDim.x + w) * 256 + lane, i = 0, 1, ...: round i of the whole grid
-// covers one contiguous window, in increasing order.  A lane stops as soon as a qualifying nonce below its own is known
-// (nothing it can find lowers the minimum) or its nonce passes base + count, so every wave leaves after a bounded number of
-// rounds and the scan ends within one round of the first hit.  The result is the MINIMUM qualifying nonce of the range, as in
-// the reference's sequential search.
 __global__ __launch_bounds__(256) void grind_dev_kernel(GrindArgs a) {
-    DevTranscript* tr = a.tr + blockIdx.y;
-    uint32_t h[8];
+    __shared__ uint32_t s_claim[2];  // blob, window (blob == ~0: nothing left)
+    const uint32_t t = threadIdx.x;
+    uint32_t b = blockIdx.x % a.batch;  // wave 0's walking position
+    for (;;) {
+        if (t < 64) {
+            uint32_t got_b = ~0u, got_w = 0, idle = 0;
+            while (idle < a.batch) {
+                uint32_t bb = b + t;
+                if (bb >= a.batch) bb -= a.batch;
+                const bool cand = t < a.batch && __hip_atomic_load(&a.tr[bb].nonce, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ~0ull &&
+                                  __hip_atomic_load(&a.next[bb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < a.n_windows;
+                const unsigned long long mask = __ballot(cand);
+                if (mask == 0) {
+                    const uint32_t adv = a.batch < 64 ? a.batch : 64;
+                    b += adv;
+                    if (b >= a.batch) b -= a.batch;
+                    idle += adv;
+                    continue;
+                }
+                const uint32_t l = (uint32_t)__ffsll((long long)mask) - 1;
+                uint32_t tb = b + l;
+                if (tb >= a.batch) tb -= a.batch;
+                uint32_t c = 0;
+                if (t == 0) c = atomicAdd(&a.next[tb], 1u);
+                c = (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
+                b = tb + 1 == a.batch ? 0 : tb + 1;
+                if (c < a.n_windows) {
+                    got_b = tb;
+                    got_w = c;
+                    break;
+                }
+                idle += l + 1;  // lost the race for that blob's last window: keep walking
+            }
+            if (t == 0) {
+                s_claim[0] = got_b;
+                s_claim[1] = got_w;
+            }
+        }
+        __syncthreads();
+        const uint32_t cb = s_claim[0], cw = s_claim[1];
+        __syncthreads();
+        if (cb == ~0u) return;
+        DevTranscript* tr = a.tr + cb;
+        uint32_t h[8];
 #pragma unroll
-    for (int i = 0; i < 8; i++) h[i] = tr->ch.digest[i];
-    const unsigned long long step = (unsigned long long)gridDim.x * 256;
-    for (unsigned long long off = (unsigned long long)blockIdx.x * 256 + threadIdx.x; off < a.count; off += step) {
-        const unsigned long long nonce = a.base + off;
-        if (__hip_atomic_load(&tr->nonce, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < nonce) return;
-        const uint32_t m[16] = {(uint32_t)nonce, (uint32_t)(nonce >> 32), 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-        uint32_t r[8];
-        b2_compress(h, m, 0, 0, 0, 0, r);
-        uint32_t tz;
-        if (r[0])
-            tz = __ffs(r[0]) - 1;
-        else if (r[1])
-            tz = 32 + __ffs(r[1]) - 1;
-        else if (r[2])
-            tz = 64 + __ffs(r[2]) - 1;
-        else if (r[3])
-            tz = 96 + __ffs(r[3]) - 1;
-        else
-            tz = 128;
-        if (tz >= a.pow_bits) atomicMin(&tr->nonce, nonce);
+        for (int i = 0; i < 8; i++) h[i] = tr->ch.digest[i];
+        const unsigned long long first = a.base + (unsigned long long)cw * GRIND_WINDOW + t;
+        for (uint32_t i = 0; i < GRIND_WINDOW / 256; i++) {
+            const unsigned long long nonce = first + 256ull * i;
+            // a smaller qualifying nonce is already known: nothing this lane finds from here on can lower the minimum
+            if (__hip_atomic_load(&tr->nonce, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < nonce) break;
+            const uint32_t m[16] = {(uint32_t)nonce, (uint32_t)(nonce >> 32), 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+            uint32_t r[8];
+            b2_compress(h, m, 0, 0, 0, 0, r);
+            uint32_t tz;
+            if (r[0])
+                tz = __ffs(r[0]) - 1;
+            else if (r[1])
+                tz = 32 + __ffs(r[1]) - 1;
+            else if (r[2])
+                tz = 64 + __ffs(r[2]) - 1;
+            else if (r[3])
+                tz = 96 + __ffs(r[3]) - 1;
+            else
+                tz = 128;
+            if (tz >= a.pow_bits) atomicMin(&tr->nonce, nonce);
+        }
     }
 }
 
@@ -820,7 +874,12 @@ void launch_tree5(const Launch& L, int mode, const TreeArgs& a, const char* name
     // takes the 256-unit kernel, which produces the same levels
     const bool aligned16 = ((reinterpret_cast<uintptr_t>(a.cols) | reinterpret_cast<uintptr_t>(a.out_vals) | reinterpret_cast<uintptr_t>(a.itw) |
                              (a.col_stride * 4) | (a.out_stride * 4)) & 15) == 0;
-    const bool small = tree5_units_log(a.level_a) == 8 || !aligned16;
+    // a batch of small trees is as wide as one large tree: the register-subtree kernel once there are >= 2^20 level-A nodes in
+    // the launch and >= 1024 per blob (both kernels produce five levels from level_a >= 4 on)
+    uint32_t batch_log = 0;
+    while ((2u << batch_log) <= L.batch) batch_log++;
+    const bool wide = a.level_a >= 10 && a.level_a + batch_log >= T5_SMALL_LOG;
+    const bool small = !wide || !aligned16;
     const uint32_t units = small ? 256u : T5_UNITS;
     const dim3 grid((unsigned)((total + units - 1) / units), L.batch);
     Scope scope(L, name, alg_bytes);
@@ -986,16 +1045,25 @@ void fri_tail(const Launch& L, const uint32_t* src, size_t src_stride, uint32_t 
     tail_kernel<<<dim3(1, L.batch), WG1_THREADS, 0, L.stream>>>(a);
 }
 
-void grind_dev(const Launch& L, DevTranscript* tr, uint32_t pow_bits, uint64_t base, uint64_t count) {
-    GrindArgs a{tr, pow_bits, base, count};
+void grind_dev(const Launch& L, DevTranscript* tr, uint32_t* d_next, uint32_t pow_bits, uint64_t base, uint64_t count) {
+    GrindArgs a{};
+    a.tr = tr;
+    a.next = d_next;
+    a.pow_bits = pow_bits;
+    a.batch = L.batch;
+    a.base = base;
+    const uint64_t nwin = (count + GRIND_WINDOW - 1) / GRIND_WINDOW;
+    a.n_windows = nwin > 0xFFFF0000ull ? 0xFFFF0000u : (uint32_t)nwin;
+    if (a.n_windows == 0) return;
     Scope scope(L, "grind", 0.0);
-    // 2048 workgroups (8 per CU) share the chip between the blobs of the batch; at least 16 per blob
-    unsigned wgs = 2048u / L.batch;
-    if (wgs < 16) wgs = 16;
-    const unsigned long long need = (count + 255) / 256;
-    if (wgs > need) wgs = (unsigned)need;
-    if (wgs == 0) return;
-    grind_dev_kernel<<<dim3(wgs, L.batch), 256, 0, L.stream>>>(a);
+    (void)hipMemsetAsync(d_next, 0, sizeof(uint32_t) * L.batch, L.stream);
+    // workgroups in flight: the chip holds 2048 (8 per CU); a lone blob gets no more than cover about half the expected search
+    // (2^pow_bits nonces), so that the windows in flight when the first hit arrives are not mostly beyond it
+    uint64_t want = (((uint64_t)1 << (pow_bits > 40 ? 40 : pow_bits)) / 2 / GRIND_WINDOW) * L.batch;
+    if (want < 64) want = 64;
+    if (want > 2048) want = 2048;
+    if (want > (uint64_t)a.n_windows * L.batch) want = (uint64_t)a.n_windows * L.batch;
+    grind_dev_kernel<<<(unsigned)want, 256, 0, L.stream>>>(a);
 }
 
 }  // namespace k

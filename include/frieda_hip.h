@@ -118,6 +118,14 @@ int frieda_commit_and_generate_proof_batch(frieda_ctx* ctx, const uint8_t* data,
 int frieda_commit_and_generate_proof_batch_device(frieda_ctx* ctx, const void* d_data, size_t stride, size_t len, uint32_t count,
                                                   const uint64_t* seeds, frieda_pcs_config cfg, uint8_t* out_commitments,
                                                   frieda_proof** out_proofs);
+/* split form, as frieda_prove_begin / _finish: _begin enqueues the commit phase of the whole batch and returns; _finish (same
+ * count) waits, opens the queries of every blob and builds the proofs.  Two contexts alternating _begin / _finish keep the
+ * host-side planning of one batch under the device work of the next. */
+int frieda_prove_batch_begin(frieda_ctx* ctx, const uint8_t* data, size_t stride, size_t len, uint32_t count, const uint64_t* seeds,
+                             frieda_pcs_config cfg);
+int frieda_prove_batch_begin_device(frieda_ctx* ctx, const void* d_data, size_t stride, size_t len, uint32_t count,
+                                    const uint64_t* seeds, frieda_pcs_config cfg);
+int frieda_prove_batch_finish(frieda_ctx* ctx, uint32_t count, uint8_t* out_commitments, frieda_proof** out_proofs);
 int frieda_commit_batch(frieda_ctx* ctx, const uint8_t* data, size_t stride, size_t len, uint32_t count, uint32_t log_blowup_factor,
                         uint8_t* out_roots);
 int frieda_commit_batch_device(frieda_ctx* ctx, const void* d_data, size_t stride, size_t len, uint32_t count,

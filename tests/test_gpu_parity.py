@@ -619,3 +619,32 @@ def test_batch_argument_errors(gpu_ctx):
         gpu_ctx.commit_and_generate_proof_batch([blob, blob], None, big_last)
     # the context is usable afterwards
     assert len(gpu_ctx.commit_and_generate_proof_batch([blob, blob], None, cfg)) == 2
+
+
+def test_two_batches_in_flight(gpu_ctx):
+    """frieda_prove_batch_begin / _finish on two contexts: same proofs as the one-call form; count mismatch is refused."""
+    import torch
+
+    import frieda_amd
+
+    cfg = _cfg(frieda_amd, 8, 4, 0, 12)
+    length, count = 2048, 9
+    host = np.concatenate([splitmix64_bytes(9100 + i, length) for i in range(2 * count)])
+    dev = torch.from_numpy(host).cuda()
+    torch.cuda.synchronize()
+    other = frieda_amd.Context(0)
+    seeds_a, seeds_b = list(range(count)), list(range(100, 100 + count))
+    gpu_ctx.prove_batch_begin_device(dev.data_ptr(), length, length, count, seeds_a, cfg)
+    other.prove_batch_begin_device(dev.data_ptr() + count * length, length, length, count, seeds_b, cfg)
+    with pytest.raises(frieda_amd.FriedaError):
+        gpu_ctx.prove_batch_finish(count + 1)
+    # the mismatch left the batch in flight
+    got_a = gpu_ctx.prove_batch_finish(count)
+    got_b = other.prove_batch_finish(count)
+    exp_a = gpu_ctx.commit_and_generate_proof_batch_device(dev.data_ptr(), length, length, count, seeds_a, cfg)
+    exp_b = gpu_ctx.commit_and_generate_proof_batch_device(dev.data_ptr() + count * length, length, length, count, seeds_b, cfg)
+    for got, exp in ((got_a, exp_a), (got_b, exp_b)):
+        assert [(r, p.serialize()) for r, p in got] == [(r, p.serialize()) for r, p in exp]
+    with pytest.raises(frieda_amd.FriedaError):
+        gpu_ctx.prove_batch_finish(count)  # nothing in flight
+    other.close()
