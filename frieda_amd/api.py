@@ -364,10 +364,22 @@ class ProofPipeline:
 _tls = threading.local()
 
 
+def _default_device():
+    """The GPU of this process: torch's current device when torch has initialised one (one process per GPU under
+    torch.distributed), else LOCAL_RANK, else 0."""
+    import os
+    import sys
+
+    torch = sys.modules.get("torch")
+    if torch is not None and torch.cuda.is_available() and torch.cuda.is_initialized():
+        return int(torch.cuda.current_device())
+    return int(os.environ.get("LOCAL_RANK", "0"))
+
+
 def default_context():
     ctx = getattr(_tls, "ctx", None)
     if ctx is None:
-        ctx = _tls.ctx = Context(0)
+        ctx = _tls.ctx = Context(_default_device())
     return ctx
 
 

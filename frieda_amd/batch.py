@@ -3,10 +3,37 @@ data-path collective; the only exchange is an all_gather of the 32-byte commitme
 backend; gloo on CPU in the tests).
 
 `commit_fn(blob) -> bytes[32]` is injected so that the sharding / gather logic is testable without a GPU; the default is the
-HIP path of this package (there is no CPU fallback).
+HIP path of this package (there is no CPU fallback): a rank's shard goes through the batched kernels
+(`frieda_commit_batch` / `frieda_commit_and_generate_proof_batch`, every kernel launched once for many blobs) whenever its
+blobs have one length, and blob by blob otherwise.
 """
 import torch
 import torch.distributed as dist
+
+
+def _chunk_size(length):
+    """Blobs per batched call: bounded so that the per-blob workspaces (a few hundred bytes per blob byte) stay within ~4 GB."""
+    return max(1, min(1024, (4 << 30) // (400 * max(length, 1) + 65536)))
+
+
+def _local_commit_many(ctx, blobs, log_blowup_factor):
+    if len(blobs) > 1 and len({len(b) for b in blobs}) == 1:
+        step, out = _chunk_size(len(blobs[0])), []
+        for k in range(0, len(blobs), step):
+            out += ctx.commit_batch(blobs[k : k + step], log_blowup_factor)
+        return out
+    return [ctx.commit(b, log_blowup_factor) for b in blobs]
+
+
+def _local_prove_many(ctx, blobs, seeds, pcs_config):
+    fc = pcs_config.fri_config
+    batched = len(blobs) > 1 and len({len(b) for b in blobs}) == 1 and fc.log_last_layer_degree_bound + fc.log_blowup_factor <= 11
+    if batched:
+        step, out = _chunk_size(len(blobs[0])), []
+        for k in range(0, len(blobs), step):
+            out += ctx.commit_and_generate_proof_batch(blobs[k : k + step], None if seeds is None else seeds[k : k + step], pcs_config)
+        return out
+    return [ctx.commit_and_generate_proof(b, None if seeds is None else seeds[i], pcs_config) for i, b in enumerate(blobs)]
 
 
 def shard_indices(n_blobs, rank, world):
@@ -19,13 +46,13 @@ def commit_batch(blobs, log_blowup_factor, commit_fn=None, device=None):
     on every rank."""
     world = dist.get_world_size() if dist.is_initialized() else 1
     rank = dist.get_rank() if dist.is_initialized() else 0
+    n = len(blobs)
+    mine = shard_indices(n, rank, world)
     if commit_fn is None:
         from . import api
 
-        ctx = api.default_context()
-        commit_fn = lambda b: ctx.commit(b, log_blowup_factor)  # noqa: E731
-    n = len(blobs)
-    mine = shard_indices(n, rank, world)
+        mine_roots = iter(_local_commit_many(api.default_context(), [blobs[i] for i in mine], log_blowup_factor))
+        commit_fn = lambda b: next(mine_roots)  # noqa: E731
     per_rank = (n + world - 1) // world
     if device is None:
         device = torch.device("cuda", torch.cuda.current_device()) if (dist.is_initialized() and dist.get_backend() == "nccl") else torch.device("cpu")
@@ -52,8 +79,8 @@ def prove_batch(blobs, seeds, pcs_config, prove_fn=None, device=None):
     """Sharded `commit_and_generate_proof`: rank r proves blobs r, r + world, ...; every rank gets all commitment roots (one
     all_gather of 32 bytes per blob slot) and the proofs of its own shard as {blob index: proof}.
 
-    `prove_fn(blob, seed) -> (bytes[32], proof)` is injectable for the CPU test; the default is the HIP path with two proofs in
-    flight per GPU (ProofPipeline)."""
+    `prove_fn(blob, seed) -> (bytes[32], proof)` is injectable for the CPU test; the default is the HIP path (batched kernels
+    for equal-length shards)."""
     world = dist.get_world_size() if dist.is_initialized() else 1
     rank = dist.get_rank() if dist.is_initialized() else 0
     n = len(blobs)
@@ -62,10 +89,11 @@ def prove_batch(blobs, seeds, pcs_config, prove_fn=None, device=None):
     if prove_fn is None:
         from . import api
 
-        ctx = api.default_context()
-        prove_fn = lambda b, s: ctx.commit_and_generate_proof(b, s, pcs_config)  # noqa: E731
-    for i in mine:
-        results[i] = prove_fn(blobs[i], seeds[i] if seeds is not None else None)
+        my_seeds = None if seeds is None else [seeds[i] for i in mine]
+        results = dict(zip(mine, _local_prove_many(api.default_context(), [blobs[i] for i in mine], my_seeds, pcs_config)))
+    else:
+        for i in mine:
+            results[i] = prove_fn(blobs[i], seeds[i] if seeds is not None else None)
     roots = commit_batch(blobs, pcs_config.fri_config.log_blowup_factor if hasattr(pcs_config, "fri_config") else 4,
                          commit_fn=lambda b, _it=iter([results[i][0] for i in mine]): next(_it), device=device)
     return roots, {i: results[i][1] for i in mine}

@@ -648,3 +648,22 @@ def test_two_batches_in_flight(gpu_ctx):
     with pytest.raises(frieda_amd.FriedaError):
         gpu_ctx.prove_batch_finish(count)  # nothing in flight
     other.close()
+
+
+def test_sharded_batch_helpers_use_the_batched_kernels(oracle):
+    """frieda_amd.batch (the multi-GPU sharding layer) on one rank: equal-length shards go through the batched kernels, ragged
+    ones blob by blob; both give the oracle's roots and proofs."""
+    import frieda_amd
+    from frieda_amd import batch
+
+    cfg = _cfg(frieda_amd, 8, 4, 0, 10)
+    ocfg = oracle.make_config(8, 4, 0, 10)
+    equal = [splitmix64_bytes(9300 + i, 1500).tobytes() for i in range(5)]
+    ragged = equal[:2] + [splitmix64_bytes(9400, 700).tobytes()]
+    for blobs in (equal, ragged):
+        seeds = list(range(len(blobs)))
+        assert batch.commit_batch(blobs, 4) == [oracle.commit(b, 4) for b in blobs]
+        roots, proofs = batch.prove_batch(blobs, seeds, cfg)
+        for i, b in enumerate(blobs):
+            o_root, o_proof = oracle.commit_and_generate_proof(b, seeds[i], ocfg)
+            assert roots[i] == o_root and proofs[i].serialize() == o_proof.serialize()
