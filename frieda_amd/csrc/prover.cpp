@@ -243,42 +243,38 @@ std::vector<uint32_t> plan_witness(const std::vector<uint32_t>& queries, const F
     return pos;
 }
 
-// MerkleProver::decommit for a tree with its columns on the leaf layer only: requests for the sibling hashes
+// MerkleProver::decommit for a tree with its columns on the leaf layer only: requests for the sibling hashes.
+// stwo walks the layers from the leaves up; on layer l it visits, in increasing order, every node that has a queried leaf or a
+// visited child below it, and emits the hash of each child that was not visited itself (left before right).  `positions` are
+// the queried leaves (sorted, unique).  Two scratch vectors are reused across calls (this runs ~25 times per proof).
 size_t plan_merkle_decommit(const std::vector<uint32_t>& positions, const FriLayerDev& lay, GatherPlan& g) {
+    static thread_local std::vector<uint32_t> buf_a, buf_b;
+    std::vector<uint32_t>* below = &buf_a;  // visited nodes of the layer below (children), sorted
+    std::vector<uint32_t>* here = &buf_b;
+    below->assign(positions.begin(), positions.end());  // leaf layer: exactly the queried leaves, no hashes needed
     size_t n_hashes = 0;
-    std::vector<uint32_t> last;
-    for (int layer = (int)lay.log; layer >= 0; layer--) {
-        const bool leaf = layer == (int)lay.log;
-        std::vector<uint32_t> cur;
-        const size_t prev_base = leaf ? 0 : (lay.o_tree + k::merkle_layer_offset(lay.log, (uint32_t)layer + 1)) / 32;
-        size_t pi = 0, ci = 0;
-        const size_t n_col = leaf ? positions.size() : 0;
-        while (pi < last.size() || ci < n_col) {
-            uint32_t node;
-            if (pi < last.size() && ci < n_col)
-                node = std::min(last[pi] / 2, positions[ci]);
-            else if (pi < last.size())
-                node = last[pi] / 2;
-            else
-                node = positions[ci];
-            if (!leaf) {
-                if (pi < last.size() && last[pi] == 2 * node)
-                    pi++;
-                else {
-                    g.hash_idx.push_back(prev_base + 2 * (size_t)node);
-                    n_hashes++;
-                }
-                if (pi < last.size() && last[pi] == 2 * node + 1)
-                    pi++;
-                else {
-                    g.hash_idx.push_back(prev_base + 2 * (size_t)node + 1);
-                    n_hashes++;
-                }
+    for (int layer = (int)lay.log - 1; layer >= 0; layer--) {
+        const size_t child_base = (lay.o_tree + k::merkle_layer_offset(lay.log, (uint32_t)layer + 1)) / 32;
+        here->clear();
+        const uint32_t* c = below->data();
+        const size_t nc = below->size();
+        for (size_t i = 0; i < nc;) {
+            const uint32_t node = c[i] >> 1;
+            const bool has_left = c[i] == 2 * node;
+            if (has_left) i++;
+            const bool has_right = i < nc && c[i] == 2 * node + 1;
+            if (has_right) i++;
+            if (!has_left) {
+                g.hash_idx.push_back(child_base + 2 * (size_t)node);
+                n_hashes++;
             }
-            if (ci < n_col && positions[ci] == node) ci++;
-            cur.push_back(node);
+            if (!has_right) {
+                g.hash_idx.push_back(child_base + 2 * (size_t)node + 1);
+                n_hashes++;
+            }
+            here->push_back(node);
         }
-        last.swap(cur);
+        std::swap(below, here);
     }
     return n_hashes;
 }
@@ -639,7 +635,9 @@ int prove_finish_batch(Ctx* ctx, uint8_t* out_commitments, std::vector<ProofData
     ctx->phase_ms[1] = ms_since(J.t_start);  // commit phase + grind complete on the device (first synchronise)
 
     // ---- FriProver::decommit: plan the openings of every blob, one gather launch for all ----
-    GatherPlan g;
+    static thread_local GatherPlan g;  // capacity is kept from proof to proof
+    g.word_idx.clear();
+    g.hash_idx.clear();
     struct LayerCounts {
         size_t n_witness, n_hashes;
     };

@@ -131,6 +131,23 @@ class Context {
         check(frieda_commit_and_generate_proof(h_, data, len, seed ? &s : nullptr, cfg.c(), root.data(), &p), h_);
         return {root, Proof(p)};
     }
+    // `count` equal-length blobs, blob i at data + i * stride: every kernel is launched once for the whole batch
+    std::vector<Commitment> commit_batch(const uint8_t* data, size_t stride, size_t len, uint32_t count, uint32_t log_blowup_factor) {
+        std::vector<Commitment> roots(count);
+        if (count) check(frieda_commit_batch(h_, data, stride, len, count, log_blowup_factor, roots.data()->data()), h_);
+        return roots;
+    }
+    std::vector<std::pair<Commitment, Proof>> commit_and_generate_proof_batch(const uint8_t* data, size_t stride, size_t len, uint32_t count,
+                                                                              const uint64_t* seeds_or_null, const PcsConfig& cfg) {
+        std::vector<std::pair<Commitment, Proof>> out;
+        if (!count) return out;
+        std::vector<Commitment> roots(count);
+        std::vector<frieda_proof*> ps(count, nullptr);
+        check(frieda_commit_and_generate_proof_batch(h_, data, stride, len, count, seeds_or_null, cfg.c(), roots.data()->data(), ps.data()), h_);
+        out.reserve(count);
+        for (uint32_t i = 0; i < count; i++) out.emplace_back(roots[i], Proof(ps[i]));
+        return out;
+    }
     frieda_ctx* handle() { return h_; }
 
   private:

@@ -106,6 +106,26 @@ int main(int argc, char** argv) {
         }
         CHECK(panicked);
     }
+    {  // batches: the same results as one call per blob
+        const uint32_t count = 5;
+        const size_t len = 777, stride = 800;
+        std::vector<uint8_t> buf(stride * count, 0xEE);
+        for (uint32_t i = 0; i < count; i++)
+            for (size_t j = 0; j < len; j++) buf[i * stride + j] = (uint8_t)(31 * i + 7 * j + (j >> 3));
+        std::vector<uint64_t> seeds = {11, 12, 13, 14, 15};
+        Context& ctx = default_context();
+        auto roots = ctx.commit_batch(buf.data(), stride, len, count, 4);
+        auto proofs = ctx.commit_and_generate_proof_batch(buf.data(), stride, len, count, seeds.data(), PCS_CONFIG);
+        CHECK(roots.size() == count && proofs.size() == count);
+        for (uint32_t i = 0; i < count && i < proofs.size(); i++) {
+            std::vector<uint8_t> one(buf.begin() + i * stride, buf.begin() + i * stride + len);
+            CHECK(roots[i] == api::commit(one, 4));
+            auto single = proof::commit_and_generate_proof(one, seeds[i], PCS_CONFIG);
+            CHECK(proofs[i].first == single.first && proofs[i].first == roots[i]);
+            CHECK(proofs[i].second.serialize() == single.second.serialize());
+            CHECK(api::verify(proofs[i].second, seeds[i]));
+        }
+    }
     std::printf("%s (%d failures)\n", failures ? "FAILED" : "ok", failures);
     return failures ? 1 : 0;
 }
