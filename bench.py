@@ -112,6 +112,7 @@ def main():
     ap.add_argument("--cpu-sample-log", type=int, default=22)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-twiddle-cache", action="store_true", help="regenerate twiddles every call, as the reference does")
+    ap.add_argument("--batch-extra", type=int, default=4, help="blobs per call for the extra 'batched' figure (0 = skip)")
     ap.add_argument("--pipeline-depth", type=int, default=2, help="proofs in flight for the extra 'pipelined' figure (0 = skip)")
     args = ap.parse_args()
 
@@ -267,6 +268,34 @@ def main():
         }
         pipe.close()
 
+    # ---- extra figure: the batched entry point (frieda_commit_and_generate_proof_batch_device): `batch` blobs of this size per
+    # call, every kernel launched once for all of them, so the Fiat-Shamir / launch latency chain is paid once per batch ----
+    batched = None
+    if args.workload == "prove" and args.batch_extra > 1 and world == 1:
+        bsz = args.batch_extra
+        many = blob.repeat(bsz)
+        bseeds = [seed] * bsz
+        bctx = frieda_amd.Context(local_rank)
+        res = bctx.commit_and_generate_proof_batch_device(many.data_ptr(), blob_len, blob_len, bsz, bseeds, cfg)  # sizes the workspace
+        assert all(r == root for r, _ in res) and res[-1][1].serialize() == proof.serialize()
+        reps = max(2, args.steps // bsz)
+        torch.cuda.synchronize()
+        tb0 = time.perf_counter()
+        for _ in range(reps):
+            res = bctx.commit_and_generate_proof_batch_device(many.data_ptr(), blob_len, blob_len, bsz, bseeds, cfg)
+        torch.cuda.synchronize()
+        dtb = (time.perf_counter() - tb0) / (reps * bsz)
+        batched = {
+            "batch": bsz,
+            "value": elems / dtb,
+            "unit": "M31 field-elems/s",
+            "ms_per_proof": 1e3 * dtb,
+            "frac_of_hbm_peak": algorithmic_bytes(n, "prove") / dtb / 1e9 / HBM_PEAK_GBS,
+            "note": "`batch` blobs of the same size per call through the batched entry point; not the headline value",
+        }
+        del res
+        bctx.close()
+
     # secondary ceiling: the path is bound by the integer VALU rate of Blake2s, not by HBM.  For the first-tree
     # kernel (16.8 M leaf + 15.7 M node compressions at n = 24) compare with the chip's measured pure-compute rate
     # (profiles/r01_blake2s_rate_mi355x.txt: 40.9 G leaf / 39.8 G node compressions per second).
@@ -327,6 +356,7 @@ def main():
             ],
         },
         "pipelined": pipelined,
+        "batched": batched,
         "root": root.hex() if root else None,
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

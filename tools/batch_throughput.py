@@ -48,14 +48,14 @@ def overlapped(dev, size, count, seeds, rounds):
 print("| blob bytes | batch | prove: proofs/s | us per proof | phases ms (device done / planned / gathered / assembled) | two batches in flight: proofs/s | commit: roots/s | us per root |")
 print("|---|---|---|---|---|---|---|---|")
 for size in sizes:
-    for count in (1, 8, 64, 256, 1024):
-        if size * count > (64 << 20):
+    for count in ((1, 8, 64, 256, 1024) if size <= (1 << 20) else (1, 2, 4, 8)):
+        if size * count > (64 << 20) and size <= (1 << 20):
             continue
         host = np.concatenate([splitmix64_bytes(31 * i + size, size) for i in range(min(count, 64))])
         host = np.tile(host, (count + 63) // 64)[: size * count]
         dev = torch.from_numpy(host).cuda()
         seeds = list(range(count))
-        reps = max(2, min(50, 2048 // count))
+        reps = max(2, min(50, 2048 // count)) if size <= (1 << 20) else 6
         if count == 1:
             tp = timed(lambda: ctx.commit_and_generate_proof_device(dev.data_ptr(), size, 0, cfg), reps)
             tc = timed(lambda: ctx.commit_batch_device(dev.data_ptr(), size, size, 1, 4), reps)
