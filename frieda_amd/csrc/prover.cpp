@@ -490,6 +490,10 @@ int prove_begin_batch(Ctx* ctx, const uint8_t* data, size_t data_stride, size_t 
         J.grind_base = 0;
         // first range: 16x the expected search (a miss has probability e^-16; workgroups without work leave at once)
         J.grind_chunk = (uint64_t)1 << std::max<uint32_t>(22, std::min<uint32_t>(cfg.pow_bits, 36) + 4);
+        if (const char* e = getenv("FRIEDA_TEST_GRIND_FIRST_LOG")) {  // test hook: a short first range exercises the retry loop
+            const int v = atoi(e);
+            if (v >= 8 && v <= 40) J.grind_chunk = (uint64_t)1 << v;
+        }
         k::grind_dev(LN, d_tr, reinterpret_cast<uint32_t*>(A + J.o_gnext), cfg.pow_bits, J.grind_base, J.grind_chunk);
         rc = download_transcripts(ctx, J);
         if (rc) return rc;

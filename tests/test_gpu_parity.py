@@ -667,3 +667,20 @@ def test_sharded_batch_helpers_use_the_batched_kernels(oracle):
         for i, b in enumerate(blobs):
             o_root, o_proof = oracle.commit_and_generate_proof(b, seeds[i], ocfg)
             assert roots[i] == o_root and proofs[i].serialize() == o_proof.serialize()
+
+
+def test_grind_retry_loop(gpu_ctx, oracle, monkeypatch):
+    """The first grind range normally holds the nonce with probability 1 - e^-16; a test hook shortens it so that the host's
+    retry loop (next range, doubled) runs — single proofs and batches, where some blobs finish rounds before others."""
+    import frieda_amd
+
+    cfg = _cfg(frieda_amd, 18, 4, 0, 8)
+    blobs = [splitmix64_bytes(9500 + i, 900).tobytes() for i in range(6)]
+    expect = [oracle.commit_and_generate_proof(b, i, oracle.make_config(18, 4, 0, 8)) for i, b in enumerate(blobs)]
+    assert len({p.c.proof_of_work for _, p in expect}) > 1
+    monkeypatch.setenv("FRIEDA_TEST_GRIND_FIRST_LOG", "10")  # 1024 nonces, then 2048, 4096, ...
+    got = gpu_ctx.commit_and_generate_proof_batch(blobs, list(range(len(blobs))), cfg)
+    for (er, ep), (gr, gp) in zip(expect, got):
+        assert er == gr and ep.serialize() == gp.serialize()
+    r, p = gpu_ctx.commit_and_generate_proof(blobs[0], 0, cfg)
+    assert r == expect[0][0] and p.serialize() == expect[0][1].serialize()
