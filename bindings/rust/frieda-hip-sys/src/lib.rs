@@ -40,6 +40,7 @@ extern "C" {
     pub fn frieda_ctx_create(device: c_int, stream: *mut c_void, out: *mut *mut frieda_ctx) -> c_int;
     pub fn frieda_ctx_destroy(ctx: *mut frieda_ctx) -> c_int;
     pub fn frieda_ctx_synchronize(ctx: *mut frieda_ctx) -> c_int;
+    pub fn frieda_ctx_release_workspace(ctx: *mut frieda_ctx) -> c_int;
     pub fn frieda_ctx_set_twiddle_cache(ctx: *mut frieda_ctx, enabled: c_int) -> c_int;
     pub fn frieda_ctx_set_host_channel(ctx: *mut frieda_ctx, enabled: c_int) -> c_int;
     pub fn frieda_ctx_test_set_draw_bound(ctx: *mut frieda_ctx, bound: u32) -> c_int;

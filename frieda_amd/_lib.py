@@ -62,6 +62,7 @@ def lib():
         "frieda_ctx_create": (C.c_int, [C.c_int, vp, pp]),
         "frieda_ctx_destroy": (C.c_int, [vp]),
         "frieda_ctx_synchronize": (C.c_int, [vp]),
+        "frieda_ctx_release_workspace": (C.c_int, [vp]),
         "frieda_ctx_set_twiddle_cache": (C.c_int, [vp, C.c_int]),
         "frieda_ctx_set_host_channel": (C.c_int, [vp, C.c_int]),
         "frieda_ctx_test_set_draw_bound": (C.c_int, [vp, u32]),

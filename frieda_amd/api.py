@@ -93,6 +93,10 @@ class Context:
     def synchronize(self):
         _check(self._L.frieda_ctx_synchronize(self._h), self._h)
 
+    def release_workspace(self):
+        """Free the device workspace, the pinned staging block and the twiddle tables (they are re-created on demand)."""
+        _check(self._L.frieda_ctx_release_workspace(self._h), self._h)
+
     def set_twiddle_cache(self, enabled):
         _check(self._L.frieda_ctx_set_twiddle_cache(self._h, int(bool(enabled))), self._h)
 

@@ -81,6 +81,21 @@ int frieda_ctx_synchronize(frieda_ctx* ctx) {
     return FRIEDA_OK;
 }
 
+int frieda_ctx_release_workspace(frieda_ctx* ctx) {
+    if (!ctx) return FRIEDA_ERR_ARG;
+    if (ctx->c.job) return ctx->c.fail(FRIEDA_ERR_ARG, "a proof is in flight on this context");
+    FR_HIP(&ctx->c, hipSetDevice(ctx->c.device));
+    FR_HIP(&ctx->c, hipStreamSynchronize(ctx->c.stream));
+    if (ctx->c.arena) FR_HIP(&ctx->c, hipFree(ctx->c.arena));
+    ctx->c.arena = nullptr;
+    ctx->c.arena_bytes = 0;
+    if (ctx->c.pinned) FR_HIP(&ctx->c, hipHostFree(ctx->c.pinned));
+    ctx->c.pinned = nullptr;
+    ctx->c.pinned_bytes = 0;
+    ctx->c.drop_twiddles();
+    return FRIEDA_OK;
+}
+
 int frieda_ctx_set_twiddle_cache(frieda_ctx* ctx, int enabled) {
     if (!ctx) return FRIEDA_ERR_ARG;
     ctx->c.cache_twiddles = enabled != 0;

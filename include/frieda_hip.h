@@ -65,6 +65,10 @@ int frieda_ctx_synchronize(frieda_ctx* ctx);
  * them on every call as the reference does (src/commit.rs:15) */
 int frieda_ctx_set_twiddle_cache(frieda_ctx* ctx, int enabled);
 
+/* The ctx keeps its device workspace (sized by the largest call so far: a few hundred bytes per blob byte, times the batch),
+ * its pinned staging block and its twiddle tables between calls.  This frees them; the next call allocates what it needs. */
+int frieda_ctx_release_workspace(frieda_ctx* ctx);
+
 /* transcript policy: 0 (default) the Fiat-Shamir channel of generate_proof runs on the device inside the commit-phase
  * kernels; 1 evaluates it on the host between layers (one 32-byte D2H + synchronise per layer).  Proofs are identical;
  * configurations whose last FRI layer exceeds 2^11 points always use the host policy. */

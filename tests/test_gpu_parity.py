@@ -684,3 +684,16 @@ def test_grind_retry_loop(gpu_ctx, oracle, monkeypatch):
         assert er == gr and ep.serialize() == gp.serialize()
     r, p = gpu_ctx.commit_and_generate_proof(blobs[0], 0, cfg)
     assert r == expect[0][0] and p.serialize() == expect[0][1].serialize()
+
+
+def test_release_workspace(gpu_ctx):
+    import frieda_amd
+
+    cfg = _cfg(frieda_amd, 6, 4, 0, 8)
+    blobs = [splitmix64_bytes(9600 + i, 5000).tobytes() for i in range(3)]
+    before = gpu_ctx.commit_and_generate_proof_batch(blobs, None, cfg)
+    gpu_ctx.release_workspace()
+    gpu_ctx.release_workspace()  # idempotent
+    after = gpu_ctx.commit_and_generate_proof_batch(blobs, None, cfg)
+    assert [(r, p.serialize()) for r, p in before] == [(r, p.serialize()) for r, p in after]
+    assert gpu_ctx.commit(blobs[0], 4) == before[0][0]
