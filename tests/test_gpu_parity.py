@@ -697,3 +697,22 @@ def test_release_workspace(gpu_ctx):
     after = gpu_ctx.commit_and_generate_proof_batch(blobs, None, cfg)
     assert [(r, p.serialize()) for r, p in before] == [(r, p.serialize()) for r, p in after]
     assert gpu_ctx.commit(blobs[0], 4) == before[0][0]
+
+
+@pytest.mark.parametrize("nq", [64, 65, 300])
+def test_many_queries_with_duplicate_draws(gpu_ctx, oracle, nq):
+    """Up to 300 queries over a 2^9 .. 2^17 domain: repeated draws are deduplicated (Queries::generate), most Merkle nodes of the
+    small trees are opened; single proofs and a batch equal the oracle's."""
+    import frieda_amd
+
+    cfg = _cfg(frieda_amd, 5, 3, 1, nq)
+    ocfg = oracle.make_config(5, 3, 1, nq)
+    blobs = [splitmix64_bytes(9700 + i, 200).tobytes() for i in range(3)] + [splitmix64_bytes(9800, 40000).tobytes()]
+    for blob in (blobs[0], blobs[3]):
+        o_root, o_proof = oracle.commit_and_generate_proof(blob, 7, ocfg)
+        r1, p1 = gpu_ctx.commit_and_generate_proof(blob, 7, cfg)
+        assert r1 == o_root and p1.serialize() == o_proof.serialize()
+    got = gpu_ctx.commit_and_generate_proof_batch(blobs[:3], [1, 2, 3], cfg)
+    for i, (ra, pa) in enumerate(got):
+        o_root, o_proof = oracle.commit_and_generate_proof(blobs[i], i + 1, ocfg)
+        assert ra == o_root and pa.serialize() == o_proof.serialize()
