@@ -317,13 +317,19 @@ __global__ __launch_bounds__(T5_THREADS) void tree5r_kernel(TreeArgs a) {
 // ------------------------------------------------------------------------------------------------
 // four-lane Blake2s compression for the latency-bound top of a tree
 // ------------------------------------------------------------------------------------------------
-// A lone wave issues a VALU instruction only every 4-8 cycles, so one compression per lane takes ~2.9 us however few
-// hashes a level has.  For levels of <= 256 nodes the four lanes of an aligned quad share one compression instead: lane q
-// owns state column q (v[q], v[4+q], v[8+q], v[12+q]); the column step is lane-local, the diagonal step rotates b, c, d by
-// 1, 2, 3 lanes with DPP quad_perm moves.  The 16 message words stay in LDS in the layout word(idx) = idx + (idx >> 3)
-// (two 8-word hashes stored 9 words apart, which also spreads the quads over the banks); every lane keeps its forty
-// per-round message offsets in registers.  Lane q ends up with output words q and 4 + q.
-constexpr uint32_t QS = 9;  // words between consecutive hashes in the quad (array-of-structs) LDS layout
+// A lone wave issues one VALU instruction every ~4 cycles whatever its rate class, so one compression per lane costs ~1.8 us
+// (~960 instructions at 2.4 GHz) however few hashes a level has.  For levels of <= 128 nodes the four lanes of an aligned quad
+// share one compression instead (~0.95 us, tools/quad_latency.hip): lane q owns state column q (v[q], v[4+q], v[8+q],
+// v[12+q]); the column step is lane-local, the diagonal step rotates b, c, d by 1, 2, 3 lanes with DPP quad_perm moves.
+// Messages live in LDS in the quad layout: hash j at words [QS j, QS j + 8), so the two children of node j form the 18-word
+// message slot [2 QS j, 2 QS j + 18) with message word idx at idx + (idx >> 3) (9 words per hash also spreads the quads over
+// the banks).  Two such buffers alternate level by level (children in buffer P, parents into buffer P ^ 1 at hash position j,
+// i.e. straight into the parent's message slot).  A quad keeps its node index through all levels, so every lane holds the forty
+// LDS addresses of its message words (round r, fetch k) in registers for the whole kernel and the buffer parity is a compile-time
+// immediate of the ds_read; the Blake2s IV words of its column are registers too (nothing is re-read from memory per level).
+// Lane q ends up with output words q and 4 + q.
+constexpr uint32_t QS = 9;                      // words between consecutive hashes in the quad (array-of-structs) LDS layout
+constexpr uint32_t QBUF_WORDS = 256 * QS + 12;  // one buffer: 256 hashes = 128 message slots (a multiple of four words)
 
 template <int CTRL>
 __device__ __forceinline__ uint32_t quad_perm(uint32_t v) {
@@ -333,37 +339,52 @@ constexpr int QROT1 = 0x39;  // lane q reads lane q+1
 constexpr int QROT2 = 0x4E;  // lane q reads lane q+2
 constexpr int QROT3 = 0x93;  // lane q reads lane q+3
 
-struct QuadOffsets {
-    uint32_t w[40];  // round r, fetch k (0,1: column step; 2,3: diagonal step): LDS byte offset of the message word
-};
+// byte offsets inside a message slot of the message word that lane q = 0..3 needs at (round r, fetch k), one byte per lane;
+// k = 0, 1: column step (SIGMA[r][2q + k]); k = 2, 3: diagonal step (SIGMA[r][8 + 2q + (k & 1)])
+constexpr uint32_t sigma_pack(int r, int k) {
+    uint32_t c = 0;
+    for (int q = 0; q < 4; q++) {
+        const uint32_t idx = b2detail::SIGMA[r][(k < 2 ? 0 : 8) + 2 * q + (k & 1)];
+        c |= (4u * (idx + (idx >> 3))) << (8 * q);
+    }
+    return c;
+}
+__device__ __forceinline__ uint32_t sel4(uint32_t q, uint32_t v0, uint32_t v1, uint32_t v2, uint32_t v3) {
+    uint32_t v = v0;
+    v = q == 1 ? v1 : v;
+    v = q == 2 ? v2 : v;
+    v = q == 3 ? v3 : v;
+    return v;
+}
 
-__device__ __forceinline__ void quad_offsets_init(QuadOffsets& o, uint32_t q) {
+struct QuadCtx {
+    uint32_t a[40];   // byte offset, inside a buffer, of this lane's message word for (round r, fetch k) at a[4 r + k]
+    uint32_t wr;      // byte offset, inside a buffer, of word q of hash `quad` (the quad's output position)
+    uint32_t c0, d0;  // IV[q], IV[4 + q]
+};
+// `quad`: the node index this quad keeps through the levels (its message slot); q = lane & 3
+__device__ __forceinline__ void quad_ctx_init(QuadCtx& x, uint32_t quad, uint32_t q) {
+    const uint32_t slot = 4u * 2u * QS * quad;
 #pragma unroll
     for (int r = 0; r < 10; r++) {
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const uint32_t pos = (k < 2 ? 0u : 8u) + 2u * q + (uint32_t)(k & 1);
-            // SIGMA[r][pos] with a lane-dependent pos: select among the four lanes' constants
-            uint32_t idx = b2detail::SIGMA[r][(k < 2 ? 0 : 8) + (k & 1)];
-            if (q == 1) idx = b2detail::SIGMA[r][(k < 2 ? 0 : 8) + 2 + (k & 1)];
-            if (q == 2) idx = b2detail::SIGMA[r][(k < 2 ? 0 : 8) + 4 + (k & 1)];
-            if (q == 3) idx = b2detail::SIGMA[r][(k < 2 ? 0 : 8) + 6 + (k & 1)];
-            (void)pos;
-            o.w[4 * r + k] = 4u * (idx + (idx >> 3));  // byte offset
-        }
+        for (int k = 0; k < 4; k++) x.a[4 * r + k] = slot + ((sigma_pack(r, k) >> (8u * q)) & 0xFFu);
     }
+    x.wr = 4u * (QS * quad + q);
+    x.c0 = sel4(q, b2detail::IV[0], b2detail::IV[1], b2detail::IV[2], b2detail::IV[3]);
+    x.d0 = sel4(q, b2detail::IV[4], b2detail::IV[5], b2detail::IV[6], b2detail::IV[7]);
 }
 
 struct Quad2 {
     uint32_t lo, hi;  // output words q and 4 + q
 };
 
-// state in: a = h[q], b = h[4+q], c = IV[q], d = IV[4+q] ^ {t0, t1, f0, f1}[q]
-__device__ __forceinline__ Quad2 b2_compress_quad(const uint32_t* msg, const QuadOffsets& o, uint32_t ha, uint32_t hb, uint32_t c,
-                                                  uint32_t d) {
+// message = the quad's slot in buffer P; state in: a = h[q], b = h[4+q], c = IV[q], d = IV[4+q] ^ {t0, t1, f0, f1}[q]
+template <int P>
+__device__ __forceinline__ Quad2 b2_compress_quad(const uint32_t* QQ, const QuadCtx& x, uint32_t ha, uint32_t hb, uint32_t c, uint32_t d) {
     uint32_t a = ha, b = hb;
-    const char* mbase = reinterpret_cast<const char*>(msg);
-    auto fetch = [&](int i) { return *reinterpret_cast<const uint32_t*>(mbase + o.w[i]); };
+    const char* mbase = reinterpret_cast<const char*>(QQ + P * QBUF_WORDS);
+    auto fetch = [&](int i) { return *reinterpret_cast<const uint32_t*>(mbase + x.a[i]); };
 #pragma unroll
     for (int r = 0; r < 10; r++) {
         const uint32_t m0 = fetch(4 * r), m1 = fetch(4 * r + 1), m2 = fetch(4 * r + 2), m3 = fetch(4 * r + 3);
@@ -379,117 +400,133 @@ __device__ __forceinline__ Quad2 b2_compress_quad(const uint32_t* msg, const Qua
     return {ha ^ a ^ c, hb ^ b ^ d};
 }
 
-// Merkle node from the zero state (Blake2sMerkleHasher::hash_node): h = 0, t = f = 0
-__device__ __forceinline__ Quad2 merkle_node_quad(const uint32_t* msg, const QuadOffsets& o, uint32_t q) {
-    return b2_compress_quad(msg, o, 0u, 0u, b2detail::IV[q & 3], b2detail::IV[4 + (q & 3)]);
-}
-__device__ __forceinline__ uint32_t iv_sel(uint32_t i) {
-    // IV[i] with a lane-dependent index, without a memory table
-    uint32_t v = b2detail::IV[0];
+__device__ __forceinline__ void q_put_hash(uint32_t* Q, uint32_t j, const uint32_t (&h)[8]) {
 #pragma unroll
-    for (int k = 1; k < 8; k++) v = (i == (uint32_t)k) ? b2detail::IV[k] : v;
-    return v;
+    for (int w = 0; w < 8; w++) Q[QS * j + w] = h[w];
+}
+// `count` hashes (32-byte array of structs in global memory) -> quad layout, 16 bytes per lane and step
+__device__ __forceinline__ void q_load_hashes(uint32_t* Q, const uint8_t* in, uint32_t count, uint32_t t, uint32_t nthreads) {
+    const uint4* in4 = reinterpret_cast<const uint4*>(in);
+    for (uint32_t e = t; e < 2 * count; e += nthreads) {
+        const uint4 v = in4[e];
+        uint32_t* dst = Q + QS * (e >> 1) + 4 * (e & 1);
+        dst[0] = v.x, dst[1] = v.y, dst[2] = v.z, dst[3] = v.w;
+    }
+}
+// store words q and 4+q of hash j (32-byte array-of-structs in global memory)
+__device__ __forceinline__ void store_hash_quad(uint8_t* out, size_t j, uint32_t q, Quad2 v) {
+    uint32_t* p = reinterpret_cast<uint32_t*>(out + 32 * j);
+    p[q] = v.lo;
+    p[4 + q] = v.hi;
+}
+
+// One quad level: the Merkle node (Blake2sMerkleHasher::hash_node: h = 0, t = f = 0) of this quad from its message slot in
+// buffer P; the result goes to global memory (`gout` non-null, node index `node`) and, when `keep`, to hash position `quad`
+// of buffer P ^ 1.  Ends with the workgroup barrier.
+template <int P>
+__device__ __forceinline__ void quad_level(uint32_t* QQ, const QuadCtx& x, bool active, uint8_t* gout, size_t node, uint32_t q, bool keep) {
+    if (active) {
+        const Quad2 v = b2_compress_quad<P>(QQ, x, 0u, 0u, x.c0, x.d0);
+        if (gout) store_hash_quad(gout, node, q, v);
+        if (keep) {
+            uint32_t* w = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(QQ + (P ^ 1) * QBUF_WORDS) + x.wr);
+            w[0] = v.lo;
+            w[4] = v.hi;
+        }
+    }
+    __syncthreads();
 }
 
 // ------------------------------------------------------------------------------------------------
 // single-workgroup tree machinery: LDS regions and the level loop
 // ------------------------------------------------------------------------------------------------
-// Levels of >= 1024 hashes live in LDS as struct-of-arrays (S regions, one thread per node); levels of <= 512 hashes live
-// in the quad layout (Q regions) because their parents (<= 256 nodes) are hashed by quads.
-struct WgRegions {
-    uint32_t* S0;  // SoA, capacity cap0 hashes
-    uint32_t* S1;  // SoA, capacity cap0 / 2 hashes
-    uint32_t* QA;  // quad layout, 512 hashes
-    uint32_t* QB;  // quad layout, 256 hashes
-};
-constexpr uint32_t QA_WORDS = 512 * QS, QB_WORDS = 256 * QS;
-
-__device__ __forceinline__ void q_put_hash(uint32_t* Q, uint32_t j, const uint32_t (&h)[8]) {
-#pragma unroll
-    for (int w = 0; w < 8; w++) Q[QS * j + w] = h[w];
-}
-// store words q and 4+q of hash j (32-byte array-of-structs in global memory)
-__device__ __forceinline__ void store_hash_quad(uint8_t* out, uint32_t j, uint32_t q, Quad2 v) {
-    uint32_t* p = reinterpret_cast<uint32_t*>(out + 32 * (size_t)j);
-    p[q] = v.lo;
-    p[4 + q] = v.hi;
-}
-
-// Reduces a level of 2^log_count hashes already in LDS (SoA in `s_cur` when 2^log_count >= 1024, else quad layout in
-// `q_cur`) down to the root.  Every produced level l is stored at its leaves-first offset when `layers` is non-null.
+// Levels of >= 512 hashes live in LDS as struct-of-arrays (S regions, one thread per parent node); levels of <= 256 hashes
+// live in buffer 0 of the quad buffers QQ because their parents (<= 128 nodes = the quads of the workgroup) are quad-hashed.
+//
+// Reduces a level of 2^log_count hashes already in LDS (SoA in `s_cur` when 2^log_count >= 512, else quad layout in buffer 0
+// of QQ) down to the root.  Every produced level l is stored at its leaves-first offset when `layers` is non-null.
 // Returns the LDS address of the root (8 consecutive words), valid for all threads after the final barrier.
-__device__ const uint32_t* wg_reduce(const WgRegions& R, uint32_t* s_cur, uint32_t* s_other, uint32_t* q_cur, uint32_t* q_other,
-                                     uint32_t log_count, uint8_t* layers, uint32_t tree_log, const QuadOffsets& qo) {
-    const uint32_t t = threadIdx.x, q = t & 3;
-    (void)R;
-    for (int l = (int)log_count - 1; l >= 0; l--) {
+// `x` must have been initialised with quad = threadIdx.x >> 2.
+__device__ const uint32_t* wg_reduce(uint32_t* s_cur, uint32_t* s_other, uint32_t* QQ, uint32_t log_count, uint8_t* layers,
+                                     uint32_t tree_log, const QuadCtx& x) {
+    const uint32_t t = threadIdx.x, q = t & 3, quad = t >> 2;
+    int l = (int)log_count - 1;
+    for (; l >= 8; l--) {
+        // one node per thread; children in SoA
         const uint32_t cnt = 1u << l;
         uint8_t* gout = layers ? layers + layer_off(tree_log, (uint32_t)l) : nullptr;
-        if (cnt >= 512) {
-            // one node per thread; children in SoA
-            for (uint32_t j = t; j < cnt; j += WG1_THREADS) {
-                uint32_t m[16], h[8];
-                lds_children(s_cur, 2 * cnt + 4, j, m);
-                b2_merkle_block(m, h);
-                if (gout) store_hash(gout, j, h);
-                if (cnt >= 1024)
-                    lds_put(s_other, cnt + 4, j, h);
-                else
-                    q_put_hash(q_cur, j, h);  // 512 hashes: the parents are quad-hashed
-            }
-            uint32_t* tmp = s_cur;
-            s_cur = s_other;
-            s_other = tmp;
-        } else {
-            // one node per quad; children in the quad layout of q_cur, parents to q_other
-            for (uint32_t j = t >> 2; j < cnt; j += WG1_THREADS / 4) {
-                Quad2 v = merkle_node_quad(q_cur + 2 * QS * j, qo, q);
-                if (gout) store_hash_quad(gout, j, q, v);
-                q_other[QS * j + q] = v.lo;
-                q_other[QS * j + 4 + q] = v.hi;
-            }
-            uint32_t* tmp = q_cur;
-            q_cur = q_other;
-            q_other = tmp;
+        for (uint32_t j = t; j < cnt; j += WG1_THREADS) {
+            uint32_t m[16], h[8];
+            lds_children(s_cur, 2 * cnt + 4, j, m);
+            b2_merkle_block(m, h);
+            if (gout) store_hash(gout, j, h);
+            if (cnt >= 512)
+                lds_put(s_other, cnt + 4, j, h);
+            else
+                q_put_hash(QQ, j, h);  // 256 hashes: the parents are quad-hashed
         }
+        uint32_t* tmp = s_cur;
+        s_cur = s_other;
+        s_other = tmp;
         __syncthreads();
     }
-    return q_cur;  // a 1-hash level is always in the quad layout
+    // one node per quad (2^l <= 128 = WG1_THREADS / 4), buffers alternating
+    uint32_t par = 0;
+    while (l >= 0) {
+        quad_level<0>(QQ, x, quad < (1u << l), layers ? layers + layer_off(tree_log, (uint32_t)l) : nullptr, quad, q, true);
+        par = 1;
+        if (--l < 0) break;
+        quad_level<1>(QQ, x, quad < (1u << l), layers ? layers + layer_off(tree_log, (uint32_t)l) : nullptr, quad, q, true);
+        par = 0;
+        --l;
+    }
+    return QQ + par * QBUF_WORDS;
 }
 
-// Fiat–Shamir step after a root, by quad 0: Blake2sMerkleChannel::mix_root (standard Blake2s-256 of digest || root) and
-// Channel::draw_felt (digest || counter, retried until all eight words are < 2P).  `root_lds`: 8 words; `mb`: 17-word LDS
-// message buffer.  Must be called by lanes 0..3 only (one full quad).
-__device__ void channel_after_root_quad(DevTranscript* tr, const uint32_t* root_lds, uint32_t* mb, const QuadOffsets& qo) {
+// Fiat–Shamir step after a root, by quad 0 (lanes 0..3 only): Blake2sMerkleChannel::mix_root (standard Blake2s-256 of
+// digest || root) and Channel::draw_felt (digest || counter, retried until all eight words are < 2P).  The channel words this
+// needs are read at kernel start (ChanRegs) so that no global load sits between the root and the alpha; quad 0's message slot
+// in buffer 0 of QQ serves as the message buffer (the tree is finished by then).  Lane q returns alpha coordinate q.
+struct ChanRegs {
+    uint32_t dg_lo, dg_hi;  // digest words q and 4 + q
+    uint32_t bound;         // draw_felt acceptance bound
+    uint32_t n_roots;
+};
+__device__ __forceinline__ void chan_prefetch(ChanRegs& cr, const DevTranscript* tr, uint32_t q) {
+    cr.dg_lo = tr->ch.digest[q];
+    cr.dg_hi = tr->ch.digest[4 + q];
+    cr.bound = tr->draw_bound;
+    cr.n_roots = tr->n_roots;
+}
+__device__ uint32_t channel_after_root_quad(DevTranscript* tr, ChanRegs& cr, uint32_t root_lo, uint32_t root_hi, uint32_t* QQ,
+                                            const QuadCtx& x) {
     const uint32_t q = threadIdx.x & 3;
     // message = digest (words 0..7) || root (words 8..15) in the idx + (idx >> 3) layout
-    mb[q] = tr->ch.digest[q];
-    mb[4 + q] = tr->ch.digest[4 + q];
-    mb[QS + q] = root_lds[q];
-    mb[QS + 4 + q] = root_lds[4 + q];
-    const uint32_t root_lo = root_lds[q], root_hi = root_lds[4 + q];
+    QQ[q] = cr.dg_lo;
+    QQ[4 + q] = cr.dg_hi;
+    QQ[QS + q] = root_lo;
+    QQ[QS + 4 + q] = root_hi;
     // h = IV ^ parameter block (digest 32, fanout 1, depth 1); t0 = 64 bytes; f0 = ~0 (single, final block)
-    const uint32_t hq = iv_sel(q) ^ (q == 0 ? 0x01010020u : 0u), h4q = iv_sel(4 + q);
+    const uint32_t hq = x.c0 ^ (q == 0 ? 0x01010020u : 0u), h4q = x.d0;
     const uint32_t dflag = (q == 0) ? 64u : (q == 2 ? 0xFFFFFFFFu : 0u);
-    Quad2 dg = b2_compress_quad(mb, qo, hq, h4q, iv_sel(q), iv_sel(4 + q) ^ dflag);
+    const Quad2 dg = b2_compress_quad<0>(QQ, x, hq, h4q, x.c0, x.d0 ^ dflag);
     // draw_felt on the new digest
-    const uint32_t bound = tr->draw_bound;
     uint32_t n_sent = 0;
     Quad2 rnd;
     for (;;) {
-        mb[q] = dg.lo;
-        mb[4 + q] = dg.hi;
-        mb[QS + q] = (q == 0) ? n_sent : 0u;
-        mb[QS + 4 + q] = 0u;
+        QQ[q] = dg.lo;
+        QQ[4 + q] = dg.hi;
+        QQ[QS + q] = (q == 0) ? n_sent : 0u;
+        QQ[QS + 4 + q] = 0u;
         n_sent++;
-        rnd = b2_compress_quad(mb, qo, hq, h4q, iv_sel(q), iv_sel(4 + q) ^ dflag);
-        uint32_t ok = (rnd.lo < bound && rnd.hi < bound) ? 1u : 0u;
+        rnd = b2_compress_quad<0>(QQ, x, hq, h4q, x.c0, x.d0 ^ dflag);
+        uint32_t ok = (rnd.lo < cr.bound && rnd.hi < cr.bound) ? 1u : 0u;
         ok &= quad_perm<QROT1>(ok);
         ok &= quad_perm<QROT2>(ok);
         if (ok) break;
     }
     const uint32_t al = m31_reduce_2p(rnd.lo);
-    const uint32_t k = tr->n_roots;
+    const uint32_t k = cr.n_roots;
     tr->ch.digest[q] = dg.lo;
     tr->ch.digest[4 + q] = dg.hi;
     tr->alpha[q] = al;
@@ -503,57 +540,55 @@ __device__ void channel_after_root_quad(DevTranscript* tr, const uint32_t* root_
         tr->ch.n_sent = n_sent;
         tr->n_roots = k + 1;
     }
+    cr.dg_lo = dg.lo;
+    cr.dg_hi = dg.hi;
+    cr.n_roots = k + 1;
+    return al;
 }
 
 // ------------------------------------------------------------------------------------------------
 // tree7q: the narrow middle of a tree (<= 32768 level-A nodes) hashed by quads across many workgroups
 // ------------------------------------------------------------------------------------------------
 // One workgroup (64 quads) owns 64 consecutive level-A nodes and produces up to seven levels (64, 32, ..., 1 nodes), every
-// node by the 4-lane compression: ~1.5 us per level instead of ~2.9 us for one-hash-per-lane, and the wide levels spread
+// node by the 4-lane compression: ~1 us per level instead of ~1.8 us for one-hash-per-lane, and the wide levels spread
 // over many CUs instead of queueing in the single-workgroup top kernel.
 constexpr uint32_t T7Q_UNITS = 64;
 constexpr uint32_t T7Q_LEVELS = 7;
 
 __global__ __launch_bounds__(256) void tree7q_kernel(TreeArgs a) {
-    __shared__ __attribute__((aligned(16))) uint32_t QX[2 * T7Q_UNITS * QS];
-    __shared__ __attribute__((aligned(16))) uint32_t QY[T7Q_UNITS * QS];
+    __shared__ __attribute__((aligned(16))) uint32_t QQ[2 * QBUF_WORDS];
     tree_args_of_blob(a);
-    const uint32_t t = threadIdx.x, q = t & 3;
-    QuadOffsets qo;
-    quad_offsets_init(qo, q);
+    const uint32_t t = threadIdx.x, q = t & 3, quad = t >> 2;
+    QuadCtx x;
+    quad_ctx_init(x, quad, q);
     const size_t total_a = (size_t)1 << a.level_a;
     const size_t wg_base = (size_t)blockIdx.x * T7Q_UNITS;
     const uint32_t cnt_a = (uint32_t)(total_a - wg_base < T7Q_UNITS ? total_a - wg_base : T7Q_UNITS);
     uint32_t nl = 1;
     while (nl < T7Q_LEVELS && (cnt_a >> nl) >= 1) nl++;
-    // the 2 * cnt_a children of this workgroup's level-A nodes: global (array of structs) -> quad layout
-    const uint32_t* inw = reinterpret_cast<const uint32_t*>(a.children) + 16 * wg_base;
-    for (uint32_t e = t; e < 16 * cnt_a; e += 256) QX[QS * (e >> 3) + (e & 7)] = inw[e];
+    // the 2 * cnt_a children of this workgroup's level-A nodes: global (array of structs) -> quad layout, buffer 0
+    q_load_hashes(QQ, a.children + 64 * wg_base, 2 * cnt_a, t, 256);
     __syncthreads();
-    uint32_t* cur = QX;
-    uint32_t* other = QY;
-    for (uint32_t l = 0; l < nl; l++) {
-        const uint32_t cnt = cnt_a >> l;
-        const bool last = l + 1 == nl;
-        uint8_t* gout = a.store_all ? a.layers + layer_off(a.tree_log, a.level_a - l) : (last ? a.last_out : nullptr);
-        for (uint32_t j = t >> 2; j < cnt; j += 64) {
-            Quad2 v = merkle_node_quad(cur + 2 * QS * j, qo, q);
-            if (gout) store_hash_quad(gout, (uint32_t)(wg_base >> l) + j, q, v);
-            if (!last) {
-                other[QS * j + q] = v.lo;
-                other[QS * j + 4 + q] = v.hi;
-            }
+    uint32_t l = 0;
+    while (l < nl) {
+        {
+            const bool last = l + 1 == nl;
+            uint8_t* gout = a.store_all ? a.layers + layer_off(a.tree_log, a.level_a - l) : (last ? a.last_out : nullptr);
+            quad_level<0>(QQ, x, quad < (cnt_a >> l), gout, (wg_base >> l) + quad, q, !last);
         }
-        __syncthreads();
-        uint32_t* tmp = cur;
-        cur = other;
-        other = tmp;
+        if (++l >= nl) break;
+        {
+            const bool last = l + 1 == nl;
+            uint8_t* gout = a.store_all ? a.layers + layer_off(a.tree_log, a.level_a - l) : (last ? a.last_out : nullptr);
+            quad_level<1>(QQ, x, quad < (cnt_a >> l), gout, (wg_base >> l) + quad, q, !last);
+        }
+        ++l;
     }
 }
 
 struct TopArgs {
     const uint8_t* in;  // 2^l_in hashes (array of structs)
-    uint32_t l_in;      // <= 11 supported; build_tree hands over at <= 9 (quad levels only)
+    uint32_t l_in;      // <= 11 supported; build_tree hands over at <= 9
     uint8_t* layers;    // non-null: store every produced level at its leaves-first offset
     uint32_t tree_log;
     uint8_t* root_out;  // non-null: also store the root here
@@ -564,9 +599,7 @@ struct TopArgs {
 __global__ __launch_bounds__(WG1_THREADS) void top_kernel(TopArgs a) {
     __shared__ __attribute__((aligned(16))) uint32_t S0[8 * (1024 + 4)];
     __shared__ __attribute__((aligned(16))) uint32_t S1[8 * (512 + 4)];
-    __shared__ __attribute__((aligned(16))) uint32_t QA[QA_WORDS];
-    __shared__ __attribute__((aligned(16))) uint32_t QB[QB_WORDS];
-    __shared__ uint32_t MB[2 * QS];
+    __shared__ __attribute__((aligned(16))) uint32_t QQ[2 * QBUF_WORDS];
     {
         const size_t off = (size_t)blockIdx.y * a.bstride;
         a.in += off;
@@ -575,45 +608,46 @@ __global__ __launch_bounds__(WG1_THREADS) void top_kernel(TopArgs a) {
         if (a.tr) a.tr += blockIdx.y;
     }
     const uint32_t t = threadIdx.x, q = t & 3;
-    QuadOffsets qo;
-    quad_offsets_init(qo, q);
-    WgRegions R{S0, S1, QA, QB};
+    QuadCtx x;
+    quad_ctx_init(x, t >> 2, q);
+    ChanRegs cr = {};
+    if (a.tr && t < 4) chan_prefetch(cr, a.tr, q);
     const uint32_t* root_lds;
     if (a.l_in == 0) {
-        if (t < 8) QA[t] = reinterpret_cast<const uint32_t*>(a.in)[t];
+        if (t < 8) QQ[t] = reinterpret_cast<const uint32_t*>(a.in)[t];
         __syncthreads();
-        root_lds = QA;
+        root_lds = QQ;
     } else {
         const uint32_t l = a.l_in - 1, cnt = 1u << l;
         uint8_t* gout = a.layers ? a.layers + layer_off(a.tree_log, l) : nullptr;
-        if (cnt >= 512) {
+        if (cnt >= 256) {
             for (uint32_t j = t; j < cnt; j += WG1_THREADS) {
                 uint32_t m[16], h[8];
                 load_children(a.in, j, m);
                 b2_merkle_block(m, h);
                 if (gout) store_hash(gout, j, h);
-                if (cnt >= 1024)
+                if (cnt >= 512)
                     lds_put(S0, cnt + 4, j, h);
                 else
-                    q_put_hash(QA, j, h);
+                    q_put_hash(QQ, j, h);
             }
             __syncthreads();
-            root_lds = wg_reduce(R, S0, S1, QA, QB, l, a.layers, a.tree_log, qo);
+            root_lds = wg_reduce(S0, S1, QQ, l, a.layers, a.tree_log, x);
         } else {
-            // children (2 cnt <= 512 hashes) from global into the quad layout, then quad levels all the way
-            const uint32_t* inw = reinterpret_cast<const uint32_t*>(a.in);
-            for (uint32_t e = t; e < 16 * cnt; e += WG1_THREADS) QA[QS * (e >> 3) + (e & 7)] = inw[e];
+            // children (2 cnt <= 256 hashes) from global into the quad layout, then quad levels all the way
+            q_load_hashes(QQ, a.in, 2 * cnt, t, WG1_THREADS);
             __syncthreads();
-            root_lds = wg_reduce(R, S0, S1, QA, QB, l + 1, a.layers, a.tree_log, qo);
+            root_lds = wg_reduce(S0, S1, QQ, l + 1, a.layers, a.tree_log, x);
         }
     }
     if (t < 4) {
+        const uint32_t root_lo = root_lds[q], root_hi = root_lds[4 + q];
         if (a.root_out) {
             uint32_t* ro = reinterpret_cast<uint32_t*>(a.root_out);
-            ro[q] = root_lds[q];
-            ro[4 + q] = root_lds[4 + q];
+            ro[q] = root_lo;
+            ro[4 + q] = root_hi;
         }
-        if (a.tr) channel_after_root_quad(a.tr, root_lds, MB, qo);
+        if (a.tr) channel_after_root_quad(a.tr, cr, root_lo, root_hi, QQ, x);
     }
 }
 
@@ -643,17 +677,19 @@ struct TailArgs {
 __global__ __launch_bounds__(WG1_THREADS) void tail_kernel(TailArgs a) {
     __shared__ __attribute__((aligned(16))) uint32_t S0[8 * (TAIL_CAP + 4)];
     __shared__ __attribute__((aligned(16))) uint32_t S1[8 * (TAIL_CAP / 2 + 4)];
-    __shared__ __attribute__((aligned(16))) uint32_t QA[QA_WORDS];
-    __shared__ __attribute__((aligned(16))) uint32_t QB[QB_WORDS];
-    __shared__ uint32_t MB[2 * QS];
+    __shared__ __attribute__((aligned(16))) uint32_t QQ[2 * QBUF_WORDS];
     __shared__ uint32_t s_alpha[4];
     uint32_t* const MSG = S0 + 4 * TAIL_CAP + 8;  // the upper half of S0 is free once the last layer is reached
     const uint32_t t = threadIdx.x, q = t & 3;
     const size_t boff = (size_t)blockIdx.y * a.bstride;  // this workgroup's blob
     DevTranscript* tr = a.tr + blockIdx.y;
-    QuadOffsets qo;
-    quad_offsets_init(qo, q);
-    WgRegions R{S0, S1, QA, QB};
+    QuadCtx x;
+    quad_ctx_init(x, t >> 2, q);
+    ChanRegs cr = {};
+    if (t < 4) {
+        chan_prefetch(cr, tr, q);
+        s_alpha[t] = tr->alpha[t];
+    }
 
     const uint32_t* src = reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(a.src) + boff);
     size_t src_stride = a.src_stride;
@@ -663,8 +699,7 @@ __global__ __launch_bounds__(WG1_THREADS) void tail_kernel(TailArgs a) {
     for (uint32_t kx = 0; kx < a.n_layers; kx++) {
         const uint32_t m_new = src_log - 1, cnt = 1u << m_new;
         const bool is_last = kx + 1 == a.n_layers;
-        if (t < 4) s_alpha[t] = tr->alpha[t];
-        __syncthreads();
+        __syncthreads();  // s_alpha of this layer (and, from the second layer on, the previous layer's values) are in place
         const QM31Mat alpha = qm_matrix({s_alpha[0], s_alpha[1], s_alpha[2], s_alpha[3]});
         // line layer of log size src_log sits on twiddle level n - 1 - src_log
         const uint32_t* itw_level = circle ? a.itw : a.itw + tw_level_offset_dev(a.n, a.n - 1 - src_log);
@@ -680,10 +715,10 @@ __global__ __launch_bounds__(WG1_THREADS) void tail_kernel(TailArgs a) {
                 uint32_t h[8];
                 leaf_hash(r.a, r.b, r.c, r.d, h);
                 store_hash(a.trees[kx] + boff, j, h);  // leaf layer sits at offset 0
-                if (cnt >= 1024)
+                if (cnt >= 512)
                     lds_put(S0, cnt + 4, j, h);
                 else
-                    q_put_hash(QA, j, h);
+                    q_put_hash(QQ, j, h);
             } else {
                 // keep the last layer in LDS for the interpolation: coordinate c of point j at S0[c * cnt + j]
                 S0[j] = r.a;
@@ -694,9 +729,11 @@ __global__ __launch_bounds__(WG1_THREADS) void tail_kernel(TailArgs a) {
         }
         __syncthreads();
         if (is_last) break;
-        const uint32_t* root_lds = wg_reduce(R, S0, S1, QA, QB, m_new, a.trees[kx] + boff, m_new, qo);
-        if (t < 4) channel_after_root_quad(tr, root_lds, MB, qo);
-        __syncthreads();
+        const uint32_t* root_lds = wg_reduce(S0, S1, QQ, m_new, a.trees[kx] + boff, m_new, x);
+        if (t < 4) {
+            const uint32_t root_lo = root_lds[q], root_hi = root_lds[4 + q];
+            s_alpha[t] = channel_after_root_quad(tr, cr, root_lo, root_hi, QQ, x);
+        }
         src = dstv;
         src_stride = cnt;
         src_log = m_new;
