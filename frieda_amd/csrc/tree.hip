@@ -547,6 +547,72 @@ __device__ uint32_t channel_after_root_quad(DevTranscript* tr, ChanRegs& cr, uin
 }
 
 // ------------------------------------------------------------------------------------------------
+// tree9: nine levels per launch for level-A sizes 2^8 .. 2^17 (the launches that cannot fill the chip)
+// ------------------------------------------------------------------------------------------------
+// One workgroup owns 256 consecutive level-A nodes and takes them all the way to one hash: levels of 256 and 128 nodes one
+// compression per lane (SoA LDS), the seven levels of 64 .. 1 nodes one compression per quad.  Such a launch is a pure
+// latency chain, so what counts is the number of dependent compressions at ~1.8 us (lane) or ~1 us (quad) and the number
+// of launches: a tree of 2^m leaves, m <= 17, is this launch plus the top kernel.
+constexpr uint32_t T9_LEVELS = 9;
+
+template <int MODE>
+__global__ __launch_bounds__(256) void tree9_kernel(TreeArgs a) {
+    __shared__ __attribute__((aligned(16))) uint32_t RA[8 * (256 + 4)];
+    __shared__ __attribute__((aligned(16))) uint32_t QQ[2 * QBUF_WORDS];
+    tree_args_of_blob(a);
+    const uint32_t t = threadIdx.x, q = t & 3, quad = t >> 2;
+    QuadCtx x;
+    quad_ctx_init(x, quad, q);
+    const size_t wg_base = (size_t)blockIdx.x * 256;  // the launcher guarantees 2^level_a >= 256
+    // ---- level A (256 nodes): one per lane ----
+    {
+        const size_t g = wg_base + t;
+        uint32_t h[8];
+        if (MODE == T_NODE) {
+            uint32_t m[16];
+            load_children(a.children, g, m);
+            b2_merkle_block(m, h);
+        } else if (MODE == T_LEAF4) {
+            leaf_hash(a.cols[g], a.cols[a.col_stride + g], a.cols[2 * a.col_stride + g], a.cols[3 * a.col_stride + g], h);
+        } else {
+            const QM31Mat alpha = qm_matrix({a.tr->alpha[0], a.tr->alpha[1], a.tr->alpha[2], a.tr->alpha[3]});
+            uint32_t it = (MODE == T_FOLD_CIRCLE) ? inv_circle_twiddle(a.itw, a.n, g, a.inv_init_y) : a.itw[g];
+            QM31 r = fold_pair(a.cols, a.col_stride, g, it, alpha);
+            a.out_vals[g] = r.a;
+            a.out_vals[a.out_stride + g] = r.b;
+            a.out_vals[2 * a.out_stride + g] = r.c;
+            a.out_vals[3 * a.out_stride + g] = r.d;
+            leaf_hash(r.a, r.b, r.c, r.d, h);
+        }
+        if (a.store_all) store_hash(a.layers + layer_off(a.tree_log, a.level_a), g, h);
+        lds_put(RA, 256 + 4, t, h);
+    }
+    __syncthreads();
+    // ---- level B (128 nodes): one per lane, results in the quad layout ----
+    if (t < 128) {
+        uint32_t m[16], h[8];
+        lds_children(RA, 256 + 4, t, m);
+        b2_merkle_block(m, h);
+        if (a.store_all) store_hash(a.layers + layer_off(a.tree_log, a.level_a - 1), (wg_base >> 1) + t, h);
+        q_put_hash(QQ, t, h);
+    }
+    __syncthreads();
+    // ---- levels of 64, 32, ..., 1 nodes: one per quad ----
+#pragma unroll
+    for (uint32_t l = 2; l < T9_LEVELS; l += 2) {
+        {
+            const bool last = l + 1 == T9_LEVELS;
+            uint8_t* gout = a.store_all ? a.layers + layer_off(a.tree_log, a.level_a - l) : (last ? a.last_out : nullptr);
+            quad_level<0>(QQ, x, quad < (256u >> l), gout, (wg_base >> l) + quad, q, !last);
+        }
+        if (l + 1 < T9_LEVELS) {
+            uint8_t* gout = a.store_all ? a.layers + layer_off(a.tree_log, a.level_a - (l + 1)) : nullptr;
+            quad_level<1>(QQ, x, quad < (256u >> (l + 1)), gout, (wg_base >> (l + 1)) + quad, q, true);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // tree7q: the narrow middle of a tree (<= 32768 level-A nodes) hashed by quads across many workgroups
 // ------------------------------------------------------------------------------------------------
 // One workgroup (64 quads) owns 64 consecutive level-A nodes and produces up to seven levels (64, 32, ..., 1 nodes), every
@@ -900,32 +966,55 @@ __global__ __launch_bounds__(256) void grind_dev_kernel(GrindArgs a) {
     }
 }
 
-// Launches with few level-A nodes cannot fill the chip and are latency-bound: they use 256-node workgroups (one hash per
-// thread and level, four times as many workgroups) instead of 1024-node ones.
-constexpr uint32_t T5_SMALL_LOG = 20;  // level_a below this: 256-node workgroups (measured: 17..19 are no faster)
-uint32_t tree5_units_log(uint32_t level_a) { return level_a < T5_SMALL_LOG ? 8u : (T5_UNITS == 1024 ? 10u : 9u); }
+// Which kernel produces level A (2^level_a nodes per blob, `batch` blobs per launch) and how many levels it yields:
+//   T_WIDE   tree5r, 1024-node workgroups, five levels: the launch fills the chip (>= 2^20 nodes in all, >= 1024 per blob)
+//   T_NINE   tree9, 256-node workgroups, nine levels: 2^8 .. 2^17 nodes per blob — a latency chain, fewest launches
+//   T_SMALL  tree5<256>, 256-node workgroups, five levels: everything else (2^18, 2^19: measured no faster with 1024-node
+//            workgroups; < 2^8: a partial workgroup)
+enum TreeKernel { T_WIDE, T_NINE, T_SMALL };
+constexpr uint32_t T5_WIDE_LOG = 20;
+constexpr uint32_t T9_MIN_LOG = 8, T9_MAX_LOG = 17;
 
-void launch_tree5(const Launch& L, int mode, const TreeArgs& a, const char* name, double alg_bytes) {
-    const size_t total = (size_t)1 << a.level_a;
-    // the register-subtree kernel uses 16-byte column accesses; anything unaligned (Level B callers may pass any pointers)
-    // takes the 256-unit kernel, which produces the same levels
-    const bool aligned16 = ((reinterpret_cast<uintptr_t>(a.cols) | reinterpret_cast<uintptr_t>(a.out_vals) | reinterpret_cast<uintptr_t>(a.itw) |
-                             (a.col_stride * 4) | (a.out_stride * 4)) & 15) == 0;
-    // a batch of small trees is as wide as one large tree: the register-subtree kernel once there are >= 2^20 level-A nodes in
-    // the launch and >= 1024 per blob (both kernels produce five levels from level_a >= 4 on)
+TreeKernel tree_kernel_for(uint32_t level_a, uint32_t batch, bool aligned16) {
     uint32_t batch_log = 0;
-    while ((2u << batch_log) <= L.batch) batch_log++;
-    const bool wide = a.level_a >= 10 && a.level_a + batch_log >= T5_SMALL_LOG;
-    const bool small = !wide || !aligned16;
-    const uint32_t units = small ? 256u : T5_UNITS;
+    while ((2u << batch_log) <= batch) batch_log++;
+    // the register-subtree kernel uses 16-byte column accesses; anything unaligned (Level B callers may pass any pointers)
+    // takes a 256-unit kernel, which produces the same hashes
+    if (aligned16 && level_a >= 10 && level_a + batch_log >= T5_WIDE_LOG) return T_WIDE;
+    if (level_a >= T9_MIN_LOG && level_a <= T9_MAX_LOG) return T_NINE;
+    return T_SMALL;
+}
+uint32_t tree_kernel_levels(TreeKernel k, uint32_t level_a) {
+    if (k == T_NINE) return T9_LEVELS;
+    const uint32_t in_wg = level_a < (k == T_WIDE ? 10u : 8u) ? level_a : (k == T_WIDE ? 10u : 8u);  // log2 of a workgroup's A nodes
+    return in_wg + 1 < T5_LEVELS ? in_wg + 1 : T5_LEVELS;
+}
+bool tree_args_aligned16(const TreeArgs& a) {
+    return ((reinterpret_cast<uintptr_t>(a.cols) | reinterpret_cast<uintptr_t>(a.out_vals) | reinterpret_cast<uintptr_t>(a.itw) |
+             (a.col_stride * 4) | (a.out_stride * 4)) & 15) == 0;
+}
+
+// launches level A (+ the levels its kernel yields) and returns the number of levels produced
+uint32_t launch_tree_a(const Launch& L, int mode, const TreeArgs& a, const char* name, double (*bytes_of)(int, uint32_t, uint32_t)) {
+    const size_t total = (size_t)1 << a.level_a;
+    const TreeKernel k = tree_kernel_for(a.level_a, L.batch, tree_args_aligned16(a));
+    const uint32_t levels = tree_kernel_levels(k, a.level_a);
+    const uint32_t units = k == T_WIDE ? T5_UNITS : 256u;
     const dim3 grid((unsigned)((total + units - 1) / units), L.batch);
-    Scope scope(L, name, alg_bytes);
-    if (small) {
+    Scope scope(L, name, bytes_of(mode, a.level_a, levels));
+    if (k == T_SMALL) {
         switch (mode) {
             case T_LEAF4: tree5_kernel<T_LEAF4, 256><<<grid, T5_THREADS, 0, L.stream>>>(a); break;
             case T_NODE: tree5_kernel<T_NODE, 256><<<grid, T5_THREADS, 0, L.stream>>>(a); break;
             case T_FOLD_CIRCLE: tree5_kernel<T_FOLD_CIRCLE, 256><<<grid, T5_THREADS, 0, L.stream>>>(a); break;
             default: tree5_kernel<T_FOLD_LINE, 256><<<grid, T5_THREADS, 0, L.stream>>>(a); break;
+        }
+    } else if (k == T_NINE) {
+        switch (mode) {
+            case T_LEAF4: tree9_kernel<T_LEAF4><<<grid, 256, 0, L.stream>>>(a); break;
+            case T_NODE: tree9_kernel<T_NODE><<<grid, 256, 0, L.stream>>>(a); break;
+            case T_FOLD_CIRCLE: tree9_kernel<T_FOLD_CIRCLE><<<grid, 256, 0, L.stream>>>(a); break;
+            default: tree9_kernel<T_FOLD_LINE><<<grid, 256, 0, L.stream>>>(a); break;
         }
     } else {
         switch (mode) {
@@ -935,13 +1024,7 @@ void launch_tree5(const Launch& L, int mode, const TreeArgs& a, const char* name
             default: tree5r_kernel<T_FOLD_LINE><<<grid, T5_THREADS, 0, L.stream>>>(a); break;
         }
     }
-}
-
-// levels produced by one tree5 launch whose level A has 2^level_a nodes
-uint32_t tree5_levels(uint32_t level_a) {
-    const uint32_t ul = tree5_units_log(level_a);
-    uint32_t in_wg = level_a < ul ? level_a : ul;  // log2 of the A nodes one workgroup owns
-    return in_wg + 1 < T5_LEVELS ? in_wg + 1 : T5_LEVELS;
+    return levels;
 }
 
 constexpr uint32_t TOP_MAX_LOG = 9;           // the top kernel starts from <= 512 hashes: quad levels only
@@ -968,13 +1051,13 @@ void build_tree(const Launch& L, int mode, TreeArgs a, uint32_t m, uint8_t* laye
     uint8_t* s0 = scratch;
     uint8_t* s1 = scratch ? scratch + ((size_t)32 << (m > 4 ? m - 4 : 0)) : nullptr;
     a.last_out = s0;
-    uint32_t lv = tree5_levels(m);
-    {
-        // level A: leaves (16 B columns in, 32 B out) or fold+leaves (32 B pair in, 16 B values + 32 B hash out)
-        double bytes = (mode == T_LEAF4 ? 48.0 : 80.0) * (double)((size_t)1 << m) + node_levels_bytes(m > 0 ? m - 1 : 0, lv - 1);
-        const char* nm = mode == T_LEAF4 ? "tree5_leaf" : (mode == T_FOLD_CIRCLE ? "tree5_fold_circle" : "tree5_fold_line");
-        launch_tree5(L, mode, a, nm, bytes);
-    }
+    // level A: leaves (16 B columns in, 32 B out) or fold+leaves (32 B pair in, 16 B values + 32 B hash out); nodes: 96 B each
+    auto bytes_of = [](int md, uint32_t la, uint32_t levels) -> double {
+        if (md == T_NODE) return node_levels_bytes(la, levels);
+        return (md == T_LEAF4 ? 48.0 : 80.0) * (double)((size_t)1 << la) + node_levels_bytes(la > 0 ? la - 1 : 0, levels - 1);
+    };
+    const char* nm = mode == T_LEAF4 ? "tree5_leaf" : (mode == T_FOLD_CIRCLE ? "tree5_fold_circle" : "tree5_fold_line");
+    const uint32_t lv = launch_tree_a(L, mode, a, nm, bytes_of);
     uint32_t cur = m - (lv - 1);  // lowest-index (smallest) level produced so far
     const uint8_t* cur_ptr = layers ? layers + merkle_layer_offset(m, cur) : s0;
     while (cur > TOP_MAX_LOG) {
@@ -991,8 +1074,7 @@ void build_tree(const Launch& L, int mode, TreeArgs a, uint32_t m, uint8_t* laye
             const dim3 grid((unsigned)((((size_t)1 << b.level_a) + T7Q_UNITS - 1) / T7Q_UNITS), L.batch);
             tree7q_kernel<<<grid, 256, 0, L.stream>>>(b);
         } else {
-            l2 = tree5_levels(cur - 1);
-            launch_tree5(L, T_NODE, b, "tree5_node", node_levels_bytes(cur - 1, l2));
+            l2 = launch_tree_a(L, T_NODE, b, "tree5_node", bytes_of);
         }
         cur = cur - l2;
         cur_ptr = layers ? layers + merkle_layer_offset(m, cur) : b.last_out;
