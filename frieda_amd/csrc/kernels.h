@@ -100,11 +100,13 @@ inline size_t merkle_layer_offset(uint32_t log_size, uint32_t layer_log) {
 }  // namespace k
 struct DevTranscript;
 namespace k {
-// tree of the first FRI layer (the 4 evaluation columns): every level kept in d_layers; when tr is non-null the finishing
-// kernel mixes the root into the device transcript and draws the folding alpha
+// tree of the first FRI layer (the 4 evaluation columns): every level above the leaf hashes kept in d_layers (the leaf hashes
+// themselves are not written: a FRI decommitment opens both members of every queried pair, so nothing ever reads them; the
+// slot in d_layers stays reserved and unwritten); when tr is non-null the finishing kernel mixes the root into the device
+// transcript and draws the folding alpha
 void tree_first_layer(const Launch& L, const uint32_t* cols, size_t stride, uint32_t m, uint8_t* d_layers, DevTranscript* tr);
 // fold the layer `src` (log size src_log; circle evaluation or line layer) with the alpha in tr into dst_vals and build the
-// tree of the folded layer in the same launches; finishes with the channel step
+// tree of the folded layer in the same launches (leaf hashes not written, as above); finishes with the channel step
 void fold_and_tree(const Launch& L, bool circle, const uint32_t* src, size_t src_stride, uint32_t src_log, uint32_t n,
                    const uint32_t* d_itw, DomainScalars ds, uint32_t* dst_vals, uint8_t* d_layers, DevTranscript* tr);
 // all remaining layers (each <= 2048 points) in one workgroup, ending with the last-layer interpolation + mix_felts

@@ -121,6 +121,8 @@ struct TreeArgs {
     uint8_t* layers;          // store_all: tree storage base
     uint8_t* last_out;        // !store_all: destination of the last produced level (indexed by global node index)
     int store_all;
+    int skip_a;               // store_all, but level A itself is not written (nothing reads the leaf hashes of a FRI layer's tree:
+                              // a decommitment opens both members of every queried pair, so the verifier derives them from values)
     size_t bstride;           // batch: bytes between consecutive blobs' workspaces (blob = blockIdx.y); tr is an array
 };
 
@@ -155,7 +157,7 @@ __global__ __launch_bounds__(T5_THREADS) void tree5_kernel(TreeArgs a) {
     // ---- level A ----
     {
         const bool last = nl == 1;
-        uint8_t* gout = a.store_all ? a.layers + layer_off(a.tree_log, a.level_a) : (last ? a.last_out : nullptr);
+        uint8_t* gout = a.store_all ? (a.skip_a ? nullptr : a.layers + layer_off(a.tree_log, a.level_a)) : (last ? a.last_out : nullptr);
         for (uint32_t j = t; j < cnt_a; j += T5_THREADS) {
             const size_t g = wg_base + j;
             uint32_t h[8];
@@ -212,7 +214,7 @@ __global__ __launch_bounds__(T5_THREADS) void tree5r_kernel(TreeArgs a) {
     const uint32_t t = threadIdx.x;
     const size_t wg_base = (size_t)blockIdx.x * 1024;  // the launcher guarantees 2^level_a >= 1024
     const size_t g0 = wg_base + 4 * t;
-    uint8_t* out_a = a.store_all ? a.layers + layer_off(a.tree_log, a.level_a) : nullptr;
+    uint8_t* out_a = a.store_all && !a.skip_a ? a.layers + layer_off(a.tree_log, a.level_a) : nullptr;
     uint8_t* out_b = a.store_all ? a.layers + layer_off(a.tree_log, a.level_a - 1) : nullptr;
     uint8_t* out_c = a.store_all ? a.layers + layer_off(a.tree_log, a.level_a - 2) : nullptr;
     uint8_t* out_d = a.store_all ? a.layers + layer_off(a.tree_log, a.level_a - 3) : nullptr;
@@ -584,7 +586,7 @@ __global__ __launch_bounds__(256) void tree9_kernel(TreeArgs a) {
             a.out_vals[3 * a.out_stride + g] = r.d;
             leaf_hash(r.a, r.b, r.c, r.d, h);
         }
-        if (a.store_all) store_hash(a.layers + layer_off(a.tree_log, a.level_a), g, h);
+        if (a.store_all && !a.skip_a) store_hash(a.layers + layer_off(a.tree_log, a.level_a), g, h);
         lds_put(RA, 256 + 4, t, h);
     }
     __syncthreads();
@@ -1062,6 +1064,7 @@ void build_tree(const Launch& L, int mode, TreeArgs a, uint32_t m, uint8_t* laye
     const uint8_t* cur_ptr = layers ? layers + merkle_layer_offset(m, cur) : s0;
     while (cur > TOP_MAX_LOG) {
         TreeArgs b = a;
+        b.skip_a = 0;
         b.level_a = cur - 1;
         b.children = cur_ptr;
         b.last_out = (cur_ptr == s0) ? s1 : s0;
@@ -1120,6 +1123,7 @@ void tree_first_layer(const Launch& L, const uint32_t* cols, size_t stride, uint
     TreeArgs a{};
     a.cols = cols;
     a.col_stride = stride;
+    a.skip_a = m >= 1;  // the prover never reads the leaf hashes (plan_merkle_decommit, prover.cpp)
     build_tree(L, T_LEAF4, a, m, layers, nullptr, nullptr, tr);
 }
 
@@ -1135,6 +1139,7 @@ void fold_and_tree(const Launch& L, bool circle, const uint32_t* src, size_t src
     a.n = n;
     a.inv_init_y = ds.inv_init_y;
     a.tr = tr;
+    a.skip_a = m >= 1;
     build_tree(L, circle ? T_FOLD_CIRCLE : T_FOLD_LINE, a, m, layers, nullptr, nullptr, tr);
 }
 
