@@ -57,6 +57,11 @@ __global__ __launch_bounds__(256) void rate_kernel(uint32_t* out, int iters) {
                 if (OP == 37) asm volatile("v_mad_i32_i24 %0, %0, %1, %2" : "+v"(x) : "v"(y), "v"(z));
                 if (OP == 38) asm volatile("v_mul_lo_u16 %0, %0, %1" : "+v"(x) : "v"(y));
                 if (OP == 39) asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(x) : "v"(y), "v"(z));
+                // pairs on live (non-decaying) data: a shift is full rate if the pair costs two full-rate slots, not three
+                if (OP == 40) asm volatile("v_lshrrev_b32 %0, 7, %1\n\tv_xor_b32 %0, %0, %2" : "+v"(x) : "v"(y), "v"(z));
+                if (OP == 41) asm volatile("v_lshlrev_b32 %0, 7, %1\n\tv_xor_b32 %0, %0, %2" : "+v"(x) : "v"(y), "v"(z));
+                if (OP == 42) asm volatile("v_alignbit_b32 %0, %1, %1, 7\n\tv_xor_b32 %0, %0, %2" : "+v"(x) : "v"(y), "v"(z));
+                if (OP == 43) asm volatile("v_xor_b32 %0, %0, %1\n\tv_xor_b32 %0, %0, %2" : "+v"(x) : "v"(y), "v"(z));
             }
         }
     }
@@ -128,5 +133,9 @@ int main() {
     run<38>("v_mul_lo_u16");
     run<35>("v_max_u32");
     run<36>("v_subrev_u32");
+    run<43>("pair: v_xor + v_xor (per pair)");
+    run<40>("pair: v_lshrrev_b32 + v_xor (per pair)");
+    run<41>("pair: v_lshlrev_b32 + v_xor (per pair)");
+    run<42>("pair: v_alignbit_b32 + v_xor (per pair)");
     return 0;
 }
