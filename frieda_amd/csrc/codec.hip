@@ -6,7 +6,8 @@
 //
 // Layout: four felts are exactly 120 bits = 15 bytes, so thread t owns bytes [15t, 15t+15) and writes felts 4t..4t+3 as one
 // 16-byte store.  A workgroup's 256 windows cover 3840 contiguous bytes = 960 aligned dwords: they are staged through LDS
-// with coalesced dword loads, then every thread funnel-shifts its own 15-byte window out of five consecutive LDS words.
+// with coalesced 16-byte loads (dword loads at the ragged end of the blob), then every thread funnel-shifts its own 15-byte
+// window out of five consecutive LDS words.
 // HBM-bound: 3.75 B read + 4 B written per felt.
 #include <hip/hip_runtime.h>
 
@@ -46,9 +47,17 @@ __global__ __launch_bounds__(256) void unpack30_aligned_kernel(const uint8_t* __
     out = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(out) + blockIdx.y * out_bstride);
     // the workgroup's 256 quads cover bytes [3840 b, 3840 (b + 1)) = 960 aligned dwords: stage them through LDS with
     // coalesced loads, then every thread funnel-shifts its own 15-byte window
-    __shared__ uint32_t stage[964];
+    __shared__ __attribute__((aligned(16))) uint32_t stage[964];
     const size_t d_base = (size_t)blockIdx.x * 960;
-    for (uint32_t i = threadIdx.x; i < 964; i += 256) stage[i] = load_dword_guarded(in, len, d_base + i);
+    if ((reinterpret_cast<uintptr_t>(in) & 15) == 0 && (d_base + 964) * 4 <= len) {
+        // interior workgroup: 240 16-byte loads (3840 = 16 * 240, so every workgroup's window starts 16-byte aligned) + 1 dword
+        if (threadIdx.x < 240)
+            reinterpret_cast<uint4*>(stage)[threadIdx.x] = reinterpret_cast<const uint4*>(in + 4 * d_base)[threadIdx.x];
+        else if (threadIdx.x < 244)
+            stage[960 + (threadIdx.x - 240)] = reinterpret_cast<const uint32_t*>(in)[d_base + 960 + (threadIdx.x - 240)];
+    } else {
+        for (uint32_t i = threadIdx.x; i < 964; i += 256) stage[i] = load_dword_guarded(in, len, d_base + i);
+    }
     __syncthreads();
     size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (t >= n_quads) return;

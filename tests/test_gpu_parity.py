@@ -82,7 +82,8 @@ def test_circle_evaluate(gpu_ctx, oracle, L, n):
     assert np.array_equal(got, exp)
 
 
-@pytest.mark.parametrize("m", [0, 1, 2, 5, 10, 11, 12, 16])
+# 7/8/9 and 17/18: either side of the nine-levels-per-launch kernel's range; 21, 22: that kernel in node mode above a wide launch
+@pytest.mark.parametrize("m", [0, 1, 2, 5, 7, 8, 9, 10, 11, 12, 16, 17, 18, 21, 22])
 def test_merkle_commit_all_layers(gpu_ctx, oracle, m):
     rng = np.random.default_rng(200 + m)
     cols = rand_m31(rng, (4, 1 << m))
