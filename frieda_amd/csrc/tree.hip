@@ -975,7 +975,15 @@ __global__ __launch_bounds__(256) void grind_dev_kernel(GrindArgs a) {
 //            workgroups; < 2^8: a partial workgroup)
 enum TreeKernel { T_WIDE, T_NINE, T_SMALL };
 constexpr uint32_t T5_WIDE_LOG = 20;
-constexpr uint32_t T9_MIN_LOG = 8, T9_MAX_LOG = 17;
+constexpr uint32_t T9_MIN_LOG = 8;
+uint32_t env_knob(const char* name, uint32_t dflt, uint32_t lo, uint32_t hi) {
+    const char* e = getenv(name);
+    const uint32_t v = e ? (uint32_t)atoi(e) : dflt;
+    return v >= lo && v <= hi ? v : dflt;
+}
+// tuning knobs (defaults = measured best): largest level-A size of the nine-level kernel; largest hand-over size of the top kernel
+const uint32_t T9_MAX_LOG = env_knob("FRIEDA_T9_MAX_LOG", 17, 8, 19);
+const uint32_t TOP_MAX_LOG = env_knob("FRIEDA_TOP_MAX_LOG", 9, 9, 11);
 
 TreeKernel tree_kernel_for(uint32_t level_a, uint32_t batch, bool aligned16) {
     uint32_t batch_log = 0;
@@ -1029,7 +1037,6 @@ uint32_t launch_tree_a(const Launch& L, int mode, const TreeArgs& a, const char*
     return levels;
 }
 
-constexpr uint32_t TOP_MAX_LOG = 9;           // the top kernel starts from <= 512 hashes: quad levels only
 constexpr uint32_t T7Q_MAX_LEVEL_A = 15;  // level-A sizes up to 2^15 nodes go through tree7q
 
 // algorithmic bytes of `levels` consecutive node levels whose first (largest) has 2^la nodes: 64 B in + 32 B out each
