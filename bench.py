@@ -150,22 +150,31 @@ def main():
     cfg = frieda_amd.PcsConfig(frieda_amd.FriConfig(4, 0, 20), 20)  # benches/proof.rs:5-12
     seed = blob_len  # benches/proof.rs:23: Some(data.len())
     roots_dev = torch.zeros(32, dtype=torch.uint8, device="cuda")
-    gathered = torch.zeros(32 * world, dtype=torch.uint8, device="cuda")
+    # The blobs are independent: nothing is exchanged while they are processed.  Each rank keeps the roots of its K blobs and the
+    # ranks exchange them once, after the last blob and inside the timed region: one all_gather (RCCL) of K x 32 bytes per rank.
+    K = args.steps
+    roots_all = torch.zeros(32 * K, dtype=torch.uint8, device="cuda")
+    gathered = torch.zeros(32 * K * world, dtype=torch.uint8, device="cuda")
+    host_roots = []
 
-    def step():
+    def step(i=None):
         if args.workload == "prove":
             root, proof = ctx.commit_and_generate_proof_device(blob.data_ptr(), blob_len, seed, cfg)
-            if use_dist:
-                roots_dev.copy_(torch.frombuffer(bytearray(root), dtype=torch.uint8))
+            if i is not None:
+                host_roots.append(root)
             return root, proof
-        ctx.commit_device(blob.data_ptr(), blob_len, 4, roots_dev.data_ptr())
-        if use_dist:
-            ctx.synchronize()
+        dst = roots_dev.data_ptr() if i is None else roots_all.data_ptr() + 32 * i
+        ctx.commit_device(blob.data_ptr(), blob_len, 4, dst)
         return None, None
 
     def gather_roots():
-        if use_dist:
-            dist.all_gather_into_tensor(gathered, roots_dev)
+        if not use_dist:
+            return
+        if args.workload == "prove":
+            roots_all.copy_(torch.frombuffer(bytearray(b"".join(host_roots)), dtype=torch.uint8))
+        else:
+            ctx.synchronize()  # the roots were written on the ctx stream; the collective runs on torch's
+        dist.all_gather_into_tensor(gathered, roots_all)
 
     def fence():
         torch.cuda.synchronize()
@@ -181,21 +190,25 @@ def main():
     last = (None, None)
     for _ in range(args.warmup):
         last = step()
-        gather_roots()
+    if use_dist:
+        dist.all_gather_into_tensor(gathered, roots_all)  # warm the collective (communicator set-up happens on first use)
     fence()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        last = step()
-        gather_roots()
+    for i in range(K):
+        last = step(i)
+    gather_roots()
     fence()
     dt = time.perf_counter() - t0
     if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        # every rank now holds every root: rank r's own root must sit in slot r
+        # every rank now holds every root: rank r's own K roots must sit in slot r
         torch.cuda.synchronize()
-        assert bytes(gathered[32 * rank : 32 * rank + 32].cpu().numpy()) == bytes(roots_dev.cpu().numpy()), "root gather mismatch"
+        mine = bytes(gathered[32 * K * rank : 32 * K * (rank + 1)].cpu().numpy())
+        assert mine == bytes(roots_all.cpu().numpy()), "root gather mismatch"
+        if args.workload == "prove":
+            assert mine == b"".join(host_roots)
 
     # correctness gate on what was just timed: the proof verifies and its first root equals commit()'s
     if args.workload == "prove":
@@ -206,7 +219,7 @@ def main():
         assert bytes(roots_dev.cpu().numpy()) == root, "first FRI root != commit() root"
     else:
         ctx.synchronize()
-        root = bytes(roots_dev.cpu().numpy())
+        root = bytes(roots_all[32 * (K - 1) :].cpu().numpy())
 
     host_phases = ctx.last_prove_phases() if args.workload == "prove" else None
     elems = 4.0 * (1 << n)
@@ -337,7 +350,7 @@ def main():
             "log_blowup_factor": 4,
             "blob_bytes": blob_len,
             "pcs_config": {"pow_bits": 20, "log_last_layer_degree_bound": 0, "n_queries": 20},
-            "parallelism": f"{world} independent blobs, one per GPU; all_gather of 32-byte roots",
+            "parallelism": f"{world} independent blobs per step, one per GPU; one all_gather of the K x 32-byte roots per rank after the last step",
             "twiddles": "regenerated per call" if args.no_twiddle_cache else "cached per context",
         },
         "roofline": roofline,
