@@ -104,7 +104,10 @@ namespace k {
 // themselves are not written: a FRI decommitment opens both members of every queried pair, so nothing ever reads them; the
 // slot in d_layers stays reserved and unwritten); when tr is non-null the finishing kernel mixes the root into the device
 // transcript and draws the folding alpha
-void tree_first_layer(const Launch& L, const uint32_t* cols, size_t stride, uint32_t m, uint8_t* d_layers, DevTranscript* tr);
+// tr_init (optional): the initial transcript of every blob in pinned host memory (blob b at tr_init + b * tr_init_pitch bytes);
+// the finishing kernel reads it from there and initialises the device transcript itself — no copy in the stream
+void tree_first_layer(const Launch& L, const uint32_t* cols, size_t stride, uint32_t m, uint8_t* d_layers, DevTranscript* tr,
+                      const DevTranscript* tr_init = nullptr, size_t tr_init_pitch = 0);
 // fold the layer `src` (log size src_log; circle evaluation or line layer) with the alpha in tr into dst_vals and build the
 // tree of the folded layer in the same launches (leaf hashes not written, as above); finishes with the channel step
 void fold_and_tree(const Launch& L, bool circle, const uint32_t* src, size_t src_stride, uint32_t src_log, uint32_t n,
@@ -113,10 +116,11 @@ void fold_and_tree(const Launch& L, bool circle, const uint32_t* src, size_t src
 constexpr uint32_t TAIL_LOG = 11;
 void fri_tail(const Launch& L, const uint32_t* src, size_t src_stride, uint32_t src_log, bool src_is_circle, uint32_t n,
               const uint32_t* d_itw, DomainScalars ds, uint32_t last_log, uint32_t last, uint32_t n_layers, uint32_t* const* vals,
-              uint8_t* const* trees, DevTranscript* tr);
+              uint8_t* const* trees, DevTranscript* tr, uint32_t* d_gnext = nullptr);
 // proof-of-work scan keyed by tr->ch.digest; atomicMin into tr->nonce
-// d_next: L.batch words of scratch (the per-blob window counters; zeroed here)
-void grind_dev(const Launch& L, DevTranscript* tr, uint32_t* d_next, uint32_t pow_bits, uint64_t base, uint64_t count);
+// d_next: L.batch words of scratch (the per-blob window counters; zeroed here unless next_zeroed: fri_tail did it)
+void grind_dev(const Launch& L, DevTranscript* tr, uint32_t* d_next, uint32_t pow_bits, uint64_t base, uint64_t count,
+               bool next_zeroed = false);
 
 // ---- fri.hip ----
 struct Alpha {

@@ -448,13 +448,11 @@ int prove_begin_batch(Ctx* ctx, const uint8_t* data, size_t data_stride, size_t 
                 ht->nonce = ~0ull;
                 ht->draw_bound = ctx->test_draw_bound;
             }
-            if (count == 1)
-                FR_HIP(ctx, hipMemcpyAsync(d_tr, ctx->pinned, hdr, hipMemcpyHostToDevice, s));
-            else
-                FR_HIP(ctx, hipMemcpy2DAsync(d_tr, sizeof(DevTranscript), ctx->pinned, tr_host_pitch, hdr, count, hipMemcpyHostToDevice, s));
+            // no copy in the stream: the kernel that finishes the first tree reads these few words from the pinned block itself
+            // (the block is next written by the transcript download behind the grind, i.e. after that kernel)
         }
         // FriProver::commit_first_layer
-        k::tree_first_layer(LN, eval, N, n, A + first.o_tree, d_tr);
+        k::tree_first_layer(LN, eval, N, n, A + first.o_tree, d_tr, reinterpret_cast<const DevTranscript*>(ctx->pinned), tr_host_pitch);
         // FriProver::commit_inner_layers: layers above 2^11 points, one fused fold + tree each
         const FriLayerDev* cur = &first;
         bool circle = true;
@@ -484,8 +482,9 @@ int prove_begin_batch(Ctx* ctx, const uint8_t* data, size_t data_stride, size_t 
         }
         tvals[n_tail - 1] = reinterpret_cast<uint32_t*>(A + o_lastv);
         ttrees[n_tail - 1] = nullptr;
+        uint32_t* d_gnext = reinterpret_cast<uint32_t*>(A + J.o_gnext);
         k::fri_tail(LN, cols(*cur, 0), (size_t)1 << cur->log, cur->log, circle, n, tw.d_itw, tw.ds, last_log, last, n_tail, tvals, ttrees,
-                    d_tr);
+                    d_tr, d_gnext);
         // grind (src/proof.rs:58), keyed by the digest now sitting in the device transcript: first chunk + transcript download
         J.grind_base = 0;
         // first range: 16x the expected search (a miss has probability e^-16; workgroups without work leave at once)
@@ -494,7 +493,7 @@ int prove_begin_batch(Ctx* ctx, const uint8_t* data, size_t data_stride, size_t 
             const int v = atoi(e);
             if (v >= 8 && v <= 40) J.grind_chunk = (uint64_t)1 << v;
         }
-        k::grind_dev(LN, d_tr, reinterpret_cast<uint32_t*>(A + J.o_gnext), cfg.pow_bits, J.grind_base, J.grind_chunk);
+        k::grind_dev(LN, d_tr, d_gnext, cfg.pow_bits, J.grind_base, J.grind_chunk, /*next_zeroed=*/true);
         rc = download_transcripts(ctx, J);
         if (rc) return rc;
         FR_HIP(ctx, hipGetLastError());

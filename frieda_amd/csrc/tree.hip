@@ -493,12 +493,14 @@ struct ChanRegs {
     uint32_t dg_lo, dg_hi;  // digest words q and 4 + q
     uint32_t bound;         // draw_felt acceptance bound
     uint32_t n_roots;
+    uint32_t n_chal;        // Channel::n_challenges
 };
 __device__ __forceinline__ void chan_prefetch(ChanRegs& cr, const DevTranscript* tr, uint32_t q) {
     cr.dg_lo = tr->ch.digest[q];
     cr.dg_hi = tr->ch.digest[4 + q];
     cr.bound = tr->draw_bound;
     cr.n_roots = tr->n_roots;
+    cr.n_chal = tr->ch.n_challenges;
 }
 __device__ uint32_t channel_after_root_quad(DevTranscript* tr, ChanRegs& cr, uint32_t root_lo, uint32_t root_hi, uint32_t* QQ,
                                             const QuadCtx& x) {
@@ -538,13 +540,14 @@ __device__ uint32_t channel_after_root_quad(DevTranscript* tr, ChanRegs& cr, uin
         tr->alphas[k][q] = al;
     }
     if (q == 0) {
-        tr->ch.n_challenges += 1;
+        tr->ch.n_challenges = cr.n_chal + 1;
         tr->ch.n_sent = n_sent;
         tr->n_roots = k + 1;
     }
     cr.dg_lo = dg.lo;
     cr.dg_hi = dg.hi;
     cr.n_roots = k + 1;
+    cr.n_chal += 1;
     return al;
 }
 
@@ -662,6 +665,10 @@ struct TopArgs {
     uint8_t* root_out;  // non-null: also store the root here
     DevTranscript* tr;  // non-null: mix the root and draw the next alpha
     size_t bstride;     // batch: bytes between blobs' workspaces (blob = blockIdx.y); tr is an array
+    // non-null (first tree of a proof): the initial transcript, read straight from pinned host memory at kernel start (blob b at
+    // tr_init + b * tr_init_pitch bytes) — the device transcript is initialised from it here instead of by a copy in the stream
+    const DevTranscript* tr_init;
+    size_t tr_init_pitch;
 };
 
 __global__ __launch_bounds__(WG1_THREADS) void top_kernel(TopArgs a) {
@@ -679,7 +686,19 @@ __global__ __launch_bounds__(WG1_THREADS) void top_kernel(TopArgs a) {
     QuadCtx x;
     quad_ctx_init(x, t >> 2, q);
     ChanRegs cr = {};
-    if (a.tr && t < 4) chan_prefetch(cr, a.tr, q);
+    if (a.tr && t < 4) {
+        if (a.tr_init) {
+            const DevTranscript* src =
+                reinterpret_cast<const DevTranscript*>(reinterpret_cast<const char*>(a.tr_init) + (size_t)blockIdx.y * a.tr_init_pitch);
+            chan_prefetch(cr, src, q);
+            if (q == 0) a.tr->status = 0;
+            if (q == 1) a.tr->nonce = ~0ull;
+            if (q == 2) a.tr->n_last_poly = 0;
+            if (q == 3) a.tr->draw_bound = cr.bound;
+        } else {
+            chan_prefetch(cr, a.tr, q);
+        }
+    }
     const uint32_t* root_lds;
     if (a.l_in == 0) {
         if (t < 8) QQ[t] = reinterpret_cast<const uint32_t*>(a.in)[t];
@@ -739,7 +758,8 @@ struct TailArgs {
     uint32_t* vals[TAIL_MAX_LAYERS];
     uint8_t* trees[TAIL_MAX_LAYERS];
     DevTranscript* tr;
-    size_t bstride;  // batch: bytes between blobs' workspaces (blob = blockIdx.y); tr is an array
+    size_t bstride;   // batch: bytes between blobs' workspaces (blob = blockIdx.y); tr is an array
+    uint32_t* gnext;  // non-null: the grind's per-blob window counters, zeroed here for the grind launch that follows
 };
 
 __global__ __launch_bounds__(WG1_THREADS) void tail_kernel(TailArgs a) {
@@ -758,6 +778,7 @@ __global__ __launch_bounds__(WG1_THREADS) void tail_kernel(TailArgs a) {
         chan_prefetch(cr, tr, q);
         s_alpha[t] = tr->alpha[t];
     }
+    if (t == 4 && a.gnext) a.gnext[blockIdx.y] = 0;
 
     const uint32_t* src = reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(a.src) + boff);
     size_t src_stride = a.src_stride;
@@ -1051,7 +1072,7 @@ double node_levels_bytes(uint32_t la, uint32_t levels) {
 // Builds the tree of a layer whose level A is produced by `mode`; finishes with the root (and the channel step when tr).
 // `layers` non-null = keep every level (leaves-first); else only the root survives and `scratch` (>= 2 * 32 * 2^(m-4) B) is used.
 void build_tree(const Launch& L, int mode, TreeArgs a, uint32_t m, uint8_t* layers, uint8_t* scratch, uint8_t* root_out,
-                DevTranscript* tr) {
+                DevTranscript* tr, const DevTranscript* tr_init = nullptr, size_t tr_init_pitch = 0) {
     a.level_a = m;
     a.tree_log = m;
     a.layers = layers;
@@ -1097,6 +1118,8 @@ void build_tree(const Launch& L, int mode, TreeArgs a, uint32_t m, uint8_t* laye
     tp.root_out = root_out;
     tp.tr = tr;
     tp.bstride = L.bstride;
+    tp.tr_init = tr_init;
+    tp.tr_init_pitch = tr_init_pitch;
     {
         Scope scope(L, "tree_top", node_levels_bytes(cur > 0 ? cur - 1 : 0, cur));
         top_kernel<<<dim3(1, L.batch), WG1_THREADS, 0, L.stream>>>(tp);
@@ -1126,12 +1149,13 @@ void merkle_root4(const Launch& L, const uint32_t* c0, const uint32_t* c1, const
     build_tree(L, T_LEAF4, a, m, nullptr, d_scratch, d_root, nullptr);
 }
 
-void tree_first_layer(const Launch& L, const uint32_t* cols, size_t stride, uint32_t m, uint8_t* layers, DevTranscript* tr) {
+void tree_first_layer(const Launch& L, const uint32_t* cols, size_t stride, uint32_t m, uint8_t* layers, DevTranscript* tr,
+                      const DevTranscript* tr_init, size_t tr_init_pitch) {
     TreeArgs a{};
     a.cols = cols;
     a.col_stride = stride;
     a.skip_a = m >= 1;  // the prover never reads the leaf hashes (plan_merkle_decommit, prover.cpp)
-    build_tree(L, T_LEAF4, a, m, layers, nullptr, nullptr, tr);
+    build_tree(L, T_LEAF4, a, m, layers, nullptr, nullptr, tr, tr_init, tr_init_pitch);
 }
 
 void fold_and_tree(const Launch& L, bool circle, const uint32_t* src, size_t src_stride, uint32_t src_log, uint32_t n,
@@ -1152,8 +1176,9 @@ void fold_and_tree(const Launch& L, bool circle, const uint32_t* src, size_t src
 
 void fri_tail(const Launch& L, const uint32_t* src, size_t src_stride, uint32_t src_log, bool src_is_circle, uint32_t n,
               const uint32_t* d_itw, DomainScalars ds, uint32_t last_log, uint32_t last, uint32_t n_layers, uint32_t* const* vals,
-              uint8_t* const* trees, DevTranscript* tr) {
+              uint8_t* const* trees, DevTranscript* tr, uint32_t* d_gnext) {
     TailArgs a{};
+    a.gnext = d_gnext;
     a.src = src;
     a.src_stride = src_stride;
     a.src_log = src_log;
@@ -1176,7 +1201,7 @@ void fri_tail(const Launch& L, const uint32_t* src, size_t src_stride, uint32_t 
     tail_kernel<<<dim3(1, L.batch), WG1_THREADS, 0, L.stream>>>(a);
 }
 
-void grind_dev(const Launch& L, DevTranscript* tr, uint32_t* d_next, uint32_t pow_bits, uint64_t base, uint64_t count) {
+void grind_dev(const Launch& L, DevTranscript* tr, uint32_t* d_next, uint32_t pow_bits, uint64_t base, uint64_t count, bool next_zeroed) {
     GrindArgs a{};
     a.tr = tr;
     a.next = d_next;
@@ -1187,7 +1212,7 @@ void grind_dev(const Launch& L, DevTranscript* tr, uint32_t* d_next, uint32_t po
     a.n_windows = nwin > 0xFFFF0000ull ? 0xFFFF0000u : (uint32_t)nwin;
     if (a.n_windows == 0) return;
     Scope scope(L, "grind", 0.0);
-    (void)hipMemsetAsync(d_next, 0, sizeof(uint32_t) * L.batch, L.stream);
+    if (!next_zeroed) (void)hipMemsetAsync(d_next, 0, sizeof(uint32_t) * L.batch, L.stream);
     // workgroups in flight: the chip holds 2048 (8 per CU); a lone blob gets no more than cover about half the expected search
     // (2^pow_bits nonces), so that the windows in flight when the first hit arrives are not mostly beyond it
     uint64_t want = (((uint64_t)1 << (pow_bits > 40 ? 40 : pow_bits)) / 2 / GRIND_WINDOW) * L.batch;
