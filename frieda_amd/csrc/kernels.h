@@ -122,6 +122,29 @@ void fri_tail(const Launch& L, const uint32_t* src, size_t src_stride, uint32_t 
 void grind_dev(const Launch& L, DevTranscript* tr, uint32_t* d_next, uint32_t pow_bits, uint64_t base, uint64_t count,
                bool next_zeroed = false);
 
+// ---- decommit.hip ----
+// Query sampling + all openings of a proof in one launch behind the grind (src/proof.rs:59-66).  Per blob the kernel writes,
+// into `out + blob * out_stride`:  a header of u32 words [status, n_unique_queries, n_words, n_hashes, |E_1| .. |E_n|], the words
+// at words_off (evaluations, then every layer's fri_witness) and the 32-byte hashes at hashes_off (every layer's hash_witness),
+// all in proof order.  Layer li has n_witness = |E_{li+1}| and n_hashes = |E_{li+2}| + ... + |E_n|.
+constexpr uint32_t DECOMMIT_MAX_QUERIES = 1024;
+constexpr uint32_t DECOMMIT_MAX_LOG_DOMAIN = 27;
+constexpr uint32_t DECOMMIT_MAX_LAYERS = 40;
+constexpr uint32_t DECOMMIT_HEADER_BYTES = 256;
+enum DecommitStatus : uint32_t { DECOMMIT_OK = 0, DECOMMIT_NO_NONCE = 1, DECOMMIT_OVERFLOW = 2 };
+struct DecommitArgs {
+    const DevTranscript* tr;  // array over the blobs: channel state after mix_felts, nonce from the grind
+    uint32_t n, n_layers, n_queries;
+    size_t bstride;     // bytes between consecutive blobs' workspaces
+    uint8_t* out;       // device-visible (normally pinned host) memory
+    size_t out_stride;  // bytes between consecutive blobs' output regions
+    size_t words_off, hashes_off;
+    uint32_t max_words, max_hashes;  // capacity of the two regions (u32 words / hashes) per blob
+    const uint32_t* vals[DECOMMIT_MAX_LAYERS];  // blob 0's layers: 4 columns of 2^(n - li) words, column stride 2^(n - li)
+    const uint8_t* trees[DECOMMIT_MAX_LAYERS];  // their trees (leaves-first layout)
+};
+void decommit(const Launch& L, const DecommitArgs& a, uint32_t wgs_per_blob);
+
 // ---- fri.hip ----
 struct Alpha {
     uint32_t v[4];

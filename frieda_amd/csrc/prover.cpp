@@ -292,6 +292,10 @@ struct ProveJob {
     size_t o_lastv = 0, o_nonce = 0, o_tr = 0, o_gnext = 0, o_widx = 0, o_hidx = 0, o_wout = 0, o_hout = 0;
     size_t max_words = 0, max_hashes = 0, tr_host_pitch = 0;
     bool dev_channel = false;
+    // openings on the device (decommit.hip): per-blob output regions in the pinned block behind the transcript summaries
+    bool dev_decommit = false;
+    size_t dec_off = 0, dec_stride = 0, dec_words_off = 0, dec_hashes_off = 0;
+    uint32_t dec_max_words = 0, dec_max_hashes = 0;
     // a batch of `count` blobs of one shape: blob b's workspace is blob 0's shifted by b * bstride bytes; the transcripts
     // (o_tr) and the gather regions sit behind the workspaces
     uint32_t count = 1;
@@ -323,6 +327,32 @@ static int download_transcripts(Ctx* ctx, const ProveJob& J) {
         FR_HIP(ctx, hipMemcpy2DAsync(ctx->pinned, J.tr_host_pitch, d_tr, sizeof(DevTranscript), bytes, J.count, hipMemcpyDeviceToHost, ctx->stream));
     }
     return FRIEDA_OK;
+}
+
+// decommit.hip over all blobs of the job: reads the device transcripts (nonce, channel) and the layers, writes the pinned block
+static void launch_decommit(Ctx* ctx, const ProveJob& J, const k::Launch& LN) {
+    uint8_t* A = ctx->arena;
+    k::DecommitArgs a{};
+    a.tr = reinterpret_cast<const DevTranscript*>(A + J.o_tr);
+    a.n = J.n;
+    a.n_layers = 1 + J.n_inner;
+    a.n_queries = J.cfg.n_queries;
+    a.bstride = J.count > 1 ? J.bstride : 0;
+    a.out = static_cast<uint8_t*>(ctx->pinned) + J.dec_off;
+    a.out_stride = J.dec_stride;
+    a.words_off = J.dec_words_off;
+    a.hashes_off = J.dec_hashes_off;
+    a.max_words = J.dec_max_words;
+    a.max_hashes = J.dec_max_hashes;
+    a.vals[0] = reinterpret_cast<const uint32_t*>(A + J.first.o_vals);
+    a.trees[0] = A + J.first.o_tree;
+    for (uint32_t kx = 0; kx < J.n_inner; kx++) {
+        a.vals[1 + kx] = reinterpret_cast<const uint32_t*>(A + J.inner[kx].o_vals);
+        a.trees[1 + kx] = A + J.inner[kx].o_tree;
+    }
+    // a lone large proof has ~4000 hashes to fetch: several workgroups share them (each repeats the cheap table set-up)
+    const uint32_t wgs = J.count >= 8 ? 1u : (J.count >= 2 ? 2u : (J.n >= 16 ? 8u : 2u));
+    k::decommit(LN, a, wgs);
 }
 
 int prove_begin(Ctx* ctx, const uint8_t* data, size_t len, bool data_on_device, const uint64_t* seed, frieda_pcs_config cfg) {
@@ -390,8 +420,17 @@ int prove_begin_batch(Ctx* ctx, const uint8_t* data, size_t data_stride, size_t 
     // pinned staging: the transcript summaries of all blobs (header + last-layer polynomial each), or the last layer itself on
     // the host-channel path, or the gather lists and results
     const size_t tr_host_pitch = J.tr_host_pitch = (offsetof(DevTranscript, last_poly) + ((size_t)16 << last) + 63) & ~(size_t)63;
-    const size_t pinned_need = std::max<size_t>(std::max<size_t>(tr_host_pitch * count, (sizeof(uint32_t) * 4) << last_log),
-                                                (4 + 8) * J.max_words + (32 + 8) * J.max_hashes + 512);
+    // device-side openings: header + words + hashes per blob, behind the transcript summaries
+    J.dec_max_words = (uint32_t)(J.max_words / count);
+    J.dec_max_hashes = (uint32_t)(J.max_hashes / count);
+    J.dec_words_off = k::DECOMMIT_HEADER_BYTES;
+    J.dec_hashes_off = J.dec_words_off + ((4 * (size_t)J.dec_max_words + 15) & ~(size_t)15);
+    J.dec_stride = (J.dec_hashes_off + 32 * (size_t)J.dec_max_hashes + 255) & ~(size_t)255;
+    J.dec_off = (tr_host_pitch * count + 255) & ~(size_t)255;
+    const size_t pinned_need =
+        std::max<size_t>(std::max<size_t>(std::max<size_t>(tr_host_pitch * count, (sizeof(uint32_t) * 4) << last_log),
+                                          (4 + 8) * J.max_words + (32 + 8) * J.max_hashes + 512),
+                         J.dec_off + J.dec_stride * count);
     rc = ensure_pinned(ctx, pinned_need);
     if (rc) return rc;
     TwiddleSet tw;
@@ -496,6 +535,10 @@ int prove_begin_batch(Ctx* ctx, const uint8_t* data, size_t data_stride, size_t 
         k::grind_dev(LN, d_tr, d_gnext, cfg.pow_bits, J.grind_base, J.grind_chunk, /*next_zeroed=*/true);
         rc = download_transcripts(ctx, J);
         if (rc) return rc;
+        // mix_u64(nonce), query sampling and every opening of the proof, written in proof order into the pinned block
+        J.dev_decommit = cfg.n_queries <= k::DECOMMIT_MAX_QUERIES && 1 + n_inner <= k::DECOMMIT_MAX_LAYERS && n <= k::DECOMMIT_MAX_LOG_DOMAIN &&
+                         !getenv("FRIEDA_HOST_DECOMMIT");
+        if (J.dev_decommit) launch_decommit(ctx, J, LN);
         FR_HIP(ctx, hipGetLastError());
         ctx->phase_ms[0] = ms_since(J.t_start);  // commit phase fully enqueued
     } else {
@@ -619,6 +662,7 @@ int prove_finish_batch(Ctx* ctx, uint8_t* out_commitments, std::vector<ProofData
             k::grind_dev(LN, d_tr, reinterpret_cast<uint32_t*>(A + J.o_gnext), cfg.pow_bits, J.grind_base, J.grind_chunk);
             int rc = download_transcripts(ctx, J);
             if (rc) return rc;
+            if (J.dev_decommit) launch_decommit(ctx, J, LN);
         }
         FR_HIP(ctx, hipGetLastError());
         for (uint32_t b = 0; b < count; b++) {
@@ -637,87 +681,127 @@ int prove_finish_batch(Ctx* ctx, uint8_t* out_commitments, std::vector<ProofData
     }
     ctx->phase_ms[1] = ms_since(J.t_start);  // commit phase + grind complete on the device (first synchronise)
 
-    // ---- FriProver::decommit: plan the openings of every blob, one gather launch for all ----
-    static thread_local GatherPlan g;  // capacity is kept from proof to proof
-    g.word_idx.clear();
-    g.hash_idx.clear();
     struct LayerCounts {
         size_t n_witness, n_hashes;
     };
-    std::vector<std::vector<uint32_t>> all_queries(count);
     std::vector<LayerCounts> counts((size_t)count * (1 + n_inner));
-    for (uint32_t b = 0; b < count; b++) {
-        ProveJob::Blob& bl = J.blobs[b];
-        bl.ch.mix_u64(bl.nonce);  // src/proof.rs:59
-        std::vector<uint32_t>& queries = all_queries[b] = generate_queries(bl.ch, n, cfg.n_queries);
-        const size_t boff = (size_t)b * J.bstride;  // this blob's workspace (a multiple of 256 bytes)
-        auto shifted = [&](FriLayerDev lay) {
-            lay.o_vals += boff;
-            lay.o_tree += boff;
-            return lay;
-        };
-        LayerCounts* cnt = &counts[(size_t)b * (1 + n_inner)];
-        // Proof.evaluations (src/proof.rs:62-66)
-        for (uint32_t q : queries)
-            for (int c = 0; c < 4; c++) g.word_idx.push_back((first.o_vals + boff) / 4 + (size_t)c * N + q);
-        {
-            const FriLayerDev lay = shifted(first);
-            std::vector<uint32_t> pos = plan_witness(queries, lay, g, cnt[0].n_witness);
-            cnt[0].n_hashes = plan_merkle_decommit(pos, lay, g);
+    std::vector<size_t> n_evals(count);
+    std::vector<const uint32_t*> words_of(count);  // per blob: evaluations, then every layer's witness, in proof order
+    std::vector<const uint8_t*> hashes_of(count);  // per blob: every layer's hash witness, in proof order
+
+    // ---- FriProver::decommit ----
+    // Normally the device has already done it (decommit.hip, launched behind the grind): the pinned block holds, per blob, a
+    // header with the list sizes and the openings in proof order.  Otherwise (more than 1024 queries, an opening table too
+    // large for the kernel, FRIEDA_HOST_DECOMMIT) the host draws the queries, plans the openings and runs one gather launch.
+    bool from_device = J.dev_decommit;
+    if (from_device) {
+        for (uint32_t b = 0; b < count && from_device; b++) {
+            const uint8_t* reg = static_cast<const uint8_t*>(ctx->pinned) + J.dec_off + (size_t)b * J.dec_stride;
+            const uint32_t* hdr = reinterpret_cast<const uint32_t*>(reg);
+            if (hdr[0] == k::DECOMMIT_OVERFLOW) {
+                from_device = false;
+                break;
+            }
+            if (hdr[0] != k::DECOMMIT_OK) return ctx->fail(FRIEDA_ERR_INVARIANT, "internal: device decommit out of step with the grind");
+            n_evals[b] = hdr[1];
+            words_of[b] = reinterpret_cast<const uint32_t*>(reg + J.dec_words_off);
+            hashes_of[b] = reg + J.dec_hashes_off;
+            LayerCounts* cnt = &counts[(size_t)b * (1 + n_inner)];
+            // layer li: n_witness = |E_{li+1}|, n_hashes = |E_{li+2}| + ... + |E_n|   (hdr[3 + s] = |E_s|)
+            size_t suffix[40] = {0};  // suffix[s] = |E_s| + ... + |E_n|, s <= n + 1 <= 33
+            for (uint32_t sft = n; sft >= 1; sft--) suffix[sft] = suffix[sft + 1] + hdr[3 + sft];
+            for (uint32_t li = 0; li <= n_inner; li++) {
+                cnt[li].n_witness = hdr[3 + li + 1];
+                cnt[li].n_hashes = li + 2 <= n ? suffix[li + 2] : 0;
+            }
         }
-        std::vector<uint32_t> lq = fold_queries(queries, 1);
-        for (uint32_t kx = 0; kx < n_inner; kx++) {
-            const FriLayerDev lay = shifted(inner[kx]);
-            std::vector<uint32_t> pos = plan_witness(lq, lay, g, cnt[kx + 1].n_witness);
-            cnt[kx + 1].n_hashes = plan_merkle_decommit(pos, lay, g);
-            lq = fold_queries(lq, 1);
+        ctx->phase_ms[2] = ctx->phase_ms[3] = ms_since(J.t_start);
+    }
+    if (!from_device) {
+        static thread_local GatherPlan g;  // capacity is kept from proof to proof
+        g.word_idx.clear();
+        g.hash_idx.clear();
+        std::vector<size_t> w_begin(count), h_begin(count);
+        for (uint32_t b = 0; b < count; b++) {
+            ProveJob::Blob& bl = J.blobs[b];
+            bl.ch.mix_u64(bl.nonce);  // src/proof.rs:59
+            const std::vector<uint32_t> queries = generate_queries(bl.ch, n, cfg.n_queries);
+            n_evals[b] = queries.size();
+            w_begin[b] = g.word_idx.size();
+            h_begin[b] = g.hash_idx.size();
+            const size_t boff = (size_t)b * J.bstride;  // this blob's workspace (a multiple of 256 bytes)
+            auto shifted = [&](FriLayerDev lay) {
+                lay.o_vals += boff;
+                lay.o_tree += boff;
+                return lay;
+            };
+            LayerCounts* cnt = &counts[(size_t)b * (1 + n_inner)];
+            // Proof.evaluations (src/proof.rs:62-66)
+            for (uint32_t q : queries)
+                for (int c = 0; c < 4; c++) g.word_idx.push_back((first.o_vals + boff) / 4 + (size_t)c * N + q);
+            {
+                const FriLayerDev lay = shifted(first);
+                std::vector<uint32_t> pos = plan_witness(queries, lay, g, cnt[0].n_witness);
+                cnt[0].n_hashes = plan_merkle_decommit(pos, lay, g);
+            }
+            std::vector<uint32_t> lq = fold_queries(queries, 1);
+            for (uint32_t kx = 0; kx < n_inner; kx++) {
+                const FriLayerDev lay = shifted(inner[kx]);
+                std::vector<uint32_t> pos = plan_witness(lq, lay, g, cnt[kx + 1].n_witness);
+                cnt[kx + 1].n_hashes = plan_merkle_decommit(pos, lay, g);
+                lq = fold_queries(lq, 1);
+            }
+        }
+        ctx->phase_ms[2] = ms_since(J.t_start);  // queries drawn, openings planned
+        if (g.word_idx.size() > J.max_words || g.hash_idx.size() > J.max_hashes) return ctx->fail(FRIEDA_ERR_INVARIANT, "internal: gather plan overflow");
+        // one upload (word indices then hash indices, staged in pinned memory), one launch, one download
+        const size_t nw = g.word_idx.size(), nh = g.hash_idx.size();
+        const size_t wbytes = 4 * nw, out_bytes = wbytes + 32 * nh;
+        uint8_t* hp = reinterpret_cast<uint8_t*>(ctx->pinned);
+        uint64_t* hidx = reinterpret_cast<uint64_t*>(hp + ((4 * J.max_words + 32 * J.max_hashes + 255) & ~(size_t)255));
+        memcpy(hidx, g.word_idx.data(), 8 * nw);
+        memcpy(hidx + nw, g.hash_idx.data(), 8 * nh);
+        // the index and output regions of the arena are laid out back to back (words region, then hashes region), so the
+        // hash part may start right behind the words actually used
+        k::Launch L1 = ctx->launch();  // the gather works on absolute indices: a single-blob launch
+        if (out_bytes <= ((size_t)1 << 20) && !getenv("FRIEDA_GATHER_COPY")) {
+            // small openings (the usual case): the kernel reads its index lists from, and writes its results to, the pinned
+            // staging block directly over PCIe — one launch instead of copy + launch + copy (each copy costs 10-20 us of setup)
+            k::gather(L1, reinterpret_cast<const uint32_t*>(A), hidx, nw, reinterpret_cast<uint32_t*>(hp), hidx + nw, nh, hp + wbytes);
+        } else {
+            FR_HIP(ctx, hipMemcpyAsync(A + J.o_widx, hidx, 8 * (nw + nh), hipMemcpyHostToDevice, s));
+            k::gather(L1, reinterpret_cast<const uint32_t*>(A), reinterpret_cast<const uint64_t*>(A + J.o_widx), nw,
+                      reinterpret_cast<uint32_t*>(A + J.o_wout), reinterpret_cast<const uint64_t*>(A + J.o_widx) + nw, nh, A + J.o_wout + wbytes);
+            FR_HIP(ctx, hipMemcpyAsync(hp, A + J.o_wout, out_bytes, hipMemcpyDeviceToHost, s));
+        }
+        FR_HIP(ctx, hipStreamSynchronize(s));
+        FR_HIP(ctx, hipGetLastError());
+        ctx->phase_ms[3] = ms_since(J.t_start);  // gather done (second and last synchronise)
+        for (uint32_t b = 0; b < count; b++) {
+            words_of[b] = reinterpret_cast<const uint32_t*>(hp) + w_begin[b];
+            hashes_of[b] = hp + wbytes + 32 * h_begin[b];
         }
     }
-    ctx->phase_ms[2] = ms_since(J.t_start);  // queries drawn, openings planned
-    if (g.word_idx.size() > J.max_words || g.hash_idx.size() > J.max_hashes) return ctx->fail(FRIEDA_ERR_INVARIANT, "internal: gather plan overflow");
-    // one upload (word indices then hash indices, staged in pinned memory), one launch, one download
-    const size_t nw = g.word_idx.size(), nh = g.hash_idx.size();
-    const size_t wbytes = 4 * nw, out_bytes = wbytes + 32 * nh;
-    uint8_t* hp = reinterpret_cast<uint8_t*>(ctx->pinned);
-    uint64_t* hidx = reinterpret_cast<uint64_t*>(hp + ((4 * J.max_words + 32 * J.max_hashes + 255) & ~(size_t)255));
-    memcpy(hidx, g.word_idx.data(), 8 * nw);
-    memcpy(hidx + nw, g.hash_idx.data(), 8 * nh);
-    // the index and output regions of the arena are laid out back to back (words region, then hashes region), so the
-    // hash part may start right behind the words actually used
-    k::Launch L1 = ctx->launch();  // the gather works on absolute indices: a single-blob launch
-    if (out_bytes <= ((size_t)1 << 20) && !getenv("FRIEDA_GATHER_COPY")) {
-        // small openings (the usual case): the kernel reads its index lists from, and writes its results to, the pinned
-        // staging block directly over PCIe — one launch instead of copy + launch + copy (each copy costs 10-20 us of setup)
-        k::gather(L1, reinterpret_cast<const uint32_t*>(A), hidx, nw, reinterpret_cast<uint32_t*>(hp), hidx + nw, nh, hp + wbytes);
-    } else {
-        FR_HIP(ctx, hipMemcpyAsync(A + J.o_widx, hidx, 8 * (nw + nh), hipMemcpyHostToDevice, s));
-        k::gather(L1, reinterpret_cast<const uint32_t*>(A), reinterpret_cast<const uint64_t*>(A + J.o_widx), nw,
-                  reinterpret_cast<uint32_t*>(A + J.o_wout), reinterpret_cast<const uint64_t*>(A + J.o_widx) + nw, nh, A + J.o_wout + wbytes);
-        FR_HIP(ctx, hipMemcpyAsync(hp, A + J.o_wout, out_bytes, hipMemcpyDeviceToHost, s));
-    }
-    FR_HIP(ctx, hipStreamSynchronize(s));
-    FR_HIP(ctx, hipGetLastError());
-    ctx->phase_ms[3] = ms_since(J.t_start);  // gather done (second and last synchronise)
 
     // ---- assemble the Proofs (src/proof.rs:67-76) ----
-    const uint32_t* wv = reinterpret_cast<const uint32_t*>(hp);
-    const uint8_t* hv = hp + wbytes;
-    size_t wi = 0, hi = 0;
-    auto take_qm = [&]() {
-        QM31 q{wv[wi], wv[wi + 1], wv[wi + 2], wv[wi + 3]};
-        wi += 4;
-        return q;
-    };
     outs.assign(count, ProofData{});
     for (uint32_t b = 0; b < count; b++) {
         ProveJob::Blob& bl = J.blobs[b];
         ProofData& out = outs[b];
         const LayerCounts* cnt = &counts[(size_t)b * (1 + n_inner)];
+        const uint32_t* wv = words_of[b];
+        const uint8_t* hv = hashes_of[b];
+        size_t wi = 0, hi = 0;
+        auto take_qm = [&]() {
+            QM31 q{wv[wi], wv[wi + 1], wv[wi + 2], wv[wi + 3]};
+            wi += 4;
+            return q;
+        };
         out.pcs_config = cfg;
         out.log_size_bound = J.sh.L;
         out.proof_of_work = bl.nonce;
         out.last_layer_poly = std::move(bl.lastv);
-        out.evaluations.resize(all_queries[b].size());
+        out.evaluations.resize(n_evals[b]);
         for (auto& q : out.evaluations) q = take_qm();
         out.inner_layers.resize(n_inner);
         for (uint32_t li = 0; li <= n_inner; li++) {
@@ -726,10 +810,8 @@ int prove_finish_batch(Ctx* ctx, uint8_t* out_commitments, std::vector<ProofData
             lp.fri_witness.resize(cnt[li].n_witness);
             for (auto& q : lp.fri_witness) q = take_qm();
             lp.hash_witness.resize(cnt[li].n_hashes);
-            for (auto& h : lp.hash_witness) {
-                memcpy(h.data(), hv + 32 * hi, 32);
-                hi++;
-            }
+            if (cnt[li].n_hashes) memcpy(lp.hash_witness.data(), hv + 32 * hi, 32 * cnt[li].n_hashes);
+            hi += cnt[li].n_hashes;
         }
         memcpy(out_commitments + 32 * (size_t)b, bl.roots[0].data(), 32);
     }

@@ -717,3 +717,40 @@ def test_many_queries_with_duplicate_draws(gpu_ctx, oracle, nq):
     for i, (ra, pa) in enumerate(got):
         o_root, o_proof = oracle.commit_and_generate_proof(blobs[i], i + 1, ocfg)
         assert ra == o_root and pa.serialize() == o_proof.serialize()
+
+
+def test_openings_device_path_host_path_and_fallbacks(gpu_ctx, oracle, monkeypatch):
+    """The openings are normally produced by the decommit kernel (one launch behind the grind).  The host planner + gather
+    launch remains as the fallback: forced by FRIEDA_HOST_DECOMMIT, taken for more than 1024 queries, and taken when the
+    kernel reports that its tables do not fit (n * unique queries > its LDS capacity).  All of them equal the oracle."""
+    import frieda_amd
+
+    cases = [("pattern:5000", 8, (10, 4, 1, 300)), ("pattern:120", 1, (4, 1, 0, 5)), ("pattern:70000", 3, (8, 4, 0, 20))]
+    for spec, seed, cfg in cases:
+        data = resolve_input(spec, None)
+        o_root, o_proof = oracle.commit_and_generate_proof(data, seed, oracle.make_config(*cfg))
+        for host in (False, True):
+            if host:
+                monkeypatch.setenv("FRIEDA_HOST_DECOMMIT", "1")
+            else:
+                monkeypatch.delenv("FRIEDA_HOST_DECOMMIT", raising=False)
+            r, p = gpu_ctx.commit_and_generate_proof(data, seed, _cfg(frieda_amd, *cfg))
+            assert r == o_root and p.serialize() == o_proof.serialize(), (spec, host)
+    # batch through the forced host path
+    monkeypatch.setenv("FRIEDA_HOST_DECOMMIT", "1")
+    cfg = _cfg(frieda_amd, 6, 4, 0, 20)
+    blobs = [splitmix64_bytes(9900 + i, 3000).tobytes() for i in range(5)]
+    got = gpu_ctx.commit_and_generate_proof_batch(blobs, [1, 2, 3, 4, 5], cfg)
+    for i, (ra, pa) in enumerate(got):
+        o_root, o_proof = oracle.commit_and_generate_proof(blobs[i], i + 1, oracle.make_config(6, 4, 0, 20))
+        assert ra == o_root and pa.serialize() == o_proof.serialize()
+    monkeypatch.delenv("FRIEDA_HOST_DECOMMIT", raising=False)
+    # 1000 queries on a 2^14 domain: ~970 unique, 14 * 970 table slots > the kernel's capacity -> it reports overflow, host plans
+    # 1100 queries: above the kernel's limit, host plans from the start
+    data = splitmix64_bytes(9950, 15000).tobytes()
+    for nq in (1000, 1100):
+        o_root, o_proof = oracle.commit_and_generate_proof(data, 5, oracle.make_config(5, 4, 0, nq))
+        r, p = gpu_ctx.commit_and_generate_proof(data, 5, _cfg(frieda_amd, 5, 4, 0, nq))
+        assert r == o_root and p.serialize() == o_proof.serialize(), nq
+        assert frieda_amd.verify(p, 5)
+
