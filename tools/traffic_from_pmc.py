@@ -41,6 +41,7 @@ RULES = [
     (r"unpack30", "unpack30", 2.0),
     (r"grind_dev_kernel", "grind", 2.0),
     (r"gather_kernel", "gather", 2.0),
+    (r"decommit_kernel", "decommit", 2.0),
 ]
 
 
