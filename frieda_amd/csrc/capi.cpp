@@ -155,16 +155,61 @@ int frieda_commit_device(frieda_ctx* ctx, const void* d_data, size_t len, uint32
     FR_GUARD_END(ctx)
 }
 
+// ---- ProofPool ----
+static size_t proof_capacity_bytes(const ProofData& d) {
+    size_t b = d.evaluations.capacity() * sizeof(QM31) + d.last_layer_poly.capacity() * sizeof(QM31);
+    auto layer = [](const LayerProof& l) { return l.fri_witness.capacity() * sizeof(QM31) + l.hash_witness.capacity() * 32 + l.column_witness.capacity() * 4; };
+    b += layer(d.first_layer);
+    for (const LayerProof& l : d.inner_layers) b += layer(l);
+    return b + d.inner_layers.capacity() * sizeof(LayerProof);
+}
+frieda_proof* ProofPool::get() {
+    {
+        std::lock_guard<std::mutex> g(mu);
+        if (!free_list.empty()) {
+            frieda_proof* p = free_list.back();
+            free_list.pop_back();
+            const size_t b = proof_capacity_bytes(p->p);
+            bytes = bytes > b ? bytes - b : 0;
+            return p;
+        }
+    }
+    return new frieda_proof();
+}
+void ProofPool::put(frieda_proof* p) {
+    if (!p) return;
+    p->home.reset();
+    const size_t b = proof_capacity_bytes(p->p);
+    {
+        std::lock_guard<std::mutex> g(mu);
+        if (free_list.size() < MAX_ENTRIES && bytes + b <= MAX_BYTES) {
+            free_list.push_back(p);
+            bytes += b;
+            return;
+        }
+    }
+    delete p;
+}
+ProofPool::~ProofPool() {
+    for (frieda_proof* p : free_list) delete p;
+}
+// a proof object for `ctx` to fill; on failure give it back with pool->put
+static frieda_proof* proof_from_pool(frieda_ctx* ctx) {
+    frieda_proof* p = ctx->pool->get();
+    p->home = ctx->pool;
+    return p;
+}
+
 static int prove_common(frieda_ctx* ctx, const void* data, size_t len, bool on_device, const uint64_t* seed, frieda_pcs_config cfg,
                         uint8_t* out_commitment, frieda_proof** out) {
     if (!ctx || !out || (!data && len)) return FRIEDA_ERR_ARG;
     *out = nullptr;
     FR_GUARD_BEGIN
-    frieda_proof* p = new frieda_proof();
+    frieda_proof* p = proof_from_pool(ctx);
     uint8_t root[32];
     int rc = prove(&ctx->c, static_cast<const uint8_t*>(data), len, on_device, seed, cfg, root, p->p);
     if (rc != FRIEDA_OK) {
-        delete p;
+        ctx->pool->put(p);
         return rc;
     }
     if (out_commitment) memcpy(out_commitment, root, 32);
@@ -202,11 +247,11 @@ int frieda_prove_finish(frieda_ctx* ctx, uint8_t out_commitment[32], frieda_proo
     if (!ctx || !out) return FRIEDA_ERR_ARG;
     *out = nullptr;
     FR_GUARD_BEGIN
-    frieda_proof* p = new frieda_proof();
+    frieda_proof* p = proof_from_pool(ctx);
     uint8_t root[32];
     int rc = prove_finish(&ctx->c, root, p->p);
     if (rc != FRIEDA_OK) {
-        delete p;
+        ctx->pool->put(p);
         return rc;
     }
     if (out_commitment) memcpy(out_commitment, root, 32);
@@ -229,22 +274,22 @@ int batch_finish(frieda_ctx* ctx, uint32_t count, uint8_t* out_commitments, frie
     for (uint32_t i = 0; i < count; i++) out_proofs[i] = nullptr;
     FR_GUARD_BEGIN
     if (ctx->c.job && job_count(&ctx->c) != count) return ctx->c.fail(FRIEDA_ERR_ARG, "count differs from the batch in flight");
-    std::vector<ProofData> outs;
-    int rc = prove_finish_batch(&ctx->c, out_commitments, outs);
-    if (rc != FRIEDA_OK) return rc;
+    // the proofs are assembled into recycled objects (their vectors keep their capacity)
+    std::vector<frieda_proof*> objs(count, nullptr);
+    std::vector<ProofData> outs(count);
     for (uint32_t i = 0; i < count; i++) {
-        frieda_proof* p = new (std::nothrow) frieda_proof();
-        if (!p) {
-            for (uint32_t j = 0; j < i; j++) {
-                delete out_proofs[j];
-                out_proofs[j] = nullptr;
-            }
-            return ctx->c.fail(FRIEDA_ERR_NOMEM, "out of host memory");
-        }
-        p->p = std::move(outs[i]);
-        out_proofs[i] = p;
+        objs[i] = proof_from_pool(ctx);
+        outs[i] = std::move(objs[i]->p);
     }
-    return FRIEDA_OK;
+    int rc = prove_finish_batch(&ctx->c, out_commitments, outs);
+    for (uint32_t i = 0; i < count; i++) {
+        if (i < outs.size()) objs[i]->p = std::move(outs[i]);
+        if (rc != FRIEDA_OK)
+            ctx->pool->put(objs[i]);
+        else
+            out_proofs[i] = objs[i];
+    }
+    return rc;
     FR_GUARD_END(ctx)
 }
 }  // namespace
@@ -302,13 +347,20 @@ int frieda_verify(const frieda_proof* proof, const uint64_t* seed, int* ok) {
 }
 
 // ---- Proof accessors ----
-void frieda_proof_free(frieda_proof* p) { delete p; }
+void frieda_proof_free(frieda_proof* p) {
+    if (!p) return;
+    if (std::shared_ptr<ProofPool> home = p->home)  // keeps the pool alive across put() even if this was its last reference
+        home->put(p);
+    else
+        delete p;
+}
 
 int frieda_proof_clone(const frieda_proof* p, frieda_proof** out) {
     if (!p || !out) return FRIEDA_ERR_ARG;
     frieda_ctx* none = nullptr;
     FR_GUARD_BEGIN
-    *out = new frieda_proof(*p);
+    *out = new frieda_proof();
+    (*out)->p = p->p;
     return FRIEDA_OK;
     FR_GUARD_END(none)
 }

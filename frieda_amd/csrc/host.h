@@ -8,6 +8,7 @@
 #include <array>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -154,9 +155,26 @@ Hash32 hash_node_host(const uint8_t* left, const uint8_t* right, const uint32_t*
 
 }  // namespace frieda
 
+// Recycled proof objects of one context.  A proof of a 2^24 domain is ~140 KB in ~50 vectors; allocating them afresh costs
+// 30-40 us per proof (page faults on heap memory the allocator had trimmed after the previous proof was freed) — more than
+// copying the openings into them.  frieda_proof_free hands the object back to the pool of the context that made it (the pool
+// outlives the context while proofs of it are alive), and the next proof is assembled into the recycled vectors.
+struct frieda_proof;
+struct ProofPool {
+    std::mutex mu;
+    std::vector<frieda_proof*> free_list;
+    size_t bytes = 0;                                  // approximate capacity held by the free list
+    static constexpr size_t MAX_BYTES = 64u << 20;     // beyond this, freed proofs are really freed
+    static constexpr size_t MAX_ENTRIES = 4096;
+    frieda_proof* get();            // a recycled object (contents unspecified, capacities kept) or a new one; never null (throws bad_alloc)
+    void put(frieda_proof* p);      // takes ownership
+    ~ProofPool();
+};
 struct frieda_ctx {
     frieda::Ctx c;
+    std::shared_ptr<ProofPool> pool = std::make_shared<ProofPool>();
 };
 struct frieda_proof {
     frieda::ProofData p;
+    std::shared_ptr<ProofPool> home;  // set while the object is out with the caller; null inside the pool and for clones / parsed proofs
 };

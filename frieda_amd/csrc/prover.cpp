@@ -619,11 +619,11 @@ int prove_begin_batch(Ctx* ctx, const uint8_t* data, size_t data_stride, size_t 
 
 int prove_finish(Ctx* ctx, uint8_t out_commitment[32], ProofData& out) {
     if (ctx->job && ctx->job->count != 1) return ctx->fail(FRIEDA_ERR_ARG, "the proof in flight is a batch: use the batch finish");
-    std::vector<ProofData> outs;
+    std::vector<ProofData> outs(1);
+    outs[0] = std::move(out);  // assemble into the caller's object: a recycled one keeps its vectors' capacity
     int rc = prove_finish_batch(ctx, out_commitment, outs);
-    if (rc) return rc;
-    out = std::move(outs[0]);
-    return FRIEDA_OK;
+    if (!outs.empty()) out = std::move(outs[0]);
+    return rc;
 }
 
 uint32_t job_count(const Ctx* ctx) { return ctx->job ? ctx->job->count : 0; }
@@ -784,7 +784,7 @@ int prove_finish_batch(Ctx* ctx, uint8_t* out_commitments, std::vector<ProofData
     }
 
     // ---- assemble the Proofs (src/proof.rs:67-76) ----
-    outs.assign(count, ProofData{});
+    if (outs.size() != count) outs.assign(count, ProofData{});  // else: the caller's (recycled) objects, every field rewritten below
     for (uint32_t b = 0; b < count; b++) {
         ProveJob::Blob& bl = J.blobs[b];
         ProofData& out = outs[b];
@@ -812,6 +812,7 @@ int prove_finish_batch(Ctx* ctx, uint8_t* out_commitments, std::vector<ProofData
             lp.hash_witness.resize(cnt[li].n_hashes);
             if (cnt[li].n_hashes) memcpy(lp.hash_witness.data(), hv + 32 * hi, 32 * cnt[li].n_hashes);
             hi += cnt[li].n_hashes;
+            lp.column_witness.clear();
         }
         memcpy(out_commitments + 32 * (size_t)b, bl.roots[0].data(), 32);
     }
