@@ -21,3 +21,10 @@ for s, e, name in rows[i0:i1]:
     print(f"{(s - t0) / 1e3:9.1f} us  dur {(e - s) / 1e3:8.1f}  gap {gap:6.1f}  {short}")
     prev_end = max(prev_end, e)
 print(f"span {(prev_end - t0) / 1e3:.1f} us, busy {tot_busy:.1f}, gaps {tot_gap:.1f}, launches {i1 - i0}")
+# idle time between consecutive proofs: end of a proof's last kernel -> start of the next proof's first kernel
+gaps = []
+for a, b in zip(starts[:-1], starts[1:]):
+    last_end = max(r[1] for r in rows[a:b])
+    gaps.append((rows[b][0] - last_end) / 1e3)
+if gaps:
+    print("between proofs (us):", " ".join(f"{g:.0f}" for g in gaps[-8:]))
