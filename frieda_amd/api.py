@@ -111,7 +111,7 @@ class Context:
         """Host wall-clock marks (ms since entry) of the last generate_proof: enqueued, device done, queries, gather, assembled."""
         a = (C.c_double * 8)()
         _check(self._L.frieda_ctx_last_prove_phases(self._h, a), self._h)
-        return dict(zip(["enqueued", "device_done", "queries", "gathered", "assembled"], list(a)[:5]))
+        return dict(zip(["enqueued", "device_done", "queries", "gathered", "assembled", "first_launch_after_entry"], list(a)[:6]))
 
     def kernel_timing_report(self, reset=True):
         """Per-kernel HIP-event timings accumulated since the last reset: list of dicts."""

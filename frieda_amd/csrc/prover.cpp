@@ -362,6 +362,7 @@ int prove_begin(Ctx* ctx, const uint8_t* data, size_t len, bool data_on_device, 
 // `count` blobs of `len` bytes each, blob b at data + b * data_stride; seeds: null or one per blob
 int prove_begin_batch(Ctx* ctx, const uint8_t* data, size_t data_stride, size_t len, uint32_t count, bool data_on_device,
                       const uint64_t* seeds, frieda_pcs_config cfg) {
+    const auto t_entry = std::chrono::steady_clock::now();
     if (ctx->job) return ctx->fail(FRIEDA_ERR_ARG, "a proof is already in flight on this context");
     if (count == 0 || count > 65535) return ctx->fail(FRIEDA_ERR_ARG, "batch count out of range");
     if (count > 1 && data_stride < len) return ctx->fail(FRIEDA_ERR_ARG, "batch stride smaller than the blob length");
@@ -461,6 +462,7 @@ int prove_begin_batch(Ctx* ctx, const uint8_t* data, size_t data_stride, size_t 
     uint32_t* coef = reinterpret_cast<uint32_t*>(A + o_coef);
     uint32_t* eval = reinterpret_cast<uint32_t*>(A + first.o_vals);
     k::unpack30(LN, d_data, len, coef, sh.cs.n_padded, d_data_stride);
+    ctx->phase_ms[5] = ms_since(t_entry);  // set-up before the first launch (workspace plan, twiddle lookup, ...) + that launch call
     k::circle_evaluate(LN, coef, (size_t)1 << sh.L, 4, sh.L, n, tw.d_tw, tw.ds, eval, N);
 
     for (uint32_t b = 0; b < count; b++) {
