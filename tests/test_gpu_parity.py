@@ -4,6 +4,7 @@ Level B (one backend operation at a time) first, then Level A (commit / generate
 size-independent properties at BASELINE.json's full sizes where the oracle would take minutes.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -754,3 +755,15 @@ def test_openings_device_path_host_path_and_fallbacks(gpu_ctx, oracle, monkeypat
         assert r == o_root and p.serialize() == o_proof.serialize(), nq
         assert frieda_amd.verify(p, 5)
 
+
+
+def test_randomised_parity_short(gpu_ctx):
+    """Ten seconds of tools/fuzz_parity.py: random blob sizes, blow-ups, last-layer bounds, query counts, proof-of-work bits and
+    seeds, single proofs and batches, every proof byte-compared with the oracle's."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("fuzz_parity", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "fuzz_parity.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    n_single, n_batch, _ = mod.run(10.0, 20261003, gpu_ctx)
+    assert n_single > 20

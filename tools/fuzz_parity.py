@@ -1,0 +1,70 @@
+"""Randomised parity run: commit() and commit_and_generate_proof() on random blob sizes and FRI configurations, single calls and
+batches, byte-compared with the CPU oracle.  Not part of the test suite (run time is whatever you ask for).
+usage: python tools/fuzz_parity.py [seconds] [seed]"""
+import os, sys, time, random
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import frieda_amd
+from oracle import oracle as O
+from conftest import splitmix64_bytes
+
+
+
+def run(budget, seed, ctx=None):
+  rng = random.Random(seed)
+  ctx = ctx or frieda_amd.Context(0)
+  t0 = time.time()
+  n_single = n_batch = 0
+  while time.time() - t0 < budget:
+      B = rng.choice([1, 2, 3, 4, 4, 4, 5])
+      size = rng.choice([rng.randint(0, 300), rng.randint(300, 20000), rng.randint(20000, 400000)])
+      data = splitmix64_bytes(rng.randint(1, 1 << 30), max(size, 1)).tobytes()[:size]
+      # shape: F felts -> padded to a power of two >= 4 -> L = log2 - 2 -> n = L + B
+      F = (8 * size + 29) // 30
+      Fp = 4
+      while Fp < F:
+          Fp *= 2
+      L = Fp.bit_length() - 1 - 2
+      n = L + B
+      root = ctx.commit(data, B)
+      assert root == O.commit(data, B), ("commit", size, B)
+      if L < 1 or n < 2:
+          continue
+      last = rng.randint(0, min(3, L - 1))
+      nq = rng.choice([1, 2, 5, 20, 20, 33, 64, 65, 100])
+      pow_bits = rng.choice([0, 3, 8, 12])
+      seed = rng.choice([None, rng.randint(0, 1 << 62)])
+      cfg = frieda_amd.PcsConfig(frieda_amd.FriConfig(B, last, nq), pow_bits)
+      ocfg = O.make_config(pow_bits, B, last, nq)
+      try:
+          o_root, o_proof = O.commit_and_generate_proof(data, seed, ocfg)
+      except Exception as e:  # configurations the reference panics on: the product must report the same
+          try:
+              ctx.commit_and_generate_proof(data, seed, cfg)
+          except frieda_amd.FriedaPanic:
+              continue
+          raise AssertionError(("oracle panicked, product did not", size, B, last, nq, str(e)))
+      r, p = ctx.commit_and_generate_proof(data, seed, cfg)
+      assert r == o_root == root and p.serialize() == o_proof.serialize(), ("prove", size, B, last, nq, pow_bits, seed)
+      n_single += 1
+      if size <= 20000 and rng.random() < 0.3:
+          cnt = rng.randint(2, 9)
+          blobs = [splitmix64_bytes(rng.randint(1, 1 << 30), max(size, 1)).tobytes()[:size] for _ in range(cnt)]
+          seeds = [rng.randint(0, 1 << 40) for _ in range(cnt)]
+          try:
+              got = ctx.commit_and_generate_proof_batch(blobs, seeds, cfg)
+          except frieda_amd.FriedaError as e:
+              if "device channel" in str(e):
+                  continue
+              raise
+          for b, s_, (rr, pp) in zip(blobs, seeds, got):
+              orr, opp = O.commit_and_generate_proof(b, s_, ocfg)
+              assert rr == orr and pp.serialize() == opp.serialize(), ("batch", size, B, last, nq, pow_bits)
+          n_batch += 1
+  return n_single, n_batch, time.time() - t0
+
+
+if __name__ == "__main__":
+    a, b, dt = run(float(sys.argv[1]) if len(sys.argv) > 1 else 60.0, int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+    print(f"fuzz ok: {a} proofs, {b} batches in {dt:.0f} s")
+
