@@ -80,13 +80,15 @@ def cpu_baseline(sample_log, workload, calls):
     data = splitmix64_bytes(100, blob_len_for(sample_log))
     cfg = O.make_config(20, 4, 0, 20)
     t0 = time.perf_counter()
+    root = None
     for _ in range(calls):
         if workload == "prove":
-            O.commit_and_generate_proof(data, data.size, cfg)
+            root = O.commit_and_generate_proof(data, data.size, cfg)[0]
         else:
-            O.commit(data, 4)
+            root = O.commit(data, 4)
     dt = time.perf_counter() - t0
     return {
+        "root": bytes(root).hex(),
         "value": 4.0 * (1 << sample_log) * calls / dt,
         "unit": "M31 field-elems/s",
         "cores": 1,
@@ -109,7 +111,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--log-domain", type=int, default=24)
     ap.add_argument("--workload", choices=["prove", "commit"], default="prove")
-    ap.add_argument("--cpu-sample-log", type=int, default=22)
+    ap.add_argument("--cpu-sample-log", type=int, default=24, help="domain size of the CPU baseline sample (24 = the GPU workload itself, ~15 s of one core)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-twiddle-cache", action="store_true", help="regenerate twiddles every call, as the reference does")
     ap.add_argument("--batch-extra", type=int, default=4, help="blobs per call for the extra 'batched' figure (0 = skip)")
@@ -373,7 +375,11 @@ def main():
         "root": root.hex() if root else None,
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(args.cpu_sample_log, args.workload, 2 if args.cpu_sample_log <= 22 else 1)
+        cb = cpu_baseline(args.cpu_sample_log, args.workload, 2 if args.cpu_sample_log <= 22 else 1)
+        if args.cpu_sample_log == n:  # the very same blob and configuration: the CPU root must be the GPU root
+            assert cb["root"] == out["root"], "CPU baseline root differs from the GPU root"
+            cb["root_equals_gpu_root"] = True
+        out["cpu_baseline"] = cb
     elif rank == 0:
         out["cpu_baseline"] = None
     if rank == 0:
