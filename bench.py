@@ -118,6 +118,8 @@ def main():
     ap.add_argument("--pipeline-depth", type=int, default=2, help="proofs in flight for the extra 'pipelined' figure (0 = skip)")
     args = ap.parse_args()
 
+    # the host driver of this pool only supports dmabuf IPC: without this RCCL fails with hipIpcGetMemHandle: invalid argument
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
