@@ -990,12 +990,12 @@ __global__ __launch_bounds__(256) void grind_dev_kernel(GrindArgs a) {
 }
 
 // Which kernel produces level A (2^level_a nodes per blob, `batch` blobs per launch) and how many levels it yields:
-//   T_WIDE   tree5r, 1024-node workgroups, five levels: the launch fills the chip (>= 2^20 nodes in all, >= 1024 per blob)
+//   T_WIDE   tree5r, 1024-node workgroups, five levels: >= 2^18 nodes in the launch (all blobs together), >= 1024 per blob
+//            (alternating A/B runs: 2^18 and 2^19 launches are ~10 us faster here than with 256-node workgroups)
 //   T_NINE   tree9, 256-node workgroups, nine levels: 2^8 .. 2^17 nodes per blob — a latency chain, fewest launches
-//   T_SMALL  tree5<256>, 256-node workgroups, five levels: everything else (2^18, 2^19: measured no faster with 1024-node
-//            workgroups; < 2^8: a partial workgroup)
+//   T_SMALL  tree5<256>, 256-node workgroups, five levels: everything else (unaligned Level B buffers; < 2^8 nodes: a partial
+//            workgroup)
 enum TreeKernel { T_WIDE, T_NINE, T_SMALL };
-constexpr uint32_t T5_WIDE_LOG = 20;
 constexpr uint32_t T9_MIN_LOG = 8;
 uint32_t env_knob(const char* name, uint32_t dflt, uint32_t lo, uint32_t hi) {
     const char* e = getenv(name);
@@ -1003,6 +1003,7 @@ uint32_t env_knob(const char* name, uint32_t dflt, uint32_t lo, uint32_t hi) {
     return v >= lo && v <= hi ? v : dflt;
 }
 // tuning knobs (defaults = measured best): largest level-A size of the nine-level kernel; largest hand-over size of the top kernel
+const uint32_t T5_WIDE_LOG = env_knob("FRIEDA_T5_WIDE_LOG", 18, 16, 24);  // smallest launch (nodes) of the register-subtree kernel
 const uint32_t T9_MAX_LOG = env_knob("FRIEDA_T9_MAX_LOG", 17, 8, 19);
 const uint32_t TOP_MAX_LOG = env_knob("FRIEDA_TOP_MAX_LOG", 9, 9, 11);
 
