@@ -209,3 +209,68 @@ def test_rust_bindings_declare_every_symbol():
         rdecl[m.group(1)] = 0 if args == "" else args.count(":")
     assert sorted(decl) == sorted(rdecl)
     assert {k: v for k, v in decl.items() if rdecl[k] != v} == {}
+
+
+def test_opening_tables_equal_the_reference_decommit_walk():
+    """decommit.hip builds every opening list of a proof from one family of tables: with uq the sorted unique queries,
+    U_s = unique(uq >> s) and E_s = the children of U_s's nodes that are missing from U_{s-1}.  The claim (frieda_amd/csrc/
+    decommit.hip header): FRI layer li's witness positions are E_{li+1} and its Merkle hash witness is, bottom-up, the nodes
+    E_{li+2} .. E_n at tree level n - s + 1.  Checked here against a literal transcription of the reference's walk
+    (stwo core/fri.rs compute_decommitment_positions_and_witness_evals + core/vcs/prover.rs MerkleProver::decommit)."""
+    import random
+
+    def tables(uq, n):
+        E = {}
+        for s in range(1, n + 1):
+            prev = set(q >> (s - 1) for q in uq)
+            out = []
+            for v in sorted(set(q >> s for q in uq)):
+                for child in (2 * v, 2 * v + 1):
+                    if child not in prev:
+                        out.append(child)
+            E[s] = out
+        return E
+
+    def reference_layer(queries, log):
+        # positions + witness (fold_step = 1)
+        pos, witness = [], []
+        for pair in sorted(set(q >> 1 for q in queries)):
+            for p in (2 * pair, 2 * pair + 1):
+                pos.append(p)
+                if p not in queries:
+                    witness.append(p)
+        # Merkle decommit: layers from the leaves up; emit the hash of every child that was not visited
+        hashes = []  # (level, node)
+        below = pos
+        for layer in range(log - 1, -1, -1):
+            here = []
+            i = 0
+            while i < len(below):
+                node = below[i] >> 1
+                has_left = below[i] == 2 * node
+                if has_left:
+                    i += 1
+                has_right = i < len(below) and below[i] == 2 * node + 1
+                if has_right:
+                    i += 1
+                if not has_left:
+                    hashes.append((layer + 1, 2 * node))
+                if not has_right:
+                    hashes.append((layer + 1, 2 * node + 1))
+                here.append(node)
+            below = here
+        return witness, hashes
+
+    rng = random.Random(5)
+    for _ in range(200):
+        n = rng.randint(2, 14)
+        nq = rng.choice([1, 2, 3, 7, 20, 64, 200])
+        uq = sorted(set(rng.randrange(1 << n) for _ in range(nq)))
+        n_layers = rng.randint(1, n - 1)
+        E = tables(uq, n)
+        for li in range(n_layers):
+            lq = set(q >> li for q in uq)
+            witness, hashes = reference_layer(lq, n - li)
+            assert witness == E[li + 1], (n, li)
+            mine = [(n - s + 1, c) for s in range(li + 2, n + 1) for c in E[s]]
+            assert mine == hashes, (n, li)

@@ -62,6 +62,19 @@ __global__ __launch_bounds__(256) void rate_kernel(uint32_t* out, int iters) {
                 if (OP == 41) asm volatile("v_lshlrev_b32 %0, 7, %1\n\tv_xor_b32 %0, %0, %2" : "+v"(x) : "v"(y), "v"(z));
                 if (OP == 42) asm volatile("v_alignbit_b32 %0, %1, %1, 7\n\tv_xor_b32 %0, %0, %2" : "+v"(x) : "v"(y), "v"(z));
                 if (OP == 43) asm volatile("v_xor_b32 %0, %0, %1\n\tv_xor_b32 %0, %0, %2" : "+v"(x) : "v"(y), "v"(z));
+                if (OP == 44) {
+                    uint64_t p;
+                    asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, 0" : "=v"(p) : "v"(x), "v"(y) : "vcc");
+                    x = (uint32_t)p;
+                }
+                if (OP == 45) {
+                    uint64_t p;
+                    asm volatile("v_mad_u64_u32 %0, vcc, s2, %1, 0" : "=v"(p) : "v"(x) : "vcc");
+                    x = (uint32_t)p;
+                }
+                if (OP == 46) asm volatile("v_add_u32 %0, s2, %0" : "+v"(x));
+                if (OP == 47) asm volatile("v_alignbit_b32 %0, %0, %1, s2" : "+v"(x) : "v"(y));
+                if (OP == 48) asm volatile("v_min_u32 %0, s2, %0" : "+v"(x));
             }
         }
     }
@@ -137,5 +150,10 @@ int main() {
     run<40>("pair: v_lshrrev_b32 + v_xor (per pair)");
     run<41>("pair: v_lshlrev_b32 + v_xor (per pair)");
     run<42>("pair: v_alignbit_b32 + v_xor (per pair)");
+    run<44>("v_mad_u64_u32 (vgpr, vgpr)");
+    run<45>("v_mad_u64_u32 (sgpr, vgpr)");
+    run<46>("v_add_u32 (sgpr operand)");
+    run<47>("v_alignbit_b32 (sgpr shift)");
+    run<48>("v_min_u32 (sgpr operand)");
     return 0;
 }
