@@ -84,8 +84,9 @@ int frieda_ctx_test_set_draw_bound(frieda_ctx* ctx, uint32_t bound);
  * {"kernels": [{"name", "launches", "total_ms", "alg_bytes"}]} (alg_bytes = algorithmic HBM bytes by the byte model
  * of DESIGN.md §5); returns the bytes needed including the NUL; reset != 0 clears the accumulated spans. */
 int frieda_ctx_set_kernel_timing(frieda_ctx* ctx, int enabled);
-/* host wall-clock marks of the last generate_proof on this ctx, ms since entry: [0] commit phase enqueued, [1] device
- * commit phase + grind complete, [2] queries drawn, [3] openings gathered, [4] proof assembled */
+/* host wall-clock marks of the last generate_proof on this ctx, ms since entry: [0] everything enqueued, [1] device work
+ * complete (the one synchronisation), [2] queries drawn, [3] openings gathered ([2] = [3] = [1] unless the host fallback
+ * planned the openings), [4] proof assembled, [5] host set-up before the first launch */
 int frieda_ctx_last_prove_phases(const frieda_ctx* ctx, double out_ms[8]);
 size_t frieda_ctx_kernel_timing_report(frieda_ctx* ctx, char* buf, size_t cap, int reset);
 
@@ -102,9 +103,9 @@ int frieda_commit_and_generate_proof(frieda_ctx* ctx, const uint8_t* data, size_
                                      frieda_pcs_config cfg, uint8_t out_commitment[32], frieda_proof** out);
 int frieda_commit_and_generate_proof_device(frieda_ctx* ctx, const void* d_data, size_t len, const uint64_t* seed,
                                             frieda_pcs_config cfg, uint8_t out_commitment[32], frieda_proof** out);
-/* The same, split in two so that several proofs can overlap on one GPU: _begin enqueues the encode and the whole FRI
- * commit phase on the ctx stream and returns without synchronising; _finish waits for it, draws the queries, gathers the
- * openings and builds the proof.  At most one proof in flight per ctx — use one ctx (= one stream + workspace) per
+/* The same, split in two so that several proofs can overlap on one GPU: _begin enqueues everything — encode, FRI commit
+ * phase, proof of work, query sampling and openings — on the ctx stream and returns without synchronising; _finish waits
+ * for it (once) and builds the proof from the openings the device left in pinned memory.  At most one proof in flight per ctx — use one ctx (= one stream + workspace) per
  * in-flight proof.  A blob passed to _begin_device must stay valid until _finish returns. */
 int frieda_prove_begin(frieda_ctx* ctx, const uint8_t* data, size_t len, const uint64_t* seed, frieda_pcs_config cfg);
 int frieda_prove_begin_device(frieda_ctx* ctx, const void* d_data, size_t len, const uint64_t* seed, frieda_pcs_config cfg);
@@ -122,9 +123,9 @@ int frieda_commit_and_generate_proof_batch(frieda_ctx* ctx, const uint8_t* data,
 int frieda_commit_and_generate_proof_batch_device(frieda_ctx* ctx, const void* d_data, size_t stride, size_t len, uint32_t count,
                                                   const uint64_t* seeds, frieda_pcs_config cfg, uint8_t* out_commitments,
                                                   frieda_proof** out_proofs);
-/* split form, as frieda_prove_begin / _finish: _begin enqueues the commit phase of the whole batch and returns; _finish (same
- * count) waits, opens the queries of every blob and builds the proofs.  Two contexts alternating _begin / _finish keep the
- * host-side planning of one batch under the device work of the next. */
+/* split form, as frieda_prove_begin / _finish: _begin enqueues the device work of the whole batch and returns; _finish (same
+ * count) waits and builds the proofs.  Two contexts alternating _begin / _finish keep the host-side assembly of one batch
+ * under the device work of the next. */
 int frieda_prove_batch_begin(frieda_ctx* ctx, const uint8_t* data, size_t stride, size_t len, uint32_t count, const uint64_t* seeds,
                              frieda_pcs_config cfg);
 int frieda_prove_batch_begin_device(frieda_ctx* ctx, const void* d_data, size_t stride, size_t len, uint32_t count,
