@@ -113,6 +113,8 @@ def lib():
         "frieda_circle_interpolate": (C.c_int, [vp, vp, u32, u32, u32, u32, vp]),
         "frieda_pack30": (C.c_int, [vp, vp, sz, vp, sz]),
         "frieda_reconstruct_device": (C.c_int, [vp, vp, u32, u32, u32, sz, vp]),
+        "frieda_circle_interpolate_cells": (C.c_int, [vp, vp, vp, u32, u32, u32, u32, u32, vp]),
+        "frieda_reconstruct_cells_device": (C.c_int, [vp, vp, vp, u32, u32, u32, u32, sz, vp]),
         "frieda_merkle_commit_layer": (C.c_int, [vp, u32, vp, pp, u32, vp]),
         "frieda_merkle_commit": (C.c_int, [vp, vp, u32, vp]),
         "frieda_merkle_layer_offset": (sz, [u32, u32]),

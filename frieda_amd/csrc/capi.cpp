@@ -560,6 +560,111 @@ int frieda_reconstruct_device(frieda_ctx* ctx, const uint32_t* d_block, uint32_t
     FR_GUARD_END(ctx)
 }
 
+// ---- reconstruction from scattered cells ----
+namespace {
+// inverse of V[r][u] = prod over the set bits b of u of s_b(c_r), s_b(c) = +- T_{m+b-1}[c >> (b+1)] (minus when bit b of c is set),
+// T_l[h] = x-coordinate of C_l.at(brev(h, n-2-l)), C_l = half_odds(n-1) doubled l times (oracle: fo_reconstruct_cells).
+// Gauss-Jordan over M31 on the host: R <= 256.  false: the cells are not distinct (singular matrix).
+bool cells_matrix_inverse(const uint32_t* cell_index, uint32_t R, uint32_t m, uint32_t n, std::vector<uint32_t>& vinv) {
+    std::vector<uint32_t> A((size_t)R * 2 * R, 0u);
+    uint32_t nb = 0;
+    while ((1u << nb) < R) nb++;
+    for (uint32_t r = 0; r < R; r++) {
+        const uint32_t c = cell_index[r];
+        uint32_t* row = &A[(size_t)r * 2 * R];
+        row[0] = 1;
+        for (uint32_t b = 0; b < nb; b++) {
+            const uint32_t lv = m + b - 1;
+            Coset cs = Coset::half_odds(n - 1);
+            for (uint32_t i = 0; i < lv; i++) cs = cs.doubled();
+            uint32_t t = cs.at(bit_reverse(c >> (b + 1), n - 2 - lv)).x;
+            if ((c >> b) & 1u) t = m31_neg(t);
+            for (uint32_t u = 0; u < (1u << b); u++) row[(1u << b) + u] = m31_mul(row[u], t);
+        }
+        row[R + r] = 1;
+    }
+    for (uint32_t col = 0; col < R; col++) {
+        uint32_t piv = col;
+        while (piv < R && A[(size_t)piv * 2 * R + col] == 0) piv++;
+        if (piv == R) return false;
+        if (piv != col)
+            for (uint32_t j = 0; j < 2 * R; j++) std::swap(A[(size_t)piv * 2 * R + j], A[(size_t)col * 2 * R + j]);
+        uint32_t* prow = &A[(size_t)col * 2 * R];
+        const uint32_t inv = m31_inv(prow[col]);
+        for (uint32_t j = col; j < 2 * R; j++) prow[j] = m31_mul(prow[j], inv);
+        for (uint32_t r = 0; r < R; r++) {
+            if (r == col) continue;
+            uint32_t* row = &A[(size_t)r * 2 * R];
+            const uint32_t f = row[col];
+            if (!f) continue;
+            for (uint32_t j = col; j < 2 * R; j++) row[j] = m31_sub(row[j], m31_mul(f, prow[j]));
+        }
+    }
+    vinv.resize((size_t)R * R);
+    for (uint32_t u = 0; u < R; u++)
+        for (uint32_t r = 0; r < R; r++) vinv[(size_t)u * R + r] = A[(size_t)u * 2 * R + R + r];
+    return true;
+}
+
+// coefficients of `ncols` columns from n_cells scattered cells into d_coef[ncols][2^log_coef], or — d_coef == nullptr — into the
+// start of the arena (the caller reserved arena_off bytes there).  Scratch: the arena behind arena_off.
+int interpolate_cells(frieda_ctx* ctx, const uint32_t* d_cells, const uint32_t* cell_index, uint32_t n_cells, uint32_t ncols, uint32_t log_cell,
+                      uint32_t log_coef, uint32_t log_domain, uint32_t* d_coef, size_t arena_off) {
+    Ctx& c = ctx->c;
+    if (log_cell < 1 || log_cell > log_coef || log_coef > log_domain || log_domain > FRIEDA_MAX_LOG_DOMAIN)
+        return c.fail(FRIEDA_ERR_ARG, "cells: need 1 <= log_cell <= log_coef <= log_domain");
+    if (log_coef - log_cell > 8 || n_cells != (1u << (log_coef - log_cell)))
+        return c.fail(FRIEDA_ERR_ARG, "cells: n_cells must be 2^(log_coef - log_cell) and at most 256");
+    for (uint32_t r = 0; r < n_cells; r++)
+        if ((uint64_t)cell_index[r] >= ((uint64_t)1 << (log_domain - log_cell))) return c.fail(FRIEDA_ERR_ARG, "cells: cell index out of range");
+    std::vector<uint32_t> vinv;
+    if (!cells_matrix_inverse(cell_index, n_cells, log_cell, log_domain, vinv)) return c.fail(FRIEDA_ERR_ARG, "cells: cell indices are not distinct");
+    const size_t M = (size_t)1 << log_cell, w_words = (size_t)n_cells * ncols * M;
+    int rc = c.ensure_arena(arena_off + 4 * (w_words + vinv.size()) + 512);
+    if (rc) return rc;
+    TwiddleSet ts;
+    rc = c.get_twiddles(log_domain, ts);
+    if (rc) return rc;
+    uint32_t* d_w = reinterpret_cast<uint32_t*>(c.arena + arena_off);
+    uint32_t* d_vinv = d_w + ((w_words + 63) & ~(size_t)63);
+    FR_HIP(&c, hipMemcpyAsync(d_vinv, vinv.data(), 4 * vinv.size(), hipMemcpyHostToDevice, c.stream));
+    for (uint32_t r = 0; r < n_cells; r++)  // undo the block transform of every cell (layers log_cell-1 .. 0 with the cell's twiddles)
+        k::circle_interpolate_block(c.launch(), d_cells + (size_t)r * ncols * M, M, ncols, log_cell, log_domain, cell_index[r], ts.d_itw, ts.ds,
+                                    d_w + (size_t)r * ncols * M, M);
+    k::cells_combine(c.launch(), d_w, d_vinv, n_cells, ncols, log_cell, d_coef ? d_coef : reinterpret_cast<uint32_t*>(c.arena),
+                     (size_t)1 << log_coef);
+    FR_HIP(&c, hipStreamSynchronize(c.stream));  // vinv is a local host vector
+    FR_HIP(&c, hipGetLastError());
+    return FRIEDA_OK;
+}
+}  // namespace
+
+int frieda_circle_interpolate_cells(frieda_ctx* ctx, const uint32_t* d_cells, const uint32_t* cell_index, uint32_t n_cells, uint32_t ncols,
+                                    uint32_t log_cell, uint32_t log_coef, uint32_t log_domain, uint32_t* d_coef) {
+    if (!ctx || !d_cells || !cell_index || !d_coef || ncols == 0 || ncols > 1024) return FRIEDA_ERR_ARG;
+    FR_GUARD_BEGIN
+    FR_HIP(&ctx->c, hipSetDevice(ctx->c.device));
+    return interpolate_cells(ctx, d_cells, cell_index, n_cells, ncols, log_cell, log_coef, log_domain, d_coef, 0);
+    FR_GUARD_END(ctx)
+}
+
+int frieda_reconstruct_cells_device(frieda_ctx* ctx, const uint32_t* d_cells, const uint32_t* cell_index, uint32_t n_cells, uint32_t log_cell,
+                                    uint32_t log_coef, uint32_t log_domain, size_t len, void* d_out_bytes) {
+    if (!ctx || !d_cells || !cell_index || (len && !d_out_bytes)) return FRIEDA_ERR_ARG;
+    if (log_coef > FRIEDA_MAX_LOG_DOMAIN) return FRIEDA_ERR_ARG;
+    const size_t n_felts = (size_t)4 << log_coef;
+    if ((8 * len + 29) / 30 > n_felts) return ctx->c.fail(FRIEDA_ERR_ARG, "len does not fit the polynomial");
+    FR_GUARD_BEGIN
+    FR_HIP(&ctx->c, hipSetDevice(ctx->c.device));
+    const size_t coef_bytes = (sizeof(uint32_t) * n_felts + 255) & ~(size_t)255;
+    int rc = interpolate_cells(ctx, d_cells, cell_index, n_cells, 4, log_cell, log_coef, log_domain, nullptr, coef_bytes);
+    if (rc) return rc;
+    k::pack30(ctx->c.launch(), reinterpret_cast<const uint32_t*>(ctx->c.arena), n_felts, static_cast<uint8_t*>(d_out_bytes), len);
+    FR_HIP(&ctx->c, hipGetLastError());
+    return FRIEDA_OK;
+    FR_GUARD_END(ctx)
+}
+
 int frieda_merkle_commit_layer(frieda_ctx* ctx, uint32_t log_size, const void* d_prev, const uint32_t* const* d_cols, uint32_t ncols,
                                void* d_out) {
     if (!ctx || !d_out || log_size > FRIEDA_MAX_LOG_DOMAIN || (ncols && !d_cols) || ncols > 1024) return FRIEDA_ERR_ARG;

@@ -204,6 +204,38 @@ void circle_interpolate_block(const Launch& L_, const uint32_t* d_block, size_t 
     }
 }
 
+// coef[col][u * M + t] = sum_r vinv[u][r] * w[r][col][t]   (M = 2^m words per cell and column, R cells; see cells_combine below)
+namespace {
+__global__ __launch_bounds__(256) void cells_combine_kernel(const uint32_t* __restrict__ w, const uint32_t* __restrict__ vinv, uint32_t R,
+                                                            uint32_t ncols, size_t M, uint32_t* __restrict__ coef, size_t coef_stride) {
+    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const uint32_t u = blockIdx.y, col = blockIdx.z;
+    if (t >= M) return;
+    const uint32_t* row = vinv + (size_t)u * R;
+    uint64_t acc = 0;
+    uint32_t pending = 0;
+    for (uint32_t r = 0; r < R; r++) {
+        acc += (uint64_t)row[r] * w[((size_t)r * ncols + col) * M + t];  // each product < 2^62
+        if (++pending == 3) {  // three products + a reduced value stay below 2^64
+            acc = m31_reduce64(acc);
+            pending = 0;
+        }
+    }
+    coef[(size_t)col * coef_stride + (size_t)u * M + t] = m31_reduce64(acc);
+}
+}  // namespace
+
+// Second half of the reconstruction from scattered cells (oracle: fo_reconstruct_cells): d_w[R][ncols][2^m] holds the cells after
+// their block transforms were undone, d_vinv[R][R] the inverse of the matrix V[c][u] = prod_{b in u} s_b(c); the coefficient
+// slice u (entries u * 2^m .. of every column) is the combination sum_r vinv[u][r] * w[r].
+void cells_combine(const Launch& L_, const uint32_t* d_w, const uint32_t* d_vinv, uint32_t R, uint32_t ncols, uint32_t m, uint32_t* d_coef,
+                   size_t coef_stride) {
+    const size_t M = (size_t)1 << m;
+    Scope scope(L_, "cells_combine", 8.0 * ncols * (double)R * (double)M);
+    dim3 grid((unsigned)((M + 255) / 256), R, ncols);
+    cells_combine_kernel<<<grid, 256, 0, L_.stream>>>(d_w, d_vinv, R, ncols, M, d_coef, coef_stride);
+}
+
 void pack30(const Launch& L_, const uint32_t* d_felts, size_t n_felts, uint8_t* d_out, size_t len) {
     if (len == 0) return;
     Scope scope(L_, "pack30", 4.0 * (double)n_felts + (double)len);

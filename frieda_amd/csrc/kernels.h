@@ -72,6 +72,9 @@ void circle_evaluate(const Launch& L_, const uint32_t* d_coef, size_t coef_strid
 // block `block` (2^L consecutive bit-reversed evaluations per column) -> the 2^L coefficients per column
 void circle_interpolate_block(const Launch& L_, const uint32_t* d_block, size_t in_stride, uint32_t ncols, uint32_t L, uint32_t n,
                               uint32_t block, const uint32_t* d_itw, DomainScalars ds, uint32_t* d_coef, size_t out_stride);
+// reconstruction from scattered cells, second half: coef slice u = sum_r vinv[u][r] * w[r] (w[R][ncols][2^m], vinv[R][R])
+void cells_combine(const Launch& L_, const uint32_t* d_w, const uint32_t* d_vinv, uint32_t R, uint32_t ncols, uint32_t m, uint32_t* d_coef,
+                   size_t coef_stride);
 // inverse of unpack30: felts (30 significant bits each) -> the first `len` bytes of the LSB-first bit stream
 void pack30(const Launch& L_, const uint32_t* d_felts, size_t n_felts, uint8_t* d_out, size_t len);
 

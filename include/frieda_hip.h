@@ -200,6 +200,18 @@ int frieda_pack30(frieda_ctx* ctx, const uint32_t* d_felts, size_t n_felts, void
 int frieda_reconstruct_device(frieda_ctx* ctx, const uint32_t* d_block, uint32_t log_coef, uint32_t log_domain, uint32_t block,
                               size_t len, void* d_out_bytes);
 
+/* Reconstruction from scattered cells — what a sampling client holds.  A cell is an aligned run of 2^log_cell consecutive
+ * entries (log_cell >= 1) of the bit-reversed evaluation, the same run of every column: cell c = entries c * 2^log_cell ..
+ * (c + 1) * 2^log_cell, c < 2^(log_domain - log_cell).  ANY n_cells = 2^(log_coef - log_cell) distinct cells (at most 256)
+ * determine the polynomial: every cell's block transform is undone on the device, then a n_cells x n_cells linear system
+ * (inverted once on the host) recombines the coefficient slices.  d_cells[n_cells][ncols][2^log_cell] (cell-major),
+ * cell_index: host array.  n_cells == 1 is frieda_circle_interpolate with block = cell_index[0]. */
+int frieda_circle_interpolate_cells(frieda_ctx* ctx, const uint32_t* d_cells, const uint32_t* cell_index, uint32_t n_cells, uint32_t ncols,
+                                    uint32_t log_cell, uint32_t log_coef, uint32_t log_domain, uint32_t* d_coef);
+/* the same for frieda's 4-column layout, followed by the packer: scattered cells -> the original len bytes */
+int frieda_reconstruct_cells_device(frieda_ctx* ctx, const uint32_t* d_cells, const uint32_t* cell_index, uint32_t n_cells, uint32_t log_cell,
+                                    uint32_t log_coef, uint32_t log_domain, size_t len, void* d_out_bytes);
+
 /* MerkleOps::commit_on_layer(log_size, prev_layer, columns): d_prev is NULL or 2^(log_size+1) hashes;
  * d_cols is a host array of ncols device column pointers (2^log_size words each); d_out gets 2^log_size
  * 32-byte hashes */

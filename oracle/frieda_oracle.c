@@ -322,6 +322,76 @@ void fo_circle_interpolate_block(const uint32_t* block, uint32_t L, uint32_t n, 
     for (size_t j = 0; j < M; j++) coef_out[j] = m31_mul(coef_out[j], inv);
 }
 
+/* Reconstruction from scattered cells (widened; not in /root/reference/src — frieda's README `sample()` /
+ * reconstruct flow is unimplemented upstream, so this is specified by the encode itself: evaluate -> take cells -> reconstruct ==
+ * identity).  A cell is an aligned run of 2^m consecutive entries (m >= 1) of the bit-reversed codeword of one column; cell c
+ * covers entries c * 2^m .. (c+1) * 2^m.  Any R = 2^(L-m) distinct cells determine the 2^L coefficients:
+ *   the encode's layers i = L-1 .. m leave in cell c the vector  w_c[t] = sum_u V[c][u] * coef[u * 2^m + t],
+ *   V[c][u] = prod over the set bits b of u of s_b(c),  s_b(c) = +- T_{m+b-1}[c >> (b+1)]  (minus when bit b of c is set),
+ *   and its layers m-1 .. 0 are the block transform of fo_circle_interpolate_block(L = m, k = c).
+ * So: undo the block transform of every cell, then solve the R x R system per t (V is a Vandermonde-type matrix in the basis
+ * 1, x, pi(x), x pi(x), ... at R distinct points, hence invertible).  Returns 0, or -1 when the cells are not distinct / in range. */
+int fo_reconstruct_cells(const uint32_t* cells, const uint32_t* cell_index, uint32_t R, uint32_t m, uint32_t L, uint32_t n,
+                         const uint32_t* tw, const uint32_t* itw, uint32_t* coef_out) {
+    if (m < 1 || m > L || L > n || R != (1u << (L - m))) return -1;
+    const size_t M = (size_t)1 << m;
+    for (uint32_t r = 0; r < R; r++) {
+        if ((uint64_t)cell_index[r] >= ((uint64_t)1 << (n - m))) return -1;
+        for (uint32_t q = 0; q < r; q++)
+            if (cell_index[q] == cell_index[r]) return -1;
+    }
+    uint32_t* w = (uint32_t*)malloc(sizeof(uint32_t) * R * M);
+    uint32_t* A = (uint32_t*)malloc(sizeof(uint32_t) * R * 2 * R); /* [V | I] */
+    for (uint32_t r = 0; r < R; r++) fo_circle_interpolate_block(cells + r * M, m, n, cell_index[r], itw, w + r * M);
+    for (uint32_t r = 0; r < R; r++) {
+        const uint32_t c = cell_index[r];
+        uint32_t* row = A + (size_t)r * 2 * R;
+        row[0] = 1;
+        for (uint32_t b = 0; (1u << b) < R; b++) {
+            uint32_t t = tw[tw_level_offset(n, m + b - 1) + (c >> (b + 1))];
+            if ((c >> b) & 1u) t = m31_sub(0, t);
+            for (uint32_t u = 0; u < (1u << b); u++) row[(1u << b) + u] = m31_mul(row[u], t);
+        }
+        for (uint32_t j = 0; j < R; j++) row[R + j] = j == r ? 1u : 0u;
+    }
+    /* Gauss-Jordan over M31 */
+    int rc = 0;
+    for (uint32_t col = 0; col < R && rc == 0; col++) {
+        uint32_t piv = col;
+        while (piv < R && A[(size_t)piv * 2 * R + col] == 0) piv++;
+        if (piv == R) {
+            rc = -1;
+            break;
+        }
+        if (piv != col)
+            for (uint32_t j = 0; j < 2 * R; j++) {
+                uint32_t tmp = A[(size_t)piv * 2 * R + j];
+                A[(size_t)piv * 2 * R + j] = A[(size_t)col * 2 * R + j];
+                A[(size_t)col * 2 * R + j] = tmp;
+            }
+        uint32_t* prow = A + (size_t)col * 2 * R;
+        const uint32_t inv = m31_inv(prow[col]);
+        for (uint32_t j = 0; j < 2 * R; j++) prow[j] = m31_mul(prow[j], inv);
+        for (uint32_t r = 0; r < R; r++) {
+            if (r == col) continue;
+            uint32_t* row = A + (size_t)r * 2 * R;
+            const uint32_t f = row[col];
+            if (!f) continue;
+            for (uint32_t j = 0; j < 2 * R; j++) row[j] = m31_sub(row[j], m31_mul(f, prow[j]));
+        }
+    }
+    if (rc == 0)
+        for (uint32_t u = 0; u < R; u++)
+            for (size_t t = 0; t < M; t++) {
+                uint32_t acc = 0;
+                for (uint32_t r = 0; r < R; r++) acc = m31_add(acc, m31_mul(A[(size_t)u * 2 * R + R + r], w[r * M + t]));
+                coef_out[u * M + t] = acc;
+            }
+    free(w);
+    free(A);
+    return rc;
+}
+
 void fo_felts_to_bytes(const uint32_t* felts, size_t n_felts, uint8_t* out, size_t len) {
     memset(out, 0, len);
     for (size_t kf = 0; kf < n_felts; kf++)

@@ -67,6 +67,10 @@ void fo_circle_evaluate(const uint32_t* coef, uint32_t L, uint32_t n, const uint
  * block: the 2^L evaluations out[k * 2^L .. (k+1) * 2^L) of the bit-reversed codeword (any k < 2^(n-L)); coef_out: the 2^L
  * coefficients.  k = 0 with L == n is exactly CpuBackend::interpolate on the canonic domain. */
 void fo_circle_interpolate_block(const uint32_t* block, uint32_t L, uint32_t n, uint32_t k, const uint32_t* itw, uint32_t* coef_out);
+/* reconstruction from R = 2^(L-m) scattered cells of one column: cells[r][2^m] = entries cell_index[r] * 2^m .. of the
+ * bit-reversed codeword (m >= 1, distinct cells); tw / itw from fo_precompute_twiddles(n); returns 0 or -1 (bad arguments) */
+int fo_reconstruct_cells(const uint32_t* cells, const uint32_t* cell_index, uint32_t R, uint32_t m, uint32_t L, uint32_t n,
+                         const uint32_t* tw, const uint32_t* itw, uint32_t* coef_out);
 /* inverse of fo_bytes_to_felt_le: felts (each < 2^30) -> the first `len` bytes of the LSB-first bit stream */
 void fo_felts_to_bytes(const uint32_t* felts, size_t n_felts, uint8_t* out, size_t len);
 

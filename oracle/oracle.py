@@ -92,6 +92,8 @@ def lib():
         L.fo_circle_evaluate.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
         L.fo_circle_interpolate_block.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
         L.fo_felts_to_bytes.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+        L.fo_reconstruct_cells.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.fo_reconstruct_cells.restype = C.c_int
         L.fo_merkle_commit_layer.argtypes = [C.c_uint32, C.c_void_p, C.POINTER(C.c_void_p), C.c_uint32, C.c_void_p]
         L.fo_merkle_commit.argtypes = [C.POINTER(C.c_void_p), C.c_uint32, C.c_uint32, C.c_void_p]
         L.fo_merkle_layer_offset.restype = C.c_size_t
@@ -196,6 +198,24 @@ def circle_interpolate_block(block, n, k, itw=None):
     out = np.zeros_like(block)
     for c in range(ncols):
         lib().fo_circle_interpolate_block(block[c].ctypes.data, L, n, k, itw.ctypes.data, out[c].ctypes.data)
+    return out
+
+
+def reconstruct_cells(cells, cell_index, n, L, tw=None, itw=None):
+    """cells [R, ncols, 2^m] (cell r = entries cell_index[r] * 2^m .. of every column of the bit-reversed codeword), R = 2^(L-m)
+    distinct cells -> coefficients [ncols, 2^L]."""
+    cells = np.ascontiguousarray(cells, dtype=np.uint32)
+    R, ncols, M = cells.shape
+    m = M.bit_length() - 1
+    idx = np.ascontiguousarray(cell_index, dtype=np.uint32)
+    if tw is None or itw is None:
+        tw, itw = precompute_twiddles(n)
+    out = np.zeros((ncols, 1 << L), dtype=np.uint32)
+    for c in range(ncols):
+        col = np.ascontiguousarray(cells[:, c, :])
+        rc = lib().fo_reconstruct_cells(col.ctypes.data, idx.ctypes.data, R, m, L, n, tw.ctypes.data, itw.ctypes.data, out[c].ctypes.data)
+        if rc != 0:
+            raise ValueError("fo_reconstruct_cells: bad arguments")
     return out
 
 

@@ -543,6 +543,59 @@ def test_encode_erase_reconstruct_round_trip(gpu_ctx, n_bytes, B):
         assert d_o.to_array(np.uint8, (n_bytes,)).tobytes() == data.tobytes(), f"block {k}"
 
 
+@pytest.mark.parametrize("L,n,m", [(1, 2, 1), (3, 5, 1), (3, 5, 3), (4, 8, 2), (6, 10, 3), (8, 12, 4), (8, 9, 2), (10, 14, 5), (12, 16, 4), (16, 20, 8), (14, 18, 13)])
+def test_circle_interpolate_scattered_cells(gpu_ctx, oracle, L, n, m):
+    """Any 2^(L-m) distinct cells of 2^m consecutive (bit-reversed) entries give back the coefficients: bit-exact against the
+    oracle's fo_reconstruct_cells and against the coefficients themselves; bad arguments are rejected."""
+    rng = np.random.default_rng(900 + 100 * L + 10 * n + m)
+    ncols = 4
+    coef = rand_m31(rng, (ncols, 1 << L))
+    ev = oracle.circle_evaluate(coef, n)
+    R = 1 << (L - m)
+    for trial in range(2):
+        idx = rng.choice(1 << (n - m), size=R, replace=False).astype(np.uint32)
+        cells = np.ascontiguousarray(np.stack([ev[:, int(c) << m : (int(c) + 1) << m] for c in idx]))  # [R, ncols, 2^m]
+        if L <= 12:
+            assert np.array_equal(oracle.reconstruct_cells(cells, idx, n, L), coef)
+        d_cells, d_c = DevBuf.from_array(gpu_ctx, cells), DevBuf(gpu_ctx, 4 * ncols << L)
+        _check(gpu_ctx, gpu_ctx._L.frieda_circle_interpolate_cells(gpu_ctx._h, d_cells.ptr, idx.ctypes.data, R, ncols, m, L, n, d_c.ptr))
+        assert np.array_equal(d_c.to_array(np.uint32, (ncols, 1 << L)), coef), (trial, idx[:4])
+    L_ = gpu_ctx._L
+    bad = idx.copy()
+    if R > 1:
+        bad[1] = bad[0]  # repeated cell
+        assert L_.frieda_circle_interpolate_cells(gpu_ctx._h, d_cells.ptr, bad.ctypes.data, R, ncols, m, L, n, d_c.ptr) != 0
+    bad = idx.copy()
+    bad[0] = 1 << (n - m)  # out of range
+    assert L_.frieda_circle_interpolate_cells(gpu_ctx._h, d_cells.ptr, bad.ctypes.data, R, ncols, m, L, n, d_c.ptr) != 0
+    assert L_.frieda_circle_interpolate_cells(gpu_ctx._h, d_cells.ptr, idx.ctypes.data, R + 1, ncols, m, L, n, d_c.ptr) != 0
+
+
+@pytest.mark.parametrize("n_bytes,B,log_cell_below", [(58, 4, 1), (1024, 4, 3), (70001, 2, 6), (262146, 4, 8), (3932160, 4, 8)])
+def test_encode_sample_cells_reconstruct_round_trip(gpu_ctx, n_bytes, B, log_cell_below):
+    """encode -> keep 2^j random cells scattered over the whole codeword (a sampling client's view) -> the original bytes."""
+    import ctypes as C
+
+    data = splitmix64_bytes(19, n_bytes)
+    L_ = gpu_ctx._L
+    nf, npad, lg = C.c_size_t(), C.c_size_t(), C.c_uint32()
+    L_.frieda_codec_shape(n_bytes, C.byref(nf), C.byref(npad), C.byref(lg))
+    L, n = lg.value, lg.value + B
+    j = min(log_cell_below, L - 1) if L >= 2 else 0
+    m = L - j
+    d_in = DevBuf.from_array(gpu_ctx, data)
+    d_coef, d_ev = DevBuf(gpu_ctx, 4 * npad.value), DevBuf(gpu_ctx, 16 << n)
+    _check(gpu_ctx, L_.frieda_unpack30(gpu_ctx._h, d_in.ptr, n_bytes, d_coef.ptr, npad.value))
+    _check(gpu_ctx, L_.frieda_circle_evaluate(gpu_ctx._h, d_coef.ptr, 4, L, n, d_ev.ptr))
+    ev = d_ev.to_array(np.uint32, (4, 1 << n))
+    rng = np.random.default_rng(n_bytes)
+    idx = rng.choice(1 << (n - m), size=1 << j, replace=False).astype(np.uint32)
+    cells = np.ascontiguousarray(np.stack([ev[:, int(c) << m : (int(c) + 1) << m] for c in idx]))
+    d_cells, d_o = DevBuf.from_array(gpu_ctx, cells), DevBuf(gpu_ctx, n_bytes + 8)
+    _check(gpu_ctx, L_.frieda_reconstruct_cells_device(gpu_ctx._h, d_cells.ptr, idx.ctypes.data, 1 << j, m, L, n, n_bytes, d_o.ptr))
+    assert d_o.to_array(np.uint8, (n_bytes,)).tobytes() == data.tobytes()
+
+
 # ---- batches of small blobs (SURVEY.md §8f item 4): every kernel handles the whole batch; results = separate calls ----
 @pytest.mark.parametrize("length,count,seeded", [(1024, 1, True), (1024, 7, False), (4096, 33, True), (16384, 16, True), (65536, 5, True),
                                                  (262144, 3, False), (58, 4, True), (16, 3, True)])

@@ -201,3 +201,21 @@ def test_fri_degree_invariant(oracle, n_bytes, B, last):
 def test_too_small_polynomial_panics(oracle):
     with pytest.raises(RuntimeError):
         oracle.commit_and_generate_proof(b"tiny", None, oracle.make_config(8, 4, 0, 4))
+
+
+@pytest.mark.parametrize("L,n,m", [(1, 2, 1), (3, 5, 1), (3, 5, 3), (4, 8, 2), (6, 10, 3), (8, 12, 4), (8, 9, 2), (10, 14, 5)])
+def test_oracle_reconstruct_from_scattered_cells(oracle, L, n, m):
+    """evaluate -> keep R = 2^(L-m) random cells of 2^m consecutive (bit-reversed) entries -> reconstruct == the coefficients.
+    (m == L is the single-block case of fo_circle_interpolate_block.)"""
+    rng = np.random.default_rng(1000 * L + 10 * n + m)
+    P = (1 << 31) - 1
+    coef = rng.integers(0, P, size=(4, 1 << L), dtype=np.uint32)
+    ev = oracle.circle_evaluate(coef, n)
+    R = 1 << (L - m)
+    for trial in range(3):
+        idx = rng.choice(1 << (n - m), size=R, replace=False).astype(np.uint32)
+        cells = np.stack([ev[:, int(c) << m : (int(c) + 1) << m] for c in idx])  # [R, 4, 2^m]
+        got = oracle.reconstruct_cells(cells, idx, n, L)
+        assert np.array_equal(got, coef), (trial, idx[:4])
+    with pytest.raises(ValueError):
+        oracle.reconstruct_cells(cells, np.zeros(R, dtype=np.uint32) if R > 1 else np.array([1 << (n - m)], dtype=np.uint32), n, L)
