@@ -172,13 +172,16 @@ def main():
         return None, None
 
     def gather_roots():
+        nonlocal gathered
         if not use_dist:
             return
+        from frieda_amd import batch
+
         if args.workload == "prove":
             roots_all.copy_(torch.frombuffer(bytearray(b"".join(host_roots)), dtype=torch.uint8))
         else:
             ctx.synchronize()  # the roots were written on the ctx stream; the collective runs on torch's
-        dist.all_gather_into_tensor(gathered, roots_all)
+        gathered = batch.gather_rank_roots(roots_all, roots_all.device).view(-1)
 
     def fence():
         torch.cuda.synchronize()

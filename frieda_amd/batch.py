@@ -75,6 +75,25 @@ def commit_batch(blobs, log_blowup_factor, commit_fn=None, device=None):
     return roots
 
 
+def gather_rank_roots(local_roots, device=None):
+    """bench.py's exchange: every rank holds the K roots of the K blobs it processed (K * 32 bytes, bytes-like or a uint8 tensor
+    already on `device`); one all_gather hands every rank every rank's roots.  Returns a uint8 tensor [world, K * 32] on `device`."""
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device()) if (dist.is_initialized() and dist.get_backend() == "nccl") else torch.device("cpu")
+    if isinstance(local_roots, torch.Tensor):
+        local = local_roots.to(device)
+    else:
+        local = torch.frombuffer(bytearray(local_roots), dtype=torch.uint8).to(device)
+    assert local.numel() % 32 == 0
+    if world > 1:
+        gathered = torch.zeros(world * local.numel(), dtype=torch.uint8, device=device)
+        dist.all_gather_into_tensor(gathered, local)
+    else:
+        gathered = local.clone()
+    return gathered.view(world, local.numel())
+
+
 def prove_batch(blobs, seeds, pcs_config, prove_fn=None, device=None):
     """Sharded `commit_and_generate_proof`: rank r proves blobs r, r + world, ...; every rank gets all commitment roots (one
     all_gather of 32 bytes per blob slot) and the proofs of its own shard as {blob index: proof}.

@@ -114,3 +114,36 @@ def test_shard_indices():
     assert shard_indices(5, 0, 2) == [0, 2, 4]
     assert shard_indices(5, 1, 2) == [1, 3]
     assert sorted(sum((shard_indices(11, r, 4) for r in range(4)), [])) == list(range(11))
+
+
+def _gather_worker(rank, world, port, k, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+
+    from frieda_amd import batch
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    mine = b"".join(bytes([(7 * rank + i) % 256]) * 32 for i in range(k))  # K distinguishable 32-byte roots
+    g = batch.gather_rank_roots(mine)
+    q.put((rank, [bytes(g[r].numpy()) for r in range(world)]))
+    dist.destroy_process_group()
+
+
+def test_bench_root_exchange_world2_gloo():
+    """bench.py's only collective: after the K timed steps every rank contributes its K roots to one all_gather."""
+    world, port, k = 2, _free_port(), 5
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_gather_worker, args=(r, world, port, k, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, rows in results:
+        for r in range(world):
+            assert rows[r] == b"".join(bytes([(7 * r + i) % 256]) * 32 for i in range(k)), (rank, r)
+
