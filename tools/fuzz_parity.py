@@ -17,9 +17,9 @@ def run(budget, seed, ctx=None):
   n_single = n_batch = 0
   t_print = t0
   while time.time() - t0 < budget:
-    if time.time() - t_print > 30:  # a progress line every half minute (long runs under gpurun must not look hung)
-        t_print = time.time()
-        print(f"  ... {n_single} proofs, {n_batch} batches after {t_print - t0:.0f} s", flush=True)
+      if time.time() - t_print > 30:  # a progress line every half minute (long runs under gpurun must not look hung)
+          t_print = time.time()
+          print(f"  ... {n_single} proofs, {n_batch} batches after {t_print - t0:.0f} s", flush=True)
       B = rng.choice([1, 2, 3, 4, 4, 4, 5])
       size = rng.choice([rng.randint(0, 300), rng.randint(300, 20000), rng.randint(20000, 400000)])
       data = splitmix64_bytes(rng.randint(1, 1 << 30), max(size, 1)).tobytes()[:size]
