@@ -133,6 +133,48 @@ class Context:
         """Blob and 32-byte root both in device memory; asynchronous on the context stream."""
         _check(self._L.frieda_commit_device(self._h, d_ptr, length, log_blowup_factor, d_root_ptr), self._h)
 
+    # ---- reconstruction side (host arrays in, bytes out; the device entry points are frieda_reconstruct_*_device) ----
+    def _dev_call_with_upload(self, host_arr, n_out_bytes, call):
+        """uploads a uint32 array, runs call(d_in, d_out), downloads n_out_bytes"""
+        import numpy as np
+
+        a = np.ascontiguousarray(host_arr, dtype=np.uint32)
+        d_in, d_out = C.c_void_p(), C.c_void_p()
+        _check(self._L.frieda_dev_alloc(self._h, a.nbytes, C.byref(d_in)), self._h)
+        _check(self._L.frieda_dev_alloc(self._h, n_out_bytes + 16, C.byref(d_out)), self._h)
+        try:
+            _check(self._L.frieda_dev_upload(self._h, d_in, a.ctypes.data, a.nbytes), self._h)
+            call(d_in, d_out)
+            out = (C.c_uint8 * max(n_out_bytes, 1))()
+            if n_out_bytes:
+                _check(self._L.frieda_dev_download(self._h, out, d_out, n_out_bytes), self._h)
+            return bytes(out)[:n_out_bytes]
+        finally:
+            self._L.frieda_dev_free(self._h, d_in)
+            self._L.frieda_dev_free(self._h, d_out)
+
+    def reconstruct_from_block(self, block, log_domain, block_index, n_bytes):
+        """block: uint32[4, 2^L] = entries block_index * 2^L .. of the four bit-reversed evaluation columns -> the blob."""
+        L = int(block.shape[1]).bit_length() - 1
+        return self._dev_call_with_upload(
+            block, n_bytes, lambda d_in, d_out: _check(self._L.frieda_reconstruct_device(self._h, d_in, L, log_domain, block_index, n_bytes, d_out), self._h)
+        )
+
+    def reconstruct_from_cells(self, cells, cell_index, log_coef, log_domain, n_bytes):
+        """cells: uint32[R, 4, 2^m] (cell r = entries cell_index[r] * 2^m .. of every column), R = 2^(log_coef - m) <= 256
+        distinct cells anywhere in the codeword -> the blob."""
+        import numpy as np
+
+        R, m = int(cells.shape[0]), int(cells.shape[2]).bit_length() - 1
+        idx = np.ascontiguousarray(cell_index, dtype=np.uint32)
+        return self._dev_call_with_upload(
+            cells,
+            n_bytes,
+            lambda d_in, d_out: _check(
+                self._L.frieda_reconstruct_cells_device(self._h, d_in, idx.ctypes.data, R, m, log_coef, log_domain, n_bytes, d_out), self._h
+            ),
+        )
+
     def commit_and_generate_proof(self, data, seed, pcs_config):
         a = _as_bytes(data)
         root = (C.c_uint8 * 32)()

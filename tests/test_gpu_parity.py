@@ -596,6 +596,20 @@ def test_encode_sample_cells_reconstruct_round_trip(gpu_ctx, n_bytes, B, log_cel
     assert d_o.to_array(np.uint8, (n_bytes,)).tobytes() == data.tobytes()
 
 
+def test_python_reconstruction_helpers(gpu_ctx, oracle):
+    """Context.reconstruct_from_block / reconstruct_from_cells (host arrays in, bytes out) on the oracle's own codeword."""
+    data = splitmix64_bytes(23, 5000).tobytes()
+    coef, L = oracle.polynomial_from_bytes(data)
+    n = L + 4
+    ev = oracle.circle_evaluate(coef, n)
+    assert gpu_ctx.reconstruct_from_block(np.ascontiguousarray(ev[:, 5 << L : 6 << L]), n, 5, len(data)) == data
+    m = L - 4
+    rng = np.random.default_rng(3)
+    idx = rng.choice(1 << (n - m), size=16, replace=False).astype(np.uint32)
+    cells = np.ascontiguousarray(np.stack([ev[:, int(c) << m : (int(c) + 1) << m] for c in idx]))
+    assert gpu_ctx.reconstruct_from_cells(cells, idx, L, n, len(data)) == data
+
+
 # ---- batches of small blobs (SURVEY.md §8f item 4): every kernel handles the whole batch; results = separate calls ----
 @pytest.mark.parametrize("length,count,seeded", [(1024, 1, True), (1024, 7, False), (4096, 33, True), (16384, 16, True), (65536, 5, True),
                                                  (262144, 3, False), (58, 4, True), (16, 3, True)])
