@@ -6,6 +6,8 @@
 #include <cstring>
 #include <fstream>
 #include <iterator>
+#include <thread>
+#include <vector>
 
 #include "frieda.hpp"
 
@@ -125,6 +127,30 @@ int main(int argc, char** argv) {
             CHECK(proofs[i].second.serialize() == single.second.serialize());
             CHECK(api::verify(proofs[i].second, seeds[i]));
         }
+    }
+    {  // host threads: one context per thread (thread_local default_context), proofs produced concurrently, then verified and
+       // freed on the main thread — after the producing threads (and their contexts) are gone
+        const int n_threads = 4, per_thread = 6;
+        std::vector<std::vector<std::pair<Commitment, Proof>>> got(n_threads);
+        std::vector<std::thread> ts;
+        for (int t = 0; t < n_threads; t++)
+            ts.emplace_back([&, t] {
+                for (int i = 0; i < per_thread; i++) {
+                    std::vector<uint8_t> d(1000 + 97 * t + 13 * i);
+                    for (size_t j = 0; j < d.size(); j++) d[j] = (uint8_t)(j * 31 + t * 7 + i);
+                    got[t].push_back(proof::commit_and_generate_proof(d, (uint64_t)(100 * t + i), PCS_CONFIG));
+                }
+            });
+        for (auto& th : ts) th.join();
+        for (int t = 0; t < n_threads; t++)
+            for (int i = 0; i < per_thread; i++) {
+                std::vector<uint8_t> d(1000 + 97 * t + 13 * i);
+                for (size_t j = 0; j < d.size(); j++) d[j] = (uint8_t)(j * 31 + t * 7 + i);
+                CHECK(got[t][i].first == api::commit(d, 4));
+                CHECK(api::verify(got[t][i].second, (uint64_t)(100 * t + i)));
+                CHECK(!api::verify(got[t][i].second, (uint64_t)(100 * t + i + 1)));
+            }
+        got.clear();  // frees 24 proofs whose contexts were destroyed with their threads
     }
     std::printf("%s (%d failures)\n", failures ? "FAILED" : "ok", failures);
     return failures ? 1 : 0;
