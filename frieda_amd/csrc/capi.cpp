@@ -564,7 +564,8 @@ int frieda_reconstruct_device(frieda_ctx* ctx, const uint32_t* d_block, uint32_t
 namespace {
 // inverse of V[r][u] = prod over the set bits b of u of s_b(c_r), s_b(c) = +- T_{m+b-1}[c >> (b+1)] (minus when bit b of c is set),
 // T_l[h] = x-coordinate of C_l.at(brev(h, n-2-l)), C_l = half_odds(n-1) doubled l times (oracle: fo_reconstruct_cells).
-// Gauss-Jordan over M31 on the host: R <= 256.  false: the cells are not distinct (singular matrix).
+// Gauss-Jordan over M31 on the host: R <= 256.  false: singular matrix (repeated cells; no singular set of distinct cells has been
+// observed — the code is MDS up to one dimension — but the solve reports it rather than assuming it away).
 bool cells_matrix_inverse(const uint32_t* cell_index, uint32_t R, uint32_t m, uint32_t n, std::vector<uint32_t>& vinv) {
     std::vector<uint32_t> A((size_t)R * 2 * R, 0u);
     uint32_t nb = 0;
@@ -618,7 +619,11 @@ int interpolate_cells(frieda_ctx* ctx, const uint32_t* d_cells, const uint32_t* 
     for (uint32_t r = 0; r < n_cells; r++)
         if ((uint64_t)cell_index[r] >= ((uint64_t)1 << (log_domain - log_cell))) return c.fail(FRIEDA_ERR_ARG, "cells: cell index out of range");
     std::vector<uint32_t> vinv;
-    if (!cells_matrix_inverse(cell_index, n_cells, log_cell, log_domain, vinv)) return c.fail(FRIEDA_ERR_ARG, "cells: cell indices are not distinct");
+    for (uint32_t r = 0; r < n_cells; r++)
+        for (uint32_t q = 0; q < r; q++)
+            if (cell_index[q] == cell_index[r]) return c.fail(FRIEDA_ERR_ARG, "cells: cell indices are not distinct");
+    if (!cells_matrix_inverse(cell_index, n_cells, log_cell, log_domain, vinv))
+        return c.fail(FRIEDA_ERR_ARG, "cells: these cells do not determine the polynomial (singular system)");
     const size_t M = (size_t)1 << log_cell, w_words = (size_t)n_cells * ncols * M;
     int rc = c.ensure_arena(arena_off + 4 * (w_words + vinv.size()) + 512);
     if (rc) return rc;

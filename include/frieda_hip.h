@@ -205,7 +205,8 @@ int frieda_reconstruct_device(frieda_ctx* ctx, const uint32_t* d_block, uint32_t
  * (c + 1) * 2^log_cell, c < 2^(log_domain - log_cell).  ANY n_cells = 2^(log_coef - log_cell) distinct cells (at most 256)
  * determine the polynomial: every cell's block transform is undone on the device, then a n_cells x n_cells linear system
  * (inverted once on the host) recombines the coefficient slices.  d_cells[n_cells][ncols][2^log_cell] (cell-major),
- * cell_index: host array.  n_cells == 1 is frieda_circle_interpolate with block = cell_index[0]. */
+ * cell_index: host array.  n_cells == 1 is frieda_circle_interpolate with block = cell_index[0].  FRIEDA_ERR_ARG for repeated or
+ * out-of-range cells (and for a singular system, which distinct cells have never produced). */
 int frieda_circle_interpolate_cells(frieda_ctx* ctx, const uint32_t* d_cells, const uint32_t* cell_index, uint32_t n_cells, uint32_t ncols,
                                     uint32_t log_cell, uint32_t log_coef, uint32_t log_domain, uint32_t* d_coef);
 /* the same for frieda's 4-column layout, followed by the packer: scattered cells -> the original len bytes */

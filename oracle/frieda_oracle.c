@@ -329,8 +329,8 @@ void fo_circle_interpolate_block(const uint32_t* block, uint32_t L, uint32_t n, 
  *   the encode's layers i = L-1 .. m leave in cell c the vector  w_c[t] = sum_u V[c][u] * coef[u * 2^m + t],
  *   V[c][u] = prod over the set bits b of u of s_b(c),  s_b(c) = +- T_{m+b-1}[c >> (b+1)]  (minus when bit b of c is set),
  *   and its layers m-1 .. 0 are the block transform of fo_circle_interpolate_block(L = m, k = c).
- * So: undo the block transform of every cell, then solve the R x R system per t (V is a Vandermonde-type matrix in the basis
- * 1, x, pi(x), x pi(x), ... at R distinct points, hence invertible).  Returns 0, or -1 when the cells are not distinct / in range. */
+ * So: undo the block transform of every cell, then solve the R x R system per t (row c of V is the tensor product of (1, s_b(c))
+ * over b; Gauss-Jordan).  Returns 0, or -1 when the cells are not distinct / not in range / the system is singular. */
 int fo_reconstruct_cells(const uint32_t* cells, const uint32_t* cell_index, uint32_t R, uint32_t m, uint32_t L, uint32_t n,
                          const uint32_t* tw, const uint32_t* itw, uint32_t* coef_out) {
     if (m < 1 || m > L || L > n || R != (1u << (L - m))) return -1;
