@@ -219,3 +219,17 @@ def test_oracle_reconstruct_from_scattered_cells(oracle, L, n, m):
         assert np.array_equal(got, coef), (trial, idx[:4])
     with pytest.raises(ValueError):
         oracle.reconstruct_cells(cells, np.zeros(R, dtype=np.uint32) if R > 1 else np.array([1 << (n - m)], dtype=np.uint32), n, L)
+
+
+@pytest.mark.parametrize("L,n,m", [(2, 4, 1), (3, 5, 2), (3, 5, 1)])
+def test_oracle_every_set_of_distinct_cells_reconstructs(oracle, L, n, m):
+    """Exhaustive over ALL subsets of 2^(L-m) cells for small shapes: none is singular, each gives back the coefficients."""
+    import itertools
+
+    rng = np.random.default_rng(7)
+    coef = rng.integers(0, (1 << 31) - 1, size=(1, 1 << L), dtype=np.uint32)
+    ev = oracle.circle_evaluate(coef, n)
+    tw, itw = oracle.precompute_twiddles(n)
+    for cs in itertools.combinations(range(1 << (n - m)), 1 << (L - m)):
+        cells = np.stack([ev[:, c << m : (c + 1) << m] for c in cs])
+        assert np.array_equal(oracle.reconstruct_cells(cells, np.array(cs, dtype=np.uint32), n, L, tw, itw), coef), cs
