@@ -9,7 +9,13 @@ interpolation -> grind (pow_bits 20) -> 20 query openings.  value = M31 field el
 n_gpus * 4 * 2^n * steps / wall time, inputs already resident in HBM when the timed region starts.
 
 Multi-GPU: one process per GPU (torch.distributed, backend nccl = RCCL), independent blobs sharded one per rank (weak
-scaling); the only collective is an all_gather of the 32-byte commitment roots per step.
+scaling); nothing is exchanged while blobs are processed — every rank keeps the roots of its K blobs and the ranks exchange
+them in ONE all_gather of K x 32 bytes per rank after the last step, inside the timed region.  `python bench.py --gpus N`
+launches its own N ranks when it was not started by torch.distributed.run (no WORLD_SIZE in the environment): the parent
+never touches the GPU, spawns one child per rank (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 / MASTER_PORT set),
+relays rank 0's JSON line and exits with the worst child status.  `--dry-collective gloo` runs the same launcher, rendezvous,
+barriers, root all_gather and max-reduce on CPU tensors with the GPU work stubbed out (the CPU test of the N > 1 plumbing;
+its line carries "dry_run": true and value 0).
 
 The JSON line also carries
   roofline     — the dominant kernel family (by summed HIP-event time on the kernels' own stream, instrumented replay of
@@ -63,48 +69,137 @@ def algorithmic_bytes(n, workload, log_blowup=4, log_last=0):
 def traffic_from_profiles(kernel, n, workload):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE collected
     in separate runs and corrected as MI355X_MICROARCH.md §HBM prescribes; tools/traffic_from_pmc.py).  Only valid for the
-    configuration the counters were taken on (2^24 domain); None otherwise."""
-    path = os.path.join(ROOT, "profiles", "r01_prove24_traffic.json")
-    if n != 24 or not os.path.exists(path):
-        return None
+    configuration the counters were taken on (2^24 domain).  Returns (bytes or None, source description): the number is a
+    committed measurement of an earlier run of this same command, NOT something this run measured."""
+    if n != 24:
+        return None, f"none: the committed PMC passes were taken on the 2^24 domain, this run is 2^{n}"
+    for name in ("r02_prove24_traffic.json", "r01_prove24_traffic.json"):
+        path = os.path.join(ROOT, "profiles", name)
+        if not os.path.exists(path):
+            continue
+        try:
+            doc = json.load(open(path))
+            val = doc["kernels"][kernel]["traffic_bytes_per_launch"]
+        except (KeyError, ValueError):
+            continue
+        src = f"profiles/{name} (committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command"
+        if doc.get("collected_at_commit"):
+            src += f", collected at commit {doc['collected_at_commit']}"
+        return val, src + "; not re-measured in this run)"
+    return None, "none: no committed PMC pass names this kernel"
+
+
+def _host_threads():
+    """threads the CPU baseline may use: the cores this process may run on, capped at the GPU box's share per GPU (16)"""
     try:
-        return json.load(open(path))["kernels"][kernel]["traffic_bytes_per_launch"]
-    except (KeyError, ValueError):
-        return None
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    return max(1, min(avail, int(os.environ.get("FRIEDA_BENCH_CPU_THREADS", "16"))))
 
 
-def cpu_baseline(sample_log, workload, calls):
+def cpu_baseline(sample_log, workload, calls, all_cores_log=22):
+    """The CPU oracle (oracle/, a restated port of the reference's single-threaded CPU path; the reference itself is Rust +
+    un-vendored stwo and cannot be built here) timed on this host: (1) one thread — the reference has no parallelism at all
+    (stwo pulled without `parallel`, Cargo.toml:12); (2) all usable cores, one independent blob per core."""
+    from concurrent.futures import ThreadPoolExecutor
+
     from oracle import oracle as O
 
     O.build()
-    data = splitmix64_bytes(100, blob_len_for(sample_log))
     cfg = O.make_config(20, 4, 0, 20)
+    name = "commit_and_generate_proof" if workload == "prove" else "commit"
+
+    def run(data):
+        if workload == "prove":
+            return O.commit_and_generate_proof(data, data.size, cfg)[0]
+        return O.commit(data, 4)
+
+    data = splitmix64_bytes(100, blob_len_for(sample_log))
     t0 = time.perf_counter()
     root = None
     for _ in range(calls):
-        if workload == "prove":
-            root = O.commit_and_generate_proof(data, data.size, cfg)[0]
-        else:
-            root = O.commit(data, 4)
+        root = run(data)
     dt = time.perf_counter() - t0
-    return {
+    out = {
         "root": bytes(root).hex(),
         "value": 4.0 * (1 << sample_log) * calls / dt,
         "unit": "M31 field-elems/s",
         "cores": 1,
         "kind": "port",
-        "sample": f"{calls} x {'commit_and_generate_proof' if workload == 'prove' else 'commit'} on a 2^{sample_log} domain "
-        f"(same generator and config as the GPU workload), {dt:.1f} s of single-thread CPU on a {os.cpu_count()}-core host; "
-        "restated CPU path (oracle/), not the upstream Rust binary",
+        "sample": f"{calls} x {name} on a 2^{sample_log} domain (same generator and config as the GPU workload), {dt:.1f} s of "
+        f"single-thread CPU on a {os.cpu_count()}-core host; restated CPU path (oracle/), not the upstream Rust binary",
     }
+    # all cores: one blob per core, the C calls run outside the GIL (the oracle keeps no shared mutable state)
+    threads = _host_threads()
+    blobs = [splitmix64_bytes(100 + i, blob_len_for(all_cores_log)) for i in range(threads)]
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(max_workers=threads) as ex:
+        roots = list(ex.map(run, blobs))
+    dta = time.perf_counter() - t0
+    out["all_cores"] = {
+        "value": 4.0 * (1 << all_cores_log) * threads / dta,
+        "unit": "M31 field-elems/s",
+        "cores": threads,
+        "nproc": os.cpu_count(),
+        "sample": f"{threads} distinct blobs, one {name} on a 2^{all_cores_log} domain per core, {threads} threads of the "
+        f"{os.cpu_count()} cores visible here (nproc), {dta:.1f} s wall",
+        "first_root": bytes(roots[0]).hex(),
+    }
+    return out
 
 
-def main():
-    # The contract is ONE JSON line on stdout.  RCCL (and anything else linked in) may write banners to the C stdout, which is
-    # flushed at exit — after our line.  Keep the real stdout for the JSON alone and send every other fd-1 writer to stderr.
-    sys.stdout.flush()
-    real_stdout = os.dup(1)
-    os.dup2(2, 1)
+def reference_bench_sizes(ctx, frieda_amd, torch):
+    """The reference's own bench inputs (benches/commit.rs:6-10: (i % 256) for 1024 / 4096 / 16384 / 65536 bytes + the blob
+    fixture; benches/proof.rs:5-12 config, seed = Some(len)): CPU oracle (1 thread) beside the GPU path, roots compared."""
+    from oracle import oracle as O
+
+    O.build()
+    cfg = frieda_amd.PcsConfig(frieda_amd.FriConfig(4, 0, 20), 20)
+    ocfg = O.make_config(20, 4, 0, 20)
+    inputs = [(f"pattern:{n}", (np.arange(n, dtype=np.uint64) % 256).astype(np.uint8)) for n in (1024, 4096, 16384, 65536)]
+    blob_path = os.path.join(ROOT, "tests", "golden", "blob")
+    if os.path.exists(blob_path):
+        inputs.append(("blob", np.frombuffer(open(blob_path, "rb").read(), dtype=np.uint8)))
+    rows = []
+    for name, data in inputs:
+        d = torch.from_numpy(data.copy()).cuda()
+        d_root = torch.zeros(32, dtype=torch.uint8, device="cuda")
+
+        def timed(fn, reps):
+            fn()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                r = fn()
+            ctx.synchronize()
+            return (time.perf_counter() - t0) / reps * 1e3, r
+
+        gpu_commit_ms, _ = timed(lambda: ctx.commit_device(d.data_ptr(), data.size, 4, d_root.data_ptr()), 50)
+        gpu_root = bytes(d_root.cpu().numpy())
+        gpu_prove_ms, (p_root, proof) = timed(lambda: ctx.commit_and_generate_proof_device(d.data_ptr(), data.size, data.size, cfg), 20)
+        t0 = time.perf_counter()
+        c_root = bytes(O.commit(data, 4))
+        cpu_commit_ms = (time.perf_counter() - t0) * 1e3
+        t0 = time.perf_counter()
+        o_root, o_proof = O.commit_and_generate_proof(data, data.size, ocfg)
+        cpu_prove_ms = (time.perf_counter() - t0) * 1e3
+        rows.append(
+            {
+                "input": name,
+                "bytes": int(data.size),
+                "cpu_commit_ms": cpu_commit_ms,
+                "gpu_commit_ms": gpu_commit_ms,
+                "cpu_prove_ms": cpu_prove_ms,
+                "gpu_prove_ms": gpu_prove_ms,
+                "roots_equal": gpu_root == c_root == p_root == bytes(o_root),
+                "proofs_equal": proof.serialize() == o_proof.serialize(),
+            }
+        )
+    return rows
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=60)
@@ -116,7 +211,117 @@ def main():
     ap.add_argument("--no-twiddle-cache", action="store_true", help="regenerate twiddles every call, as the reference does")
     ap.add_argument("--batch-extra", type=int, default=4, help="blobs per call for the extra 'batched' figure (0 = skip)")
     ap.add_argument("--pipeline-depth", type=int, default=2, help="proofs in flight for the extra 'pipelined' figure (0 = skip)")
-    args = ap.parse_args()
+    ap.add_argument("--dry-collective", choices=["gloo"], default=None,
+                    help="CPU rehearsal of the N > 1 plumbing: launcher, rendezvous, barriers, root all_gather and max-reduce over gloo; GPU work stubbed")
+    ap.add_argument("--launch-timeout", type=float, default=1500.0, help="seconds the self-launcher waits for its ranks")
+    return ap.parse_args(argv)
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` without a launcher: spawn the N ranks ourselves.  This parent never imports torch.cuda or
+    touches HIP (a process that has initialised the GPU must not be replaced or forked); every rank is a fresh interpreter."""
+    import socket
+    import subprocess
+
+    n = args.gpus
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   FRIEDA_BENCH_SELF_LAUNCHED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=None))
+    import threading
+
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    deadline = time.time() + args.launch_timeout
+    worst = 0
+    try:
+        while any(p.poll() is None for p in procs):
+            if any(p.poll() not in (None, 0) for p in procs):
+                break  # a rank died: the others would wait in the rendezvous or a collective for ever
+            if time.time() > deadline:
+                worst = 124
+                break
+            time.sleep(0.1)
+    finally:
+        for p in procs:  # exactly the PIDs started above
+            if p.poll() is None:
+                p.kill()
+            p.wait()
+            if p.returncode != 0:
+                worst = max(worst, abs(p.returncode), 1)
+    reader.join(timeout=10)
+    out0 = b"".join(c for c in chunks if c)
+    lines = [ln for ln in out0.decode(errors="replace").splitlines() if ln.startswith("{")]
+    if worst == 0 and len(lines) != 1:
+        worst = 1
+    if lines:
+        sys.stdout.write(lines[-1] + "\n")
+        sys.stdout.flush()
+    return worst
+
+
+def dry_run(args):
+    """The distributed skeleton of main() on CPU tensors over gloo: same barriers, same root all_gather, same max-reduce; the
+    GPU step is a stub that fabricates a 32-byte root from (rank, step).  For tests of the N > 1 plumbing only."""
+    import hashlib
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    if os.environ.get("FRIEDA_BENCH_TEST_FAIL_RANK") == str(rank):  # test hook: a rank that dies before the rendezvous
+        return 7
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29511")
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    from frieda_amd import batch
+
+    K = args.steps
+    dist.barrier()
+    t0 = time.perf_counter()
+    roots = b"".join(hashlib.sha256(f"{rank}:{i}".encode()).digest() for i in range(K))
+    gathered = batch.gather_rank_roots(roots, torch.device("cpu"))
+    dist.barrier()
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    for r in range(world):
+        exp = b"".join(hashlib.sha256(f"{r}:{i}".encode()).digest() for i in range(K))
+        assert bytes(gathered[r].numpy()) == exp, "root gather mismatch"
+    if rank == 0:
+        out = {
+            "metric": "M31 field-elems/s committed (NTT+FRI+Merkle)", "value": 0.0, "unit": "M31 field-elems/s", "n_gpus": world,
+            "steps": K, "warmup": args.warmup, "ms_per_step": 1e3 * float(t.item()) / max(K, 1), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "none (dry run: GPU work stubbed)", "dry_run": True,
+            "config": {"workload": "dry-collective gloo: launcher + rendezvous + root all_gather only", "log_domain": args.log_domain},
+            "roots_gathered": int(gathered.numel() // 32),
+        }
+        sys.stdout.write(json.dumps(out) + "\n")
+        sys.stdout.flush()
+    dist.destroy_process_group()
+    return 0
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))
+    if args.dry_collective:
+        sys.exit(dry_run(args))
+    # The contract is ONE JSON line on stdout.  RCCL (and anything else linked in) may write banners to the C stdout, which is
+    # flushed at exit — after our line.  Keep the real stdout for the JSON alone and send every other fd-1 writer to stderr.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
 
     # the host driver of this pool only supports dmabuf IPC: without this RCCL fails with hipIpcGetMemHandle: invalid argument
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -126,8 +331,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: start one rank per GPU (or drop WORLD_SIZE and let bench.py launch them)")
     # one rank per GPU; if the launcher narrowed the visible devices per rank, index what is visible
     local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
@@ -250,7 +454,8 @@ def main():
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": ach / HBM_PEAK_GBS,
-            "traffic": traffic_from_profiles(dom["name"], n, args.workload),
+            "traffic": traffic_from_profiles(dom["name"], n, args.workload)[0],
+            "traffic_source": traffic_from_profiles(dom["name"], n, args.workload)[1],
             "avg_launch_us": 1e3 * dom["total_ms"] / max(dom["launches"], 1),
             "launches_per_step": dom["launches"] / args.steps,
             "alg_bytes_per_launch": dom["alg_bytes"] / max(dom["launches"], 1),
@@ -316,6 +521,22 @@ def main():
         del res
         bctx.close()
 
+    # ---- extra figure: twiddles regenerated on every call, as the reference does (src/commit.rs:15, src/proof.rs:47) ----
+    uncached = None
+    if not args.no_twiddle_cache and world == 1:
+        ctx.set_twiddle_cache(False)
+        reps = max(3, args.steps // 4)
+        step()
+        torch.cuda.synchronize()
+        tu0 = time.perf_counter()
+        for _ in range(reps):
+            step()
+        ctx.synchronize()
+        dtu = (time.perf_counter() - tu0) / reps
+        ctx.set_twiddle_cache(True)
+        uncached = {"ms_per_step": 1e3 * dtu, "value": elems / dtu, "unit": "M31 field-elems/s",
+                    "note": "same step with frieda_ctx_set_twiddle_cache(0): twiddle tables regenerated on the device every call"}
+
     # secondary ceiling: the path is bound by the integer VALU rate of Blake2s, not by HBM.  For the first-tree
     # kernel (16.8 M leaf + 15.7 M node compressions at n = 24) compare with the chip's measured pure-compute rate
     # (profiles/r01_blake2s_rate_mi355x.txt: 40.9 G leaf / 39.8 G node compressions per second).
@@ -375,6 +596,7 @@ def main():
                 {"name": k["name"], "ms_per_step": k["total_ms"] / args.steps, "launches_per_step": k["launches"] / args.steps} for k in kern
             ],
         },
+        "uncached_twiddles": uncached,
         "pipelined": pipelined,
         "batched": batched,
         "root": root.hex() if root else None,
@@ -384,6 +606,7 @@ def main():
         if args.cpu_sample_log == n:  # the very same blob and configuration: the CPU root must be the GPU root
             assert cb["root"] == out["root"], "CPU baseline root differs from the GPU root"
             cb["root_equals_gpu_root"] = True
+        cb["reference_bench_sizes"] = reference_bench_sizes(ctx, frieda_amd, torch)
         out["cpu_baseline"] = cb
     elif rank == 0:
         out["cpu_baseline"] = None

@@ -141,8 +141,8 @@ class Context:
         a = np.ascontiguousarray(host_arr, dtype=np.uint32)
         d_in, d_out = C.c_void_p(), C.c_void_p()
         _check(self._L.frieda_dev_alloc(self._h, a.nbytes, C.byref(d_in)), self._h)
-        _check(self._L.frieda_dev_alloc(self._h, n_out_bytes + 16, C.byref(d_out)), self._h)
         try:
+            _check(self._L.frieda_dev_alloc(self._h, n_out_bytes + 16, C.byref(d_out)), self._h)
             _check(self._L.frieda_dev_upload(self._h, d_in, a.ctypes.data, a.nbytes), self._h)
             call(d_in, d_out)
             out = (C.c_uint8 * max(n_out_bytes, 1))()
@@ -151,7 +151,8 @@ class Context:
             return bytes(out)[:n_out_bytes]
         finally:
             self._L.frieda_dev_free(self._h, d_in)
-            self._L.frieda_dev_free(self._h, d_out)
+            if d_out:
+                self._L.frieda_dev_free(self._h, d_out)
 
     def reconstruct_from_block(self, block, log_domain, block_index, n_bytes):
         """block: uint32[4, 2^L] = entries block_index * 2^L .. of the four bit-reversed evaluation columns -> the blob."""

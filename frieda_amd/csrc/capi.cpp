@@ -544,6 +544,7 @@ int frieda_reconstruct_device(frieda_ctx* ctx, const uint32_t* d_block, uint32_t
     if ((uint64_t)block >= ((uint64_t)1 << (log_domain - log_coef))) return FRIEDA_ERR_ARG;
     const size_t n_felts = (size_t)4 << log_coef;
     if ((8 * len + 29) / 30 > n_felts) return ctx->c.fail(FRIEDA_ERR_ARG, "len does not fit the polynomial");
+    FR_NO_JOB(&ctx->c);
     FR_GUARD_BEGIN
     FR_HIP(&ctx->c, hipSetDevice(ctx->c.device));
     int rc = ctx->c.ensure_arena(sizeof(uint32_t) * n_felts);
@@ -612,6 +613,7 @@ bool cells_matrix_inverse(const uint32_t* cell_index, uint32_t R, uint32_t m, ui
 int interpolate_cells(frieda_ctx* ctx, const uint32_t* d_cells, const uint32_t* cell_index, uint32_t n_cells, uint32_t ncols, uint32_t log_cell,
                       uint32_t log_coef, uint32_t log_domain, uint32_t* d_coef, size_t arena_off) {
     Ctx& c = ctx->c;
+    FR_NO_JOB(&c);
     if (log_cell < 1 || log_cell > log_coef || log_coef > log_domain || log_domain > FRIEDA_MAX_LOG_DOMAIN)
         return c.fail(FRIEDA_ERR_ARG, "cells: need 1 <= log_cell <= log_coef <= log_domain");
     if (log_coef - log_cell > 8 || n_cells != (1u << (log_coef - log_cell)))
@@ -673,6 +675,7 @@ int frieda_reconstruct_cells_device(frieda_ctx* ctx, const uint32_t* d_cells, co
 int frieda_merkle_commit_layer(frieda_ctx* ctx, uint32_t log_size, const void* d_prev, const uint32_t* const* d_cols, uint32_t ncols,
                                void* d_out) {
     if (!ctx || !d_out || log_size > FRIEDA_MAX_LOG_DOMAIN || (ncols && !d_cols) || ncols > 1024) return FRIEDA_ERR_ARG;
+    FR_NO_JOB(&ctx->c);
     FR_GUARD_BEGIN
     FR_HIP(&ctx->c, hipSetDevice(ctx->c.device));
     hipStream_t s = ctx->c.stream;
@@ -709,6 +712,7 @@ int frieda_merkle_commit(frieda_ctx* ctx, const uint32_t* d_cols, uint32_t log_s
 
 int frieda_merkle_root(frieda_ctx* ctx, const uint32_t* d_cols, uint32_t log_size, void* d_root) {
     if (!ctx || !d_cols || !d_root || log_size > FRIEDA_MAX_LOG_DOMAIN) return FRIEDA_ERR_ARG;
+    FR_NO_JOB(&ctx->c);
     FR_GUARD_BEGIN
     FR_HIP(&ctx->c, hipSetDevice(ctx->c.device));
     int rc = ctx->c.ensure_arena(k::merkle_root_scratch_bytes(log_size));
@@ -753,6 +757,7 @@ int frieda_fold_line(frieda_ctx* ctx, const uint32_t* d_src, uint32_t line_log, 
 
 int frieda_grind(frieda_ctx* ctx, const uint8_t digest[32], uint32_t pow_bits, uint64_t* nonce) {
     if (!ctx || !digest || !nonce || pow_bits > 48) return FRIEDA_ERR_ARG;
+    FR_NO_JOB(&ctx->c);
     FR_GUARD_BEGIN
     FR_HIP(&ctx->c, hipSetDevice(ctx->c.device));
     int rc = ctx->c.ensure_arena(256);

@@ -189,9 +189,16 @@ int Ctx::get_twiddles(uint32_t n, TwiddleSet& out) {
         ts = it->second;  // regenerate into the existing buffers (reference behaviour: recomputed per call)
     } else {
         size_t bytes = sizeof(uint32_t) << (n - 1);
-        FR_HIP(this, hipMalloc((void**)&ts.d_tw, bytes));
-        FR_HIP(this, hipMalloc((void**)&ts.d_itw, bytes));
-        FR_HIP(this, hipMalloc((void**)&ts.d_scratch, 8192));
+        hipError_t e = hipMalloc((void**)&ts.d_tw, bytes);
+        if (e == hipSuccess) e = hipMalloc((void**)&ts.d_itw, bytes);
+        if (e == hipSuccess) e = hipMalloc((void**)&ts.d_scratch, 8192);
+        if (e != hipSuccess) {  // nothing of a half-allocated set survives
+            if (ts.d_tw) (void)hipFree(ts.d_tw);
+            if (ts.d_itw) (void)hipFree(ts.d_itw);
+            err = std::string("hipMalloc(twiddles, 2 x ") + std::to_string(bytes) + " B): " + hipGetErrorString(e);
+            return FRIEDA_ERR_NOMEM;
+        }
+        twiddles[n] = ts;  // owned by the cache from here on, whatever happens below
     }
     // seeds: initial point of half_odds(n-1) and the step multiples the kernel combines
     Coset h = Coset::half_odds(n - 1);

@@ -114,6 +114,14 @@ struct Ctx {
         if (e__ != hipSuccess) return (ctx)->hip_fail(e__, #expr);   \
     } while (0)
 
+// One proof (or batch) may be in flight per context between prove_begin and prove_finish: its workspace offsets point into the
+// arena and its transcript summary sits in the pinned block.  Every other entry point that (re)allocates or writes either of
+// them refuses to run meanwhile.
+#define FR_NO_JOB(ctx)                                                                                                 \
+    do {                                                                                                               \
+        if ((ctx)->job) return (ctx)->fail(FRIEDA_ERR_ARG, "a proof is in flight on this context (finish it first, or use another context)"); \
+    } while (0)
+
 // bump allocator over the ctx arena (sizes are planned before ensure_arena)
 struct ArenaPlan {
     size_t off = 0;

@@ -48,12 +48,15 @@ struct Shape {
 };
 
 int make_shape(Ctx* ctx, size_t len, uint32_t B, Shape& sh) {
+    // B arrives unchecked from the caller (a ctypes c_uint32 turns -1 into 0xFFFFFFFF): bound it before any sum is formed
+    if (B > FRIEDA_MAX_LOG_DOMAIN) return ctx->fail(FRIEDA_ERR_ARG, "log_blowup_factor larger than FRIEDA_MAX_LOG_DOMAIN");
+    if (len > ((size_t)1 << 40)) return ctx->fail(FRIEDA_ERR_ARG, "blob larger than 2^40 bytes");
     sh.cs = codec_shape(len);
     sh.L = sh.cs.log_size;
     sh.B = B;
     // Coset::half_odds(L + B - 1) panics for L + B == 0 (u32 underflow)
-    if (sh.L + B < 1) return ctx->fail(FRIEDA_ERR_INVARIANT, "log_size + log_blowup_factor must be >= 1");
-    if (sh.L + B > FRIEDA_MAX_LOG_DOMAIN) return ctx->fail(FRIEDA_ERR_ARG, "domain larger than FRIEDA_MAX_LOG_DOMAIN");
+    if ((uint64_t)sh.L + B < 1) return ctx->fail(FRIEDA_ERR_INVARIANT, "log_size + log_blowup_factor must be >= 1");
+    if ((uint64_t)sh.L + B > FRIEDA_MAX_LOG_DOMAIN) return ctx->fail(FRIEDA_ERR_ARG, "domain larger than FRIEDA_MAX_LOG_DOMAIN");
     sh.n = sh.L + B;
     sh.N = (size_t)1 << sh.n;
     return FRIEDA_OK;
@@ -100,6 +103,7 @@ void bit_reverse_vec(std::vector<QM31>& v, size_t count, uint32_t lg) {
 // commit
 // -------------------------------------------------------------------------------------------------
 int commit_device(Ctx* ctx, const uint8_t* d_data, size_t len, uint32_t log_blowup, uint8_t* d_root, bool data_in_arena) {
+    FR_NO_JOB(ctx);
     Shape sh;
     int rc = make_shape(ctx, len, log_blowup, sh);
     if (rc) return rc;
@@ -131,6 +135,7 @@ int commit_device(Ctx* ctx, const uint8_t* d_data, size_t len, uint32_t log_blow
 }
 
 int commit_host(Ctx* ctx, const uint8_t* data, size_t len, uint32_t log_blowup, uint8_t out_root[32]) {
+    FR_NO_JOB(ctx);
     Shape sh;
     int rc = make_shape(ctx, len, log_blowup, sh);
     if (rc) return rc;
@@ -158,6 +163,7 @@ int commit_host(Ctx* ctx, const uint8_t* data, size_t len, uint32_t log_blowup, 
 // commit() of `count` blobs of one length in one pass of launches (blob b at data + b * data_stride); roots to host memory
 int commit_batch(Ctx* ctx, const uint8_t* data, size_t data_stride, size_t len, uint32_t count, bool data_on_device, uint32_t log_blowup,
                  uint8_t* out_roots) {
+    FR_NO_JOB(ctx);
     if (count == 0 || count > 65535) return ctx->fail(FRIEDA_ERR_ARG, "batch count out of range");
     if (count > 1 && data_stride < len) return ctx->fail(FRIEDA_ERR_ARG, "batch stride smaller than the blob length");
     Shape sh;
@@ -367,6 +373,9 @@ int prove_begin_batch(Ctx* ctx, const uint8_t* data, size_t data_stride, size_t 
     if (count == 0 || count > 65535) return ctx->fail(FRIEDA_ERR_ARG, "batch count out of range");
     if (count > 1 && data_stride < len) return ctx->fail(FRIEDA_ERR_ARG, "batch stride smaller than the blob length");
     const uint32_t B = cfg.log_blowup_factor, last = cfg.log_last_layer_degree_bound;
+    // both arrive unchecked: bound them before `last + B` and the shifts that use it are formed
+    if (last > 10) return ctx->fail(FRIEDA_ERR_ARG, "log_last_layer_degree_bound > 10");
+    if (B > FRIEDA_MAX_LOG_DOMAIN) return ctx->fail(FRIEDA_ERR_ARG, "log_blowup_factor larger than FRIEDA_MAX_LOG_DOMAIN");
     std::unique_ptr<ProveJob, ProveJobDeleter> jp(new ProveJob());
     ProveJob& J = *jp;
     Shape& sh = J.sh;
@@ -375,7 +384,6 @@ int prove_begin_batch(Ctx* ctx, const uint8_t* data, size_t data_stride, size_t 
     // FriProver::commit_last_layer asserts evaluation.len() == last_layer_domain_size: needs L - 1 >= last;
     // the line domain half_odds(n - 1) needs n >= 2
     if (sh.n < 2 || sh.L < 1 + last) return ctx->fail(FRIEDA_ERR_INVARIANT, "polynomial too small for the FRI configuration");
-    if (last > 10) return ctx->fail(FRIEDA_ERR_ARG, "log_last_layer_degree_bound > 10");
     if (cfg.n_queries == 0 || cfg.n_queries > 4096) return ctx->fail(FRIEDA_ERR_ARG, "n_queries out of range");
     if (cfg.pow_bits > 48) return ctx->fail(FRIEDA_ERR_ARG, "pow_bits > 48");
     FR_HIP(ctx, hipSetDevice(ctx->device));

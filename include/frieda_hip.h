@@ -105,8 +105,13 @@ int frieda_commit_and_generate_proof_device(frieda_ctx* ctx, const void* d_data,
                                             frieda_pcs_config cfg, uint8_t out_commitment[32], frieda_proof** out);
 /* The same, split in two so that several proofs can overlap on one GPU: _begin enqueues everything — encode, FRI commit
  * phase, proof of work, query sampling and openings — on the ctx stream and returns without synchronising; _finish waits
- * for it (once) and builds the proof from the openings the device left in pinned memory.  At most one proof in flight per ctx — use one ctx (= one stream + workspace) per
- * in-flight proof.  A blob passed to _begin_device must stay valid until _finish returns. */
+ * for it (once) and builds the proof from the openings the device left in pinned memory.  At most one proof (or batch) in
+ * flight per ctx — use one ctx (= one stream + workspace) per in-flight proof.  While one is in flight, every other entry
+ * point that sizes or writes the ctx's workspace or pinned block returns FRIEDA_ERR_ARG ("a proof is in flight on this
+ * context") and leaves the proof untouched: frieda_commit*, frieda_commit_batch*, a second _begin, frieda_merkle_root,
+ * frieda_merkle_commit_layer, frieda_grind, frieda_reconstruct*_device, frieda_circle_interpolate_cells,
+ * frieda_ctx_release_workspace.  Level B calls that only read the twiddle cache and caller buffers stay available.
+ * A blob passed to _begin_device must stay valid until _finish returns. */
 int frieda_prove_begin(frieda_ctx* ctx, const uint8_t* data, size_t len, const uint64_t* seed, frieda_pcs_config cfg);
 int frieda_prove_begin_device(frieda_ctx* ctx, const void* d_data, size_t len, const uint64_t* seed, frieda_pcs_config cfg);
 int frieda_prove_finish(frieda_ctx* ctx, uint8_t out_commitment[32], frieda_proof** out);

@@ -380,6 +380,71 @@ def test_panics_map_to_status(gpu_ctx):
         gpu_ctx.generate_proof(b"tiny", None, _cfg(frieda_amd, 8, 4, 0, 4))
 
 
+@pytest.mark.parametrize("B", [-1, 0xFFFFFFFF, 0xFFFFFFFE, 29, 1 << 31])
+def test_huge_or_negative_blowup_is_refused(gpu_ctx, B):
+    """log_blowup_factor arrives unchecked (ctypes turns -1 into 0xFFFFFFFF): L + B must not wrap into a small domain."""
+    import frieda_amd
+
+    data = splitmix64_bytes(3, 16)  # L = 2: B = 0xFFFFFFFF would wrap L + B to 1
+    Bc = B & 0xFFFFFFFF
+    with pytest.raises(frieda_amd.FriedaError):
+        gpu_ctx.commit(data.tobytes(), Bc)
+    buf = (C.c_uint8 * 64)(*data.tolist(), *([0] * 48))
+    roots = (C.c_uint8 * 64)()
+    assert gpu_ctx._L.frieda_commit_batch(gpu_ctx._h, buf, 16, 16, 2, Bc, roots) == 1  # FRIEDA_ERR_ARG
+    cfg = _cfg(frieda_amd, 4, Bc, 0, 5)
+    with pytest.raises(frieda_amd.FriedaError):
+        gpu_ctx.commit_and_generate_proof(data.tobytes(), None, cfg)
+    with pytest.raises(frieda_amd.FriedaError):
+        gpu_ctx.prove_begin(data.tobytes(), None, cfg)
+    with pytest.raises(frieda_amd.FriedaError):
+        gpu_ctx.commit_and_generate_proof_batch([data.tobytes()] * 2, None, cfg)
+    # log_last_layer_degree_bound is bounded before it is added to B, too
+    with pytest.raises(frieda_amd.FriedaError):
+        gpu_ctx.commit_and_generate_proof(data.tobytes(), None, _cfg(frieda_amd, 4, 4, 0xFFFFFFFC, 5))
+    # the context is still usable
+    assert len(gpu_ctx.commit(data.tobytes(), 4)) == 32
+
+
+def test_proof_in_flight_blocks_every_workspace_user(gpu_ctx, oracle):
+    """Between prove_begin and prove_finish the job's offsets point into the arena and its transcript summary sits in the pinned
+    block: every other entry point that (re)allocates or writes either must refuse, and the proof must come out unharmed."""
+    import torch
+
+    import frieda_amd
+
+    cfg = _cfg(frieda_amd, 10, 4, 0, 12)
+    blob = splitmix64_bytes(77, 20000).tobytes()
+    big = splitmix64_bytes(78, 400000)  # a larger call would have re-allocated the arena
+    d_big = torch.from_numpy(big).cuda()
+    d_root = torch.zeros(32, dtype=torch.uint8, device="cuda")
+    cols = DevBuf.from_array(gpu_ctx, rand_m31(np.random.default_rng(1), (4, 64)))
+    out = DevBuf(gpu_ctx, 32 * 64)
+    gpu_ctx.prove_begin(blob, 5, cfg)
+    L, h = gpu_ctx._L, gpu_ctx._h
+    with pytest.raises(frieda_amd.FriedaError, match="in flight"):
+        gpu_ctx.commit(big.tobytes(), 4)
+    with pytest.raises(frieda_amd.FriedaError, match="in flight"):
+        gpu_ctx.commit_device(d_big.data_ptr(), big.size, 4, d_root.data_ptr())
+    with pytest.raises(frieda_amd.FriedaError, match="in flight"):
+        gpu_ctx.commit_batch([big.tobytes()] * 2, 4)
+    with pytest.raises(frieda_amd.FriedaError, match="in flight"):
+        gpu_ctx.prove_begin(blob, 5, cfg)
+    assert L.frieda_merkle_root(h, cols.ptr, 6, out.ptr) == 1
+    digest = (C.c_uint8 * 32)()
+    nonce = C.c_uint64()
+    assert L.frieda_grind(h, digest, 4, C.byref(nonce)) == 1
+    assert L.frieda_reconstruct_device(h, cols.ptr, 6, 10, 0, 100, out.ptr) == 1
+    idx = (C.c_uint32 * 1)(0)
+    assert L.frieda_circle_interpolate_cells(h, cols.ptr, idx, 1, 4, 6, 6, 10, out.ptr) == 1
+    assert L.frieda_ctx_release_workspace(h) == 1
+    root, proof = gpu_ctx.prove_finish()
+    o_root, o_proof = oracle.commit_and_generate_proof(blob, 5, oracle.make_config(10, 4, 0, 12))
+    assert root == o_root and proof.serialize() == o_proof.serialize()
+    # and everything works again afterwards
+    assert gpu_ctx.commit(big.tobytes(), 4) == oracle.commit(big.tobytes(), 4)
+
+
 # ------------------------------------------------------------------------------------------------
 # full sizes: properties that do not need the oracle at size
 # ------------------------------------------------------------------------------------------------

@@ -147,3 +147,46 @@ def test_bench_root_exchange_world2_gloo():
         for r in range(world):
             assert rows[r] == b"".join(bytes([(7 * r + i) % 256]) * 32 for i in range(k)), (rank, r)
 
+
+
+def _run_bench(argv, env_extra=None, timeout=300):
+    import json
+    import subprocess
+
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(env_extra or {})
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + argv, capture_output=True, text=True, timeout=timeout, env=env)
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    return r, [json.loads(ln) for ln in lines if ln.startswith("{")]
+
+
+@pytest.mark.parametrize("gpus", [2, 3])
+def test_bench_self_launches_its_ranks(gpus):
+    """`python bench.py --gpus N` (no torch.distributed.run, no WORLD_SIZE) spawns its N ranks itself and relays rank 0's single
+    JSON line.  `--dry-collective gloo` keeps the launcher, rendezvous, barriers, root all_gather and max-reduce and stubs the GPU."""
+    r, docs = _run_bench(["--gpus", str(gpus), "--steps", "5", "--warmup", "1", "--dry-collective", "gloo"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert len(docs) == 1 and r.stdout.count("\n") == 1
+    d = docs[0]
+    assert d["n_gpus"] == gpus and d["steps"] == 5 and d["dry_run"] is True and d["scaling"] == "weak"
+    assert d["roots_gathered"] == gpus * 5
+
+
+def test_bench_under_an_external_launcher_does_not_respawn():
+    """Started the way the driver starts it (torch.distributed.run sets WORLD_SIZE / RANK), bench.py must not spawn anything."""
+    import subprocess
+
+    port = _free_port()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port",
+           str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--dry-collective", "gloo"]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1 and '"n_gpus": 2' in lines[0]
+
+
+def test_bench_self_launch_reports_a_failing_rank():
+    """A rank that dies takes the launch down with a non-zero status instead of leaving the others in the rendezvous."""
+    r, docs = _run_bench(["--gpus", "2", "--steps", "2", "--dry-collective", "gloo"], env_extra={"FRIEDA_BENCH_TEST_FAIL_RANK": "1"}, timeout=120)
+    assert r.returncode != 0 and docs == []
