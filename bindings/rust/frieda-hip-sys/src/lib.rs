@@ -10,6 +10,10 @@ pub struct frieda_ctx {
     _private: [u8; 0],
 }
 #[repr(C)]
+pub struct frieda_multi {
+    _private: [u8; 0],
+}
+#[repr(C)]
 pub struct frieda_proof {
     _private: [u8; 0],
 }
@@ -46,6 +50,8 @@ extern "C" {
     pub fn frieda_ctx_test_set_draw_bound(ctx: *mut frieda_ctx, bound: u32) -> c_int;
     pub fn frieda_ctx_set_kernel_timing(ctx: *mut frieda_ctx, enabled: c_int) -> c_int;
     pub fn frieda_ctx_last_prove_phases(ctx: *const frieda_ctx, out_ms: *mut f64) -> c_int;
+    /// diagnostic: alphas per FRI layer and the pre-grind channel digest of the last finished proof
+    pub fn frieda_ctx_last_transcript(ctx: *const frieda_ctx, n_layers: *mut u32, alphas: *mut u32, cap_layers: usize, digest_before_grind: *mut u8) -> c_int;
     pub fn frieda_ctx_kernel_timing_report(ctx: *mut frieda_ctx, buf: *mut c_char, cap: usize, reset: c_int) -> usize;
 
     // Level A
@@ -64,6 +70,16 @@ extern "C" {
     pub fn frieda_commit_batch(ctx: *mut frieda_ctx, data: *const u8, stride: usize, len: usize, count: u32, log_blowup_factor: u32, out_roots: *mut u8) -> c_int;
     pub fn frieda_commit_batch_device(ctx: *mut frieda_ctx, d_data: *const c_void, stride: usize, len: usize, count: u32, log_blowup_factor: u32, out_roots: *mut u8) -> c_int;
     pub fn frieda_generate_proof(ctx: *mut frieda_ctx, data: *const u8, len: usize, seed: *const u64, cfg: frieda_pcs_config, out: *mut *mut frieda_proof) -> c_int;
+    // multi-GPU: blob i -> devices[i mod n]; roots gathered with ncclAllGather on a single-process communicator
+    pub fn frieda_multi_create(devices: *const c_int, n_devices: u32, out: *mut *mut frieda_multi) -> c_int;
+    pub fn frieda_multi_destroy(m: *mut frieda_multi) -> c_int;
+    pub fn frieda_multi_device_count(m: *const frieda_multi) -> u32;
+    pub fn frieda_multi_last_error(m: *const frieda_multi) -> *const c_char;
+    pub fn frieda_multi_uses_rccl(m: *const frieda_multi) -> c_int;
+    pub fn frieda_multi_gather_count(m: *const frieda_multi) -> u64;
+    pub fn frieda_multi_ctx(m: *mut frieda_multi, device_slot: u32) -> *mut frieda_ctx;
+    pub fn frieda_commit_many(m: *mut frieda_multi, blobs: *const *const u8, lens: *const usize, count: u32, log_blowup_factor: u32, out_roots: *mut u8) -> c_int;
+    pub fn frieda_prove_many(m: *mut frieda_multi, blobs: *const *const u8, lens: *const usize, count: u32, seeds: *const u64, cfg: frieda_pcs_config, out_commitments: *mut u8, out_proofs: *mut *mut frieda_proof) -> c_int;
     pub fn frieda_verify(proof: *const frieda_proof, seed: *const u64, ok: *mut c_int) -> c_int;
 
     // struct Proof
@@ -91,6 +107,11 @@ extern "C" {
     pub fn frieda_dev_upload(ctx: *mut frieda_ctx, d_dst: *mut c_void, h_src: *const c_void, bytes: usize) -> c_int;
     pub fn frieda_dev_download(ctx: *mut frieda_ctx, h_dst: *mut c_void, d_src: *const c_void, bytes: usize) -> c_int;
     // Level B: codec, PolyOps, MerkleOps, FriOps, GrindOps
+    /// Column::at for a BaseField column / a SecureColumn (SoA); synchronises the ctx stream
+    pub fn frieda_dev_at(ctx: *mut frieda_ctx, d_col: *const u32, index: usize, out: *mut u32) -> c_int;
+    pub fn frieda_dev_at_secure(ctx: *mut frieda_ctx, d_cols: *const u32, stride: usize, index: usize, out: *mut u32) -> c_int;
+    /// ColumnOps::bit_reverse_column, in place (ncols = 1: BaseField column; 4: SecureColumn)
+    pub fn frieda_bit_reverse_column(ctx: *mut frieda_ctx, d_cols: *mut u32, stride: usize, ncols: u32, log_size: u32) -> c_int;
     pub fn frieda_codec_shape(len: usize, n_felts: *mut usize, n_padded: *mut usize, log_size: *mut u32) -> c_int;
     pub fn frieda_unpack30(ctx: *mut frieda_ctx, d_bytes: *const c_void, len: usize, d_coef: *mut u32, n_out: usize) -> c_int;
     pub fn frieda_pack30(ctx: *mut frieda_ctx, d_felts: *const u32, n_felts: usize, d_bytes: *mut c_void, len: usize) -> c_int;

@@ -8,6 +8,7 @@ from .api import (  # noqa: F401
     FriConfig,
     FriedaError,
     FriedaPanic,
+    MultiContext,
     PcsConfig,
     Proof,
     ProofPipeline,
@@ -23,6 +24,7 @@ __all__ = [
     "FriConfig",
     "FriedaError",
     "FriedaPanic",
+    "MultiContext",
     "PcsConfig",
     "Proof",
     "ProofPipeline",

@@ -68,6 +68,7 @@ def lib():
         "frieda_ctx_test_set_draw_bound": (C.c_int, [vp, u32]),
         "frieda_ctx_set_kernel_timing": (C.c_int, [vp, C.c_int]),
         "frieda_ctx_last_prove_phases": (C.c_int, [vp, C.POINTER(C.c_double)]),
+        "frieda_ctx_last_transcript": (C.c_int, [vp, C.POINTER(u32), vp, sz, vp]),
         "frieda_ctx_kernel_timing_report": (sz, [vp, vp, sz, C.c_int]),
         "frieda_commit": (C.c_int, [vp, vp, sz, u32, vp]),
         "frieda_commit_device": (C.c_int, [vp, vp, sz, u32, vp]),
@@ -84,6 +85,15 @@ def lib():
         "frieda_prove_batch_finish": (C.c_int, [vp, u32, vp, pp]),
         "frieda_commit_batch": (C.c_int, [vp, vp, sz, sz, u32, u32, vp]),
         "frieda_commit_batch_device": (C.c_int, [vp, vp, sz, sz, u32, u32, vp]),
+        "frieda_multi_create": (C.c_int, [C.POINTER(C.c_int), u32, pp]),
+        "frieda_multi_destroy": (C.c_int, [vp]),
+        "frieda_multi_device_count": (u32, [vp]),
+        "frieda_multi_last_error": (C.c_char_p, [vp]),
+        "frieda_multi_uses_rccl": (C.c_int, [vp]),
+        "frieda_multi_gather_count": (u64, [vp]),
+        "frieda_multi_ctx": (vp, [vp, u32]),
+        "frieda_commit_many": (C.c_int, [vp, pp, C.POINTER(sz), u32, u32, vp]),
+        "frieda_prove_many": (C.c_int, [vp, pp, C.POINTER(sz), u32, u64p, PcsConfigC, vp, pp]),
         "frieda_verify": (C.c_int, [vp, u64p, C.POINTER(C.c_int)]),
         "frieda_proof_free": (None, [vp]),
         "frieda_proof_clone": (C.c_int, [vp, pp]),
@@ -106,6 +116,9 @@ def lib():
         "frieda_dev_free": (C.c_int, [vp, vp]),
         "frieda_dev_upload": (C.c_int, [vp, vp, vp, sz]),
         "frieda_dev_download": (C.c_int, [vp, vp, vp, sz]),
+        "frieda_dev_at": (C.c_int, [vp, vp, sz, C.POINTER(u32)]),
+        "frieda_dev_at_secure": (C.c_int, [vp, vp, sz, sz, C.POINTER(u32)]),
+        "frieda_bit_reverse_column": (C.c_int, [vp, vp, sz, u32, u32]),
         "frieda_codec_shape": (C.c_int, [sz, C.POINTER(sz), C.POINTER(sz), C.POINTER(u32)]),
         "frieda_unpack30": (C.c_int, [vp, vp, sz, vp, sz]),
         "frieda_precompute_twiddles": (C.c_int, [vp, u32, pp, pp]),

@@ -113,6 +113,14 @@ class Context:
         _check(self._L.frieda_ctx_last_prove_phases(self._h, a), self._h)
         return dict(zip(["enqueued", "device_done", "queries", "gathered", "assembled", "first_launch_after_entry"], list(a)[:6]))
 
+    def last_transcript(self):
+        """Diagnostic: alphas drawn per FRI layer and the channel digest the grind was keyed by, of the last finished proof."""
+        n = C.c_uint32()
+        alphas = (C.c_uint32 * (4 * 64))()
+        digest = (C.c_uint8 * 32)()
+        _check(self._L.frieda_ctx_last_transcript(self._h, C.byref(n), alphas, 64, digest), self._h)
+        return {"alphas": [[int(alphas[4 * i + c]) for c in range(4)] for i in range(min(n.value, 64))], "digest_before_grind": bytes(digest)}
+
     def kernel_timing_report(self, reset=True):
         """Per-kernel HIP-event timings accumulated since the last reset: list of dicts."""
         import json
@@ -370,6 +378,78 @@ class Proof:
         out = C.c_void_p()
         _check(_lib.lib().frieda_proof_deserialize(a.ctypes.data, a.size, C.byref(out)))
         return Proof(out)
+
+
+class MultiContext:
+    """A batch of independent blobs across the GPUs of one node from ONE process (frieda_multi, include/frieda_hip.h): blob i runs
+    on devices[i mod n] (one host thread + two contexts per device), the 32-byte roots are gathered with ncclAllGather on a
+    single-process RCCL communicator.  The one-process-per-GPU launch model (bench.py, torch.distributed) lives in batch.py."""
+
+    def __init__(self, devices):
+        self._L = _lib.lib()
+        self._h = C.c_void_p()
+        devs = (C.c_int * len(devices))(*[int(d) for d in devices])
+        st = self._L.frieda_multi_create(devs, len(devices), C.byref(self._h))
+        if st != _lib.OK:
+            raise FriedaError(st, f"frieda_multi_create({list(devices)})")
+
+    def _check(self, st):
+        if st != _lib.OK:
+            detail = self._L.frieda_multi_last_error(self._h).decode(errors="replace")
+            raise (FriedaPanic if st == _lib.ERR_INVARIANT else FriedaError)(st, detail)
+
+    def close(self):
+        if self._h:
+            self._L.frieda_multi_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def device_count(self):
+        return self._L.frieda_multi_device_count(self._h)
+
+    @property
+    def uses_rccl(self):
+        return bool(self._L.frieda_multi_uses_rccl(self._h))
+
+    @property
+    def gather_count(self):
+        return int(self._L.frieda_multi_gather_count(self._h))
+
+    def _blob_table(self, blobs):
+        arrs = [_as_bytes(b) for b in blobs]
+        ptrs = (C.c_void_p * len(arrs))(*[a.ctypes.data if a.size else None for a in arrs])
+        lens = (C.c_size_t * len(arrs))(*[a.size for a in arrs])
+        return arrs, ptrs, lens
+
+    def commit_many(self, blobs, log_blowup_factor):
+        if not blobs:
+            return []
+        arrs, ptrs, lens = self._blob_table(blobs)
+        roots = (C.c_uint8 * (32 * len(arrs)))()
+        self._check(self._L.frieda_commit_many(self._h, ptrs, lens, len(arrs), log_blowup_factor, roots))
+        rb = bytes(roots)
+        return [rb[32 * i : 32 * i + 32] for i in range(len(arrs))]
+
+    def prove_many(self, blobs, seeds, pcs_config):
+        """-> [(commitment, Proof)] in blob order; seeds: None or one per blob"""
+        if not blobs:
+            return []
+        arrs, ptrs, lens = self._blob_table(blobs)
+        n = len(arrs)
+        if seeds is not None and len(seeds) != n:
+            raise ValueError("one seed per blob")
+        sd = (C.c_uint64 * n)(*seeds) if seeds is not None else None
+        roots = (C.c_uint8 * (32 * n))()
+        outs = (C.c_void_p * n)()
+        self._check(self._L.frieda_prove_many(self._h, ptrs, lens, n, sd, pcs_config._c(), roots, outs))
+        rb = bytes(roots)
+        return [(rb[32 * i : 32 * i + 32], Proof(C.c_void_p(outs[i]))) for i in range(n)]
 
 
 class ProofPipeline:

@@ -114,6 +114,18 @@ int frieda_ctx_last_prove_phases(const frieda_ctx* ctx, double out_ms[8]) {
     return FRIEDA_OK;
 }
 
+int frieda_ctx_last_transcript(const frieda_ctx* ctx, uint32_t* n_layers, uint32_t* alphas, size_t cap_layers, uint8_t digest_before_grind[32]) {
+    if (!ctx || !n_layers) return FRIEDA_ERR_ARG;
+    const Ctx::LastTranscript& t = ctx->c.last_transcript;
+    *n_layers = (uint32_t)t.alphas.size();
+    if (alphas)
+        for (size_t i = 0; i < t.alphas.size() && i < cap_layers; i++) memcpy(alphas + 4 * i, t.alphas[i].data(), 16);
+    if (digest_before_grind)
+        for (int w = 0; w < 8; w++)
+            for (int b = 0; b < 4; b++) digest_before_grind[4 * w + b] = (uint8_t)(t.digest_before_grind[w] >> (8 * b));
+    return FRIEDA_OK;
+}
+
 int frieda_ctx_test_set_draw_bound(frieda_ctx* ctx, uint32_t bound) {
     if (!ctx || bound > 2u * P31) return FRIEDA_ERR_ARG;
     ctx->c.test_draw_bound = bound ? bound : 2u * P31;
@@ -462,6 +474,31 @@ int frieda_dev_download(frieda_ctx* ctx, void* h_dst, const void* d_src, size_t 
     FR_HIP(&ctx->c, hipSetDevice(ctx->c.device));
     if (bytes) FR_HIP(&ctx->c, hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->c.stream));
     FR_HIP(&ctx->c, hipStreamSynchronize(ctx->c.stream));
+    return FRIEDA_OK;
+}
+
+int frieda_dev_at(frieda_ctx* ctx, const uint32_t* d_col, size_t index, uint32_t* out) {
+    if (!ctx || !d_col || !out) return FRIEDA_ERR_ARG;
+    FR_HIP(&ctx->c, hipSetDevice(ctx->c.device));
+    FR_HIP(&ctx->c, hipMemcpyAsync(out, d_col + index, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->c.stream));
+    FR_HIP(&ctx->c, hipStreamSynchronize(ctx->c.stream));
+    return FRIEDA_OK;
+}
+int frieda_dev_at_secure(frieda_ctx* ctx, const uint32_t* d_cols, size_t stride, size_t index, uint32_t out[4]) {
+    if (!ctx || !d_cols || !out || index >= stride) return FRIEDA_ERR_ARG;
+    FR_HIP(&ctx->c, hipSetDevice(ctx->c.device));
+    // one strided copy: 4 rows of 4 bytes, `stride` words apart
+    FR_HIP(&ctx->c, hipMemcpy2DAsync(out, sizeof(uint32_t), d_cols + index, sizeof(uint32_t) * stride, sizeof(uint32_t), 4,
+                                     hipMemcpyDeviceToHost, ctx->c.stream));
+    FR_HIP(&ctx->c, hipStreamSynchronize(ctx->c.stream));
+    return FRIEDA_OK;
+}
+int frieda_bit_reverse_column(frieda_ctx* ctx, uint32_t* d_cols, size_t stride, uint32_t ncols, uint32_t log_size) {
+    if (!ctx || !d_cols || ncols == 0 || ncols > 65535 || log_size > FRIEDA_MAX_LOG_DOMAIN) return FRIEDA_ERR_ARG;
+    if (ncols > 1 && stride < ((size_t)1 << log_size)) return ctx->c.fail(FRIEDA_ERR_ARG, "column stride smaller than the column");
+    FR_HIP(&ctx->c, hipSetDevice(ctx->c.device));
+    k::bit_reverse_columns(ctx->c.launch(), d_cols, stride, ncols, log_size);
+    FR_HIP(&ctx->c, hipGetLastError());
     return FRIEDA_OK;
 }
 

@@ -95,6 +95,12 @@ struct Ctx {
     double phase_ms[8] = {0};  // host wall-clock marks of the last prove() (ms since entry): enqueued, device done, queries, gather, assembled
     KernelTimerImpl* timer = nullptr;  // non-null while kernel timing is enabled
     std::unique_ptr<ProveJob, ProveJobDeleter> job;  // the proof in flight, if any
+    // Fiat-Shamir transcript of the last finished proof (blob 0 of a batch), kept for frieda_ctx_last_transcript
+    struct LastTranscript {
+        std::vector<Hash32> roots;                      // one per FRI layer (first + inner)
+        std::vector<std::array<uint32_t, 4>> alphas;    // the folding challenge drawn after each root
+        uint32_t digest_before_grind[8] = {0};          // channel digest after mix_felts(last_layer_poly)
+    } last_transcript;
 
     k::Launch launch() const;
     int set_kernel_timing(bool enabled);

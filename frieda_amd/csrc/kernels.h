@@ -54,6 +54,11 @@ struct DomainScalars {
 // d_bytes + b * src_bstride (the caller's layout); its felts go to d_out shifted by b * L.bstride bytes.
 void unpack30(const Launch& L, const uint8_t* d_bytes, size_t len, uint32_t* d_out, size_t n_out, size_t src_bstride = 0);
 
+// ---- column.hip ----
+// ColumnOps::bit_reverse_column in place on `ncols` columns of 2^log_size words, `stride` words apart (1 = BaseField column,
+// 4 = SecureColumn)
+void bit_reverse_columns(const Launch& L, uint32_t* d_cols, size_t stride, uint32_t ncols, uint32_t log_size);
+
 // ---- twiddle.hip ----
 struct TwiddleSeeds {
     CPoint p0;        // point(initial index of half_odds(n-1))

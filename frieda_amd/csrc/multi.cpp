@@ -1,0 +1,367 @@
+// multi.cpp — a batch of independent blobs across the GPUs of one node, behind the C ABI (include/frieda_hip.h, "multi-GPU").
+//
+// What it replaces: a caller looping `api::commit` / `proof::commit_and_generate_proof` over blobs
+// (/root/reference/src/lib.rs:31-38; the bench loops of benches/commit.rs:11-15, benches/proof.rs:30-44).  The blobs are
+// independent, so the path shards at blob granularity: blob i -> device i mod n, one host thread and two
+// contexts per device (two proofs in flight: the latency chain of one runs under the wide kernels of the other), no data-path
+// collective.  The only exchange is the gather of the 32-byte commitment roots: one `ncclAllGather` per device on a
+// single-process communicator (`ncclCommInitAll`) — RCCL over xGMI — after which every device holds every root (slot layout:
+// rank-major, blob i at rank i mod n, slot i div n); the host reads device 0's copy.  With one device there is nothing to
+// gather and RCCL is not touched (FRIEDA_MULTI_FORCE_RCCL=1 forces the one-rank collective: the hardware test of this file).
+//
+// RCCL is bound at frieda_multi_create by dlopen, not by a NEEDED entry: a process that already carries an RCCL (PyTorch
+// bundles its own librccl.so.1) must share that instance, and single-GPU users of libfrieda_hip.so should not load a 570 MB
+// library.  FRIEDA_RCCL_PATH overrides the library (the tests substitute a recording stub).
+#include <dlfcn.h>
+#include <string.h>
+
+#include <atomic>
+#include <cstdio>
+#include <cstdlib>
+#include <thread>
+
+#include "host.h"
+
+using namespace frieda;
+
+namespace {
+
+// ---- the slice of the RCCL API used here (signatures as in <rccl/rccl.h>) ----
+typedef struct ncclComm* ncclComm_t;
+typedef int ncclResult_t;  // ncclSuccess == 0
+constexpr int kNcclUint8 = 1;  // ncclDataType_t::ncclUint8
+
+struct RcclApi {
+    void* handle = nullptr;
+    ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+
+    bool load(std::string& err) {
+        const char* override_path = getenv("FRIEDA_RCCL_PATH");
+        const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        if (override_path && *override_path) {
+            handle = dlopen(override_path, RTLD_NOW | RTLD_LOCAL);
+        } else {
+            for (const char* nm : names)  // an instance the process already carries wins
+                if (!handle) handle = dlopen(nm, RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD);
+            for (const char* nm : names)
+                if (!handle) handle = dlopen(nm, RTLD_NOW | RTLD_LOCAL);
+        }
+        if (!handle) {
+            const char* e = dlerror();
+            err = std::string("RCCL not loadable (librccl.so.1): ") + (e ? e : "?");
+            return false;
+        }
+        auto sym = [&](const char* nm) -> void* {
+            void* p = dlsym(handle, nm);
+            if (!p && err.empty()) err = std::string("RCCL lacks symbol ") + nm;
+            return p;
+        };
+        CommInitAll = reinterpret_cast<decltype(CommInitAll)>(sym("ncclCommInitAll"));
+        CommDestroy = reinterpret_cast<decltype(CommDestroy)>(sym("ncclCommDestroy"));
+        AllGather = reinterpret_cast<decltype(AllGather)>(sym("ncclAllGather"));
+        GroupStart = reinterpret_cast<decltype(GroupStart)>(sym("ncclGroupStart"));
+        GroupEnd = reinterpret_cast<decltype(GroupEnd)>(sym("ncclGroupEnd"));
+        GetErrorString = reinterpret_cast<decltype(GetErrorString)>(sym("ncclGetErrorString"));
+        return err.empty();
+    }
+};
+
+}  // namespace
+
+struct frieda_multi {
+    std::vector<int> devices;
+    std::vector<frieda_ctx*> ctx;        // 2 per device: [2 d], [2 d + 1]
+    std::vector<hipStream_t> gstream;    // per device: the stream the gather runs on
+    std::vector<uint8_t*> d_send, d_recv;
+    size_t slot_cap = 0;                 // roots per device the gather buffers hold
+    bool use_rccl = false;
+    RcclApi rccl;
+    std::vector<ncclComm_t> comms;
+    std::string err;
+    uint64_t gathers = 0;                // collectives issued so far (diagnostic)
+
+    int fail(int code, const std::string& what) {
+        err = what;
+        return code;
+    }
+    int ensure_gather_buffers(size_t slots);
+    int gather_roots(const std::vector<std::vector<Hash32>>& local, uint32_t count, uint8_t* out_roots);
+};
+
+int frieda_multi::ensure_gather_buffers(size_t slots) {
+    if (slots <= slot_cap) return FRIEDA_OK;
+    const size_t n = devices.size();
+    size_t cap = 64;
+    while (cap < slots) cap *= 2;
+    for (size_t d = 0; d < n; d++) {
+        if (hipSetDevice(devices[d]) != hipSuccess) return fail(FRIEDA_ERR_HIP, "hipSetDevice");
+        if (d_send[d]) (void)hipFree(d_send[d]);
+        if (d_recv[d]) (void)hipFree(d_recv[d]);
+        d_send[d] = d_recv[d] = nullptr;
+        if (hipMalloc((void**)&d_send[d], 32 * cap) != hipSuccess || hipMalloc((void**)&d_recv[d], 32 * cap * n) != hipSuccess) {
+            slot_cap = 0;
+            return fail(FRIEDA_ERR_NOMEM, "hipMalloc(root gather buffers)");
+        }
+    }
+    slot_cap = cap;
+    return FRIEDA_OK;
+}
+
+// local[d] = the roots device d produced, in its processing order (blob d, d + n, ...).  Every device ends up with every root;
+// out_roots (host, count * 32 bytes, blob order) is read back from device 0.
+int frieda_multi::gather_roots(const std::vector<std::vector<Hash32>>& local, uint32_t count, uint8_t* out_roots) {
+    const size_t n = devices.size();
+    const size_t per = (count + n - 1) / n;
+    if (!use_rccl) {  // one device: nothing to exchange
+        for (size_t s = 0; s < local[0].size(); s++) memcpy(out_roots + 32 * s, local[0][s].data(), 32);
+        return FRIEDA_OK;
+    }
+    int rc = ensure_gather_buffers(per);
+    if (rc) return rc;
+    std::vector<uint8_t> stage(32 * per);
+    for (size_t d = 0; d < n; d++) {
+        if (hipSetDevice(devices[d]) != hipSuccess) return fail(FRIEDA_ERR_HIP, "hipSetDevice");
+        memset(stage.data(), 0, stage.size());
+        for (size_t s = 0; s < local[d].size(); s++) memcpy(stage.data() + 32 * s, local[d][s].data(), 32);
+        if (hipMemcpy(d_send[d], stage.data(), stage.size(), hipMemcpyHostToDevice) != hipSuccess) return fail(FRIEDA_ERR_HIP, "hipMemcpy(roots H2D)");
+    }
+    ncclResult_t r = rccl.GroupStart();
+    for (size_t d = 0; d < n && r == 0; d++) {
+        if (hipSetDevice(devices[d]) != hipSuccess) return fail(FRIEDA_ERR_HIP, "hipSetDevice");
+        r = rccl.AllGather(d_send[d], d_recv[d], 32 * per, kNcclUint8, comms[d], gstream[d]);
+    }
+    const ncclResult_t r2 = rccl.GroupEnd();
+    if (r == 0) r = r2;
+    if (r != 0) return fail(FRIEDA_ERR_HIP, std::string("ncclAllGather(roots): ") + rccl.GetErrorString(r));
+    gathers++;
+    for (size_t d = 0; d < n; d++) {
+        if (hipSetDevice(devices[d]) != hipSuccess || hipStreamSynchronize(gstream[d]) != hipSuccess)
+            return fail(FRIEDA_ERR_HIP, "hipStreamSynchronize(root gather)");
+    }
+    std::vector<uint8_t> all(32 * per * n);
+    if (hipSetDevice(devices[0]) != hipSuccess || hipMemcpy(all.data(), d_recv[0], all.size(), hipMemcpyDeviceToHost) != hipSuccess)
+        return fail(FRIEDA_ERR_HIP, "hipMemcpy(roots D2H)");
+    for (uint32_t i = 0; i < count; i++) {
+        const uint8_t* got = all.data() + 32 * ((size_t)(i % n) * per + i / n);
+        if (memcmp(got, local[i % n][i / n].data(), 32) != 0) return fail(FRIEDA_ERR_INVARIANT, "internal: gathered root differs from the producer's copy");
+        memcpy(out_roots + 32 * (size_t)i, got, 32);
+    }
+    return FRIEDA_OK;
+}
+
+extern "C" {
+
+int frieda_multi_create(const int* devices, uint32_t n_devices, frieda_multi** out) {
+    if (!out) return FRIEDA_ERR_ARG;
+    *out = nullptr;
+    if (!devices || n_devices == 0 || n_devices > 64) return FRIEDA_ERR_ARG;
+    frieda_multi* m = new (std::nothrow) frieda_multi();
+    if (!m) return FRIEDA_ERR_NOMEM;
+    try {
+        m->devices.assign(devices, devices + n_devices);
+        m->ctx.assign(2 * (size_t)n_devices, nullptr);
+        m->gstream.assign(n_devices, nullptr);
+        m->d_send.assign(n_devices, nullptr);
+        m->d_recv.assign(n_devices, nullptr);
+        int rc = FRIEDA_OK;
+        for (uint32_t d = 0; d < n_devices && rc == FRIEDA_OK; d++) {
+            for (int k = 0; k < 2 && rc == FRIEDA_OK; k++) rc = frieda_ctx_create(devices[d], nullptr, &m->ctx[2 * d + k]);
+            if (rc == FRIEDA_OK && (hipSetDevice(devices[d]) != hipSuccess || hipStreamCreateWithFlags(&m->gstream[d], hipStreamNonBlocking) != hipSuccess))
+                rc = FRIEDA_ERR_HIP;
+        }
+        const char* force = getenv("FRIEDA_MULTI_FORCE_RCCL");
+        m->use_rccl = n_devices > 1 || (force && *force == '1');
+        if (rc == FRIEDA_OK && m->use_rccl) {
+            std::string e;
+            if (!m->rccl.load(e)) {
+                rc = FRIEDA_ERR_HIP;
+                fprintf(stderr, "frieda_multi_create: %s\n", e.c_str());
+            } else {
+                m->comms.assign(n_devices, nullptr);
+                const ncclResult_t r = m->rccl.CommInitAll(m->comms.data(), (int)n_devices, m->devices.data());
+                if (r != 0) {
+                    fprintf(stderr, "frieda_multi_create: ncclCommInitAll: %s\n", m->rccl.GetErrorString(r));
+                    m->comms.clear();
+                    rc = FRIEDA_ERR_HIP;
+                }
+            }
+        }
+        if (rc != FRIEDA_OK) {
+            frieda_multi_destroy(m);
+            return rc;
+        }
+    } catch (...) {
+        frieda_multi_destroy(m);
+        return FRIEDA_ERR_NOMEM;
+    }
+    *out = m;
+    return FRIEDA_OK;
+}
+
+int frieda_multi_destroy(frieda_multi* m) {
+    if (!m) return FRIEDA_ERR_ARG;
+    for (size_t d = 0; d < m->devices.size(); d++) {
+        (void)hipSetDevice(m->devices[d]);
+        if (d < m->comms.size() && m->comms[d]) (void)m->rccl.CommDestroy(m->comms[d]);
+        if (m->gstream[d]) {
+            (void)hipStreamSynchronize(m->gstream[d]);
+            (void)hipStreamDestroy(m->gstream[d]);
+        }
+        if (m->d_send[d]) (void)hipFree(m->d_send[d]);
+        if (m->d_recv[d]) (void)hipFree(m->d_recv[d]);
+    }
+    for (frieda_ctx* c : m->ctx)
+        if (c) frieda_ctx_destroy(c);
+    // the RCCL handle stays open: other users of the process (PyTorch) may share the instance
+    delete m;
+    return FRIEDA_OK;
+}
+
+uint32_t frieda_multi_device_count(const frieda_multi* m) { return m ? (uint32_t)m->devices.size() : 0; }
+const char* frieda_multi_last_error(const frieda_multi* m) { return m ? m->err.c_str() : "null handle"; }
+int frieda_multi_uses_rccl(const frieda_multi* m) { return m && m->use_rccl ? 1 : 0; }
+uint64_t frieda_multi_gather_count(const frieda_multi* m) { return m ? m->gathers : 0; }
+frieda_ctx* frieda_multi_ctx(frieda_multi* m, uint32_t device_slot) {
+    return m && device_slot < m->devices.size() ? m->ctx[2 * (size_t)device_slot] : nullptr;
+}
+
+int frieda_commit_many(frieda_multi* m, const uint8_t* const* blobs, const size_t* lens, uint32_t count, uint32_t log_blowup_factor,
+                       uint8_t* out_roots) {
+    if (!m) return FRIEDA_ERR_ARG;
+    if (count == 0) return FRIEDA_OK;
+    if (!blobs || !lens || !out_roots) return m->fail(FRIEDA_ERR_ARG, "null argument");
+    for (uint32_t i = 0; i < count; i++)
+        if (!blobs[i] && lens[i]) return m->fail(FRIEDA_ERR_ARG, "null blob");
+    try {
+        const size_t n = m->devices.size();
+        std::vector<std::vector<Hash32>> local(n);
+        std::vector<int> status(n, FRIEDA_OK);
+        std::atomic<bool> abort{false};
+        std::vector<std::thread> workers;
+        for (size_t d = 0; d < n; d++) {
+            local[d].resize((count + n - 1 - d) / n);
+            workers.emplace_back([&, d] {
+                frieda_ctx* c = m->ctx[2 * d];
+                try {
+                    size_t slot = 0;
+                    for (uint32_t i = (uint32_t)d; i < count && !abort.load(); i += (uint32_t)n, slot++) {
+                        const int rc = commit_host(&c->c, blobs[i], lens[i], log_blowup_factor, local[d][slot].data());
+                        if (rc != FRIEDA_OK) {
+                            status[d] = rc;
+                            abort.store(true);
+                            return;
+                        }
+                    }
+                } catch (...) {  // nothing may unwind out of a worker thread
+                    c->c.err = "host allocation failed";
+                    status[d] = FRIEDA_ERR_NOMEM;
+                    abort.store(true);
+                }
+            });
+        }
+        for (auto& w : workers) w.join();
+        for (size_t d = 0; d < n; d++)
+            if (status[d] != FRIEDA_OK) return m->fail(status[d], "device " + std::to_string(m->devices[d]) + ": " + m->ctx[2 * d]->c.err);
+        return m->gather_roots(local, count, out_roots);
+    } catch (const std::bad_alloc&) {
+        return m->fail(FRIEDA_ERR_NOMEM, "host allocation failed");
+    } catch (const std::exception& e) {
+        return m->fail(FRIEDA_ERR_INVARIANT, e.what());
+    }
+}
+
+int frieda_prove_many(frieda_multi* m, const uint8_t* const* blobs, const size_t* lens, uint32_t count, const uint64_t* seeds,
+                      frieda_pcs_config cfg, uint8_t* out_commitments, frieda_proof** out_proofs) {
+    if (!m) return FRIEDA_ERR_ARG;
+    if (count == 0) return FRIEDA_OK;
+    if (!blobs || !lens || !out_commitments || !out_proofs) return m->fail(FRIEDA_ERR_ARG, "null argument");
+    for (uint32_t i = 0; i < count; i++) {
+        out_proofs[i] = nullptr;
+        if (!blobs[i] && lens[i]) return m->fail(FRIEDA_ERR_ARG, "null blob");
+    }
+    try {
+        const size_t n = m->devices.size();
+        std::vector<std::vector<Hash32>> local(n);
+        std::vector<int> status(n, FRIEDA_OK);
+        std::vector<std::string> what(n);
+        std::atomic<bool> abort{false};
+        std::vector<std::thread> workers;
+        for (size_t d = 0; d < n; d++) {
+            local[d].resize((count + n - 1 - d) / n);
+            workers.emplace_back([&, d] {
+              try {
+                // two proofs in flight on this device: begin(k + 1) is enqueued before finish(k) waits
+                frieda_ctx* cx[2] = {m->ctx[2 * d], m->ctx[2 * d + 1]};
+                const uint32_t mine = (uint32_t)local[d].size();
+                auto blob_of = [&](uint32_t slot) { return (uint32_t)d + slot * (uint32_t)n; };
+                auto begin = [&](uint32_t slot) {
+                    const uint32_t i = blob_of(slot);
+                    return prove_begin(&cx[slot & 1]->c, blobs[i], lens[i], false, seeds ? &seeds[i] : nullptr, cfg);
+                };
+                auto bail = [&](int rc, frieda_ctx* c) {
+                    status[d] = rc;
+                    what[d] = c->c.err;
+                    abort.store(true);
+                };
+                if (mine == 0) return;
+                int rc = begin(0);
+                if (rc != FRIEDA_OK) return bail(rc, cx[0]);
+                for (uint32_t slot = 0; slot < mine; slot++) {
+                    bool next_begun = false;
+                    if (slot + 1 < mine && !abort.load()) {
+                        rc = begin(slot + 1);
+                        if (rc != FRIEDA_OK) bail(rc, cx[(slot + 1) & 1]);
+                        next_begun = rc == FRIEDA_OK;
+                    }
+                    frieda_ctx* c = cx[slot & 1];
+                    frieda_proof* p = c->pool->get();
+                    p->home = c->pool;
+                    const int rf = prove_finish(&c->c, local[d][slot].data(), p->p);
+                    if (rf != FRIEDA_OK) {
+                        c->pool->put(p);
+                        if (status[d] == FRIEDA_OK) bail(rf, c);
+                    } else {
+                        out_proofs[blob_of(slot)] = p;
+                    }
+                    if (status[d] != FRIEDA_OK || abort.load()) {
+                        if (next_begun) {  // drain the proof already enqueued so that the context is reusable
+                            frieda_ctx* c2 = cx[(slot + 1) & 1];
+                            ProofData scratch;
+                            uint8_t r[32];
+                            (void)prove_finish(&c2->c, r, scratch);
+                        }
+                        return;
+                    }
+                }
+              } catch (...) {  // nothing may unwind out of a worker thread
+                  status[d] = FRIEDA_ERR_NOMEM;
+                  what[d] = "host allocation failed";
+                  abort.store(true);
+              }
+            });
+        }
+        for (auto& w : workers) w.join();
+        int rc = FRIEDA_OK;
+        for (size_t d = 0; d < n && rc == FRIEDA_OK; d++)
+            if (status[d] != FRIEDA_OK) rc = m->fail(status[d], "device " + std::to_string(m->devices[d]) + ": " + what[d]);
+        if (rc == FRIEDA_OK && abort.load()) rc = m->fail(FRIEDA_ERR_INVARIANT, "internal: aborted without a status");
+        if (rc == FRIEDA_OK) rc = m->gather_roots(local, count, out_commitments);
+        if (rc != FRIEDA_OK)
+            for (uint32_t i = 0; i < count; i++) {
+                if (out_proofs[i]) frieda_proof_free(out_proofs[i]);
+                out_proofs[i] = nullptr;
+            }
+        return rc;
+    } catch (const std::bad_alloc&) {
+        return m->fail(FRIEDA_ERR_NOMEM, "host allocation failed");
+    } catch (const std::exception& e) {
+        return m->fail(FRIEDA_ERR_INVARIANT, e.what());
+    }
+}
+
+}  // extern "C"

@@ -309,8 +309,10 @@ struct ProveJob {
     struct Blob {
         Channel ch{};
         std::vector<Hash32> roots;
+        std::vector<std::array<uint32_t, 4>> alphas;  // per layer, for frieda_ctx_last_transcript
         std::vector<QM31> lastv;
         uint64_t nonce = ~0ull;
+        uint32_t digest_before_grind[8] = {0};
     };
     std::vector<Blob> blobs;
     uint64_t grind_base = 0, grind_chunk = 0;
@@ -569,6 +571,8 @@ int prove_begin_batch(Ctx* ctx, const uint8_t* data, size_t data_stride, size_t 
 
         // ---- FriProver::commit_inner_layers ----
         QM31 alpha = ch.draw_felt(ctx->test_draw_bound);
+        J.blobs[0].alphas.assign(1 + n_inner, std::array<uint32_t, 4>{});
+        J.blobs[0].alphas[0] = {alpha.a, alpha.b, alpha.c, alpha.d};
         {
             // LineEvaluation::new_zero then fold_circle_into_line
             uint32_t* dst = (n_inner > 0) ? cols(inner[0], 0) : reinterpret_cast<uint32_t*>(A + o_lastv);
@@ -583,6 +587,7 @@ int prove_begin_batch(Ctx* ctx, const uint8_t* data, size_t data_stride, size_t 
             hash_to_words(roots[kx + 1].data(), rw);
             ch.mix_root(rw);
             alpha = ch.draw_felt(ctx->test_draw_bound);
+            J.blobs[0].alphas[kx + 1] = {alpha.a, alpha.b, alpha.c, alpha.d};
             uint32_t* dst = (kx + 1 < n_inner) ? cols(inner[kx + 1], 0) : reinterpret_cast<uint32_t*>(A + o_lastv);
             k::fold_line(LN, cols(lay, 0), (size_t)1 << lay.log, lay.log, n, tw.d_itw, tw.ds, k::Alpha{{alpha.a, alpha.b, alpha.c, alpha.d}}, dst,
                          (size_t)1 << (lay.log - 1));
@@ -605,6 +610,7 @@ int prove_begin_batch(Ctx* ctx, const uint8_t* data, size_t data_stride, size_t 
         lastv.resize(n_poly);
         bit_reverse_vec(lastv, n_poly, last);  // LinePoly::from_ordered_coefficients
         channel_mix_felts(ch, lastv);
+        memcpy(J.blobs[0].digest_before_grind, ch.digest, 32);
 
         // ---- grind (src/proof.rs:58-59) ----
         unsigned long long* d_nonce = reinterpret_cast<unsigned long long*>(A + o_nonce);
@@ -681,15 +687,22 @@ int prove_finish_batch(Ctx* ctx, uint8_t* out_commitments, std::vector<ProofData
             if (ht->n_roots != 1 + n_inner || ht->n_last_poly != n_poly) return ctx->fail(FRIEDA_ERR_INVARIANT, "internal: transcript out of step");
             bl.nonce = ht->nonce;
             bl.ch = ht->ch;
-            for (uint32_t li = 0; li <= n_inner; li++)
+            memcpy(bl.digest_before_grind, ht->ch.digest, 32);  // downloaded behind the grind, ahead of the decommit kernel
+            bl.alphas.resize(1 + n_inner);
+            for (uint32_t li = 0; li <= n_inner; li++) {
                 for (int w = 0; w < 8; w++)
                     for (int bb = 0; bb < 4; bb++) bl.roots[li][4 * w + bb] = (uint8_t)(ht->roots[li][w] >> (8 * bb));
+                bl.alphas[li] = {ht->alphas[li][0], ht->alphas[li][1], ht->alphas[li][2], ht->alphas[li][3]};
+            }
             bl.lastv.resize(n_poly);
             for (size_t i = 0; i < n_poly; i++)
                 bl.lastv[i] = {ht->last_poly[4 * i], ht->last_poly[4 * i + 1], ht->last_poly[4 * i + 2], ht->last_poly[4 * i + 3]};
         }
     }
     ctx->phase_ms[1] = ms_since(J.t_start);  // commit phase + grind complete on the device (first synchronise)
+    ctx->last_transcript.roots = J.blobs[0].roots;
+    ctx->last_transcript.alphas = J.blobs[0].alphas;
+    memcpy(ctx->last_transcript.digest_before_grind, J.blobs[0].digest_before_grind, 32);
 
     struct LayerCounts {
         size_t n_witness, n_hashes;

@@ -154,6 +154,48 @@ class Context {
     frieda_ctx* h_ = nullptr;
 };
 
+// A batch of independent blobs across the GPUs of one node (frieda_multi): blob i -> devices[i mod n]; roots gathered with RCCL.
+class MultiContext {
+  public:
+    explicit MultiContext(const std::vector<int>& devices) { check(frieda_multi_create(devices.data(), (uint32_t)devices.size(), &h_)); }
+    MultiContext(const MultiContext&) = delete;
+    MultiContext& operator=(const MultiContext&) = delete;
+    ~MultiContext() { frieda_multi_destroy(h_); }
+
+    bool uses_rccl() const { return frieda_multi_uses_rccl(h_) != 0; }
+    uint64_t gather_count() const { return frieda_multi_gather_count(h_); }
+    std::vector<Commitment> commit_many(const std::vector<std::vector<uint8_t>>& blobs, uint32_t log_blowup_factor) {
+        std::vector<const uint8_t*> ptrs;
+        std::vector<size_t> lens;
+        for (const auto& b : blobs) ptrs.push_back(b.data()), lens.push_back(b.size());
+        std::vector<Commitment> roots(blobs.size());
+        if (!blobs.empty()) mcheck(frieda_commit_many(h_, ptrs.data(), lens.data(), (uint32_t)blobs.size(), log_blowup_factor, roots.data()->data()));
+        return roots;
+    }
+    std::vector<std::pair<Commitment, Proof>> prove_many(const std::vector<std::vector<uint8_t>>& blobs, const uint64_t* seeds_or_null,
+                                                         const PcsConfig& cfg) {
+        std::vector<const uint8_t*> ptrs;
+        std::vector<size_t> lens;
+        for (const auto& b : blobs) ptrs.push_back(b.data()), lens.push_back(b.size());
+        std::vector<std::pair<Commitment, Proof>> out;
+        if (blobs.empty()) return out;
+        std::vector<Commitment> roots(blobs.size());
+        std::vector<frieda_proof*> ps(blobs.size(), nullptr);
+        mcheck(frieda_prove_many(h_, ptrs.data(), lens.data(), (uint32_t)blobs.size(), seeds_or_null, cfg.c(), roots.data()->data(), ps.data()));
+        for (size_t i = 0; i < blobs.size(); i++) out.emplace_back(roots[i], Proof(ps[i]));
+        return out;
+    }
+
+  private:
+    void mcheck(int status) {
+        if (status == FRIEDA_OK) return;
+        const std::string detail = frieda_multi_last_error(h_);
+        if (status == FRIEDA_ERR_INVARIANT) throw Panic(status, detail);
+        throw Error(status, detail);
+    }
+    frieda_multi* h_ = nullptr;
+};
+
 inline Context& default_context() {
     thread_local Context ctx(0);
     return ctx;

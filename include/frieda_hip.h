@@ -89,6 +89,14 @@ int frieda_ctx_set_kernel_timing(frieda_ctx* ctx, int enabled);
  * planned the openings), [4] proof assembled, [5] host set-up before the first launch */
 int frieda_ctx_last_prove_phases(const frieda_ctx* ctx, double out_ms[8]);
 size_t frieda_ctx_kernel_timing_report(frieda_ctx* ctx, char* buf, size_t cap, int reset);
+/* diagnostic: the Fiat-Shamir transcript of the last finished generate_proof on this ctx (blob 0 of a batch) — what
+ * FriProver::commit derives between src/proof.rs:52 and :58 and the Proof does not carry: per FRI layer (first, then inner)
+ * the folding alpha drawn after its root (4 u32 each; the roots themselves are the layer commitments of the Proof), and the
+ * channel digest the proof of work was keyed by (after mix_felts(last_layer_poly)).  *n_layers receives the layer count;
+ * at most cap_layers alphas are written.  Exists so that a cargo-side dump of the reference's transcript can be diffed
+ * against this path value by value (tools/dump_trace.py, tests/golden/trace_selfcheck.json). */
+int frieda_ctx_last_transcript(const frieda_ctx* ctx, uint32_t* n_layers, uint32_t* alphas, size_t cap_layers,
+                               uint8_t digest_before_grind[32]);
 
 /* ---- Level A: frieda's public API ------------------------------------------------------------- */
 /* api::commit(data, log_blowup_factor) -> [u8; 32]   (src/lib.rs:31, src/commit.rs:11-22) */
@@ -148,6 +156,33 @@ int frieda_generate_proof(frieda_ctx* ctx, const uint8_t* data, size_t len, cons
  * reference panics (src/proof.rs:166-173). */
 int frieda_verify(const frieda_proof* proof, const uint64_t* seed, int* ok);
 
+/* ---- multi-GPU: a batch of independent blobs across the GPUs of one node ---------------------------------------------
+ * What a caller looping api::commit / commit_and_generate_proof over blobs gets on an 8 x MI355X node
+ * (src/lib.rs:31-38; benches/commit.rs:11-15, benches/proof.rs:30-44).  The path shards at blob granularity: blob i runs
+ * on devices[i mod n], one host thread and two contexts per device (two proofs in flight), no data-path collective.  The
+ * only exchange is the gather of the 32-byte commitment roots: one ncclAllGather per device on a single-process
+ * communicator (ncclCommInitAll; RCCL over xGMI), after which every device holds every root; the host reads device 0's
+ * copy.  n == 1 needs no exchange and does not touch RCCL.  RCCL is bound at frieda_multi_create by dlopen("librccl.so.1")
+ * (an instance already in the process — PyTorch's — is shared); creation fails with FRIEDA_ERR_HIP if it cannot be loaded.
+ * blobs / lens: host arrays of `count` pointers / byte lengths (lengths may differ); out_roots / out_commitments:
+ * count * 32 bytes in blob order; out_proofs: count handles, each released with frieda_proof_free; seeds == NULL is None
+ * for every blob, else seeds[i] is Some.  A handle is not thread-safe; results are exactly those of `count` separate
+ * single-GPU calls. */
+typedef struct frieda_multi frieda_multi;
+int frieda_multi_create(const int* devices, uint32_t n_devices, frieda_multi** out);
+int frieda_multi_destroy(frieda_multi* m);
+uint32_t frieda_multi_device_count(const frieda_multi* m);
+const char* frieda_multi_last_error(const frieda_multi* m);
+/* 1 when root gathers go through RCCL (n > 1, or FRIEDA_MULTI_FORCE_RCCL=1); collectives issued so far */
+int frieda_multi_uses_rccl(const frieda_multi* m);
+uint64_t frieda_multi_gather_count(const frieda_multi* m);
+/* the first context of device slot d (e.g. to set a policy on it); owned by the handle */
+frieda_ctx* frieda_multi_ctx(frieda_multi* m, uint32_t device_slot);
+int frieda_commit_many(frieda_multi* m, const uint8_t* const* blobs, const size_t* lens, uint32_t count, uint32_t log_blowup_factor,
+                       uint8_t* out_roots);
+int frieda_prove_many(frieda_multi* m, const uint8_t* const* blobs, const size_t* lens, uint32_t count, const uint64_t* seeds,
+                      frieda_pcs_config cfg, uint8_t* out_commitments, frieda_proof** out_proofs);
+
 /* ---- struct Proof (src/proof.rs:19-26) accessors; fields are `pub` upstream, hence the setters --- */
 void frieda_proof_free(frieda_proof* p);
 int frieda_proof_clone(const frieda_proof* p, frieda_proof** out);
@@ -177,6 +212,18 @@ int frieda_dev_alloc(frieda_ctx* ctx, size_t bytes, void** d_out);
 int frieda_dev_free(frieda_ctx* ctx, void* d);
 int frieda_dev_upload(frieda_ctx* ctx, void* d_dst, const void* h_src, size_t bytes);
 int frieda_dev_download(frieda_ctx* ctx, void* h_dst, const void* d_src, size_t bytes);
+
+/* Column::at(index) (stwo core/backend Column<T>; CpuBackend is `Vec<T>` indexing — the accessor frieda's evaluation gather
+ * uses, src/proof.rs:62-66): one element of a device column to the host.  Synchronises the ctx stream (it is a debugging /
+ * trait-completeness accessor, not a hot path — the prover gathers its openings on the device).
+ * frieda_dev_at: M31 column.  frieda_dev_at_secure: QM31 from a SecureColumn d_cols[4][stride] (SoA), out = 4 coordinates. */
+int frieda_dev_at(frieda_ctx* ctx, const uint32_t* d_col, size_t index, uint32_t* out);
+int frieda_dev_at_secure(frieda_ctx* ctx, const uint32_t* d_cols, size_t stride, size_t index, uint32_t out[4]);
+/* ColumnOps::bit_reverse_column (stwo core/backend/mod.rs; the trait surface `CirclePoly::<CpuBackend>::new` and
+ * `SecureCirclePoly` are instantiated over at src/utils.rs:21,28 and src/proof.rs:47-52): in place, v[i] <-> v[brev(i)] over
+ * log_size bits, for each of ncols columns of 2^log_size words laid out `stride` words apart (ncols = 1: a BaseField
+ * column; ncols = 4, stride = 2^log_size: a SecureColumn).  Asynchronous on the ctx stream. */
+int frieda_bit_reverse_column(frieda_ctx* ctx, uint32_t* d_cols, size_t stride, uint32_t ncols, uint32_t log_size);
 
 /* codec, src/utils.rs:10-33: d_bytes[len] -> d_coef[n_out] felts (30-bit LSB-first chunks), zero padded
  * to n_out words.  frieda_codec_shape gives F (felts), F' (padded) and L (per-column log size). */

@@ -191,6 +191,9 @@ void fo_circle_domain_at(uint32_t n, uint32_t i, uint32_t* x, uint32_t* y) {
     *y = p.y;
 }
 
+/* stwo core/utils.rs bit_reverse (what CpuBackend's ColumnOps::bit_reverse_column calls): v[i] <-> v[brev(i)] for i < brev(i) */
+static void bit_reverse_u32(uint32_t* v, uint32_t log_size);
+void fo_bit_reverse_column(uint32_t* v, uint32_t log_size) { bit_reverse_u32(v, log_size); }
 static void bit_reverse_u32(uint32_t* v, uint32_t log_size) {
     uint32_t n = 1u << log_size;
     for (uint32_t i = 0; i < n; i++) {

@@ -54,6 +54,8 @@ void fo_point_from_index(uint32_t index, uint32_t* x, uint32_t* y);
 /* CircleDomain::new(Coset::half_odds(n-1)).at(i) */
 void fo_circle_domain_at(uint32_t n, uint32_t i, uint32_t* x, uint32_t* y);
 uint32_t fo_bit_reverse_index(uint32_t i, uint32_t log_size);
+/* ColumnOps::bit_reverse_column of CpuBackend (stwo core/utils.rs bit_reverse), in place on 2^log_size words */
+void fo_bit_reverse_column(uint32_t* v, uint32_t log_size);
 
 /* ---- twiddles (stwo backend/cpu/circle.rs::precompute_twiddles on Coset::half_odds(n-1)) ----
  * tw and itw each hold 2^(n-1) words: levels of size N/4, N/8, ..., 1, then the pad value 1. */

@@ -166,6 +166,13 @@ def polynomial_from_bytes(data):
     return coef.reshape(4, -1), L.value
 
 
+def bit_reverse_column(col):
+    """CpuBackend's ColumnOps::bit_reverse_column on a copy of `col` (1-D uint32, power-of-two length)."""
+    v = np.ascontiguousarray(col, dtype=np.uint32).copy()
+    lib().fo_bit_reverse_column(C.c_void_p(v.ctypes.data), C.c_uint32(v.size.bit_length() - 1))
+    return v
+
+
 # ---- NTT -----------------------------------------------------------------------------------------
 def precompute_twiddles(n):
     half = max(1, 1 << (n - 1))

@@ -3,6 +3,7 @@
 // tests/test_gpu_parity.py::test_cpp_api_harness.  argv[1] = path of the `blob` fixture.  Exit code 0 = all passed.
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <fstream>
 #include <iterator>
@@ -24,11 +25,63 @@ static int failures = 0;
 
 static const PcsConfig PCS_CONFIG{20, FriConfig{4, 1, 20}};  // src/proof.rs:109-116
 
+// `test_api.bin <blob> multi <n_slots>`: the multi-GPU entry points over n_slots device slots, all of them device 0 (the test
+// box has one GPU).  n_slots == 1 takes the no-exchange path unless FRIEDA_MULTI_FORCE_RCCL=1 (then the real one-rank RCCL
+// collective runs); n_slots > 1 needs FRIEDA_RCCL_PATH = tests/cpp/librccl_stub.so (real RCCL refuses a device listed twice).
+static int multi_mode(const std::vector<uint8_t>& blob, int n_slots) {
+    std::vector<std::vector<uint8_t>> blobs;
+    blobs.push_back(blob);  // the reference's fixture: its root is the golden root
+    for (int i = 0; i < 6; i++) {  // ragged lengths, an empty blob among them
+        std::vector<uint8_t> d(i == 3 ? 0 : 700 + 1311 * i);
+        for (size_t j = 0; j < d.size(); j++) d[j] = (uint8_t)(j * 29 + i * 5 + (j >> 5));
+        blobs.push_back(d);
+    }
+    const uint8_t golden[32] = {209, 162, 213, 6,  157, 197, 135, 229, 93,  194, 156, 198, 37, 90, 249, 55,
+                                255, 127, 237, 14, 228, 27,  223, 90,  249, 135, 23,  249, 215, 79, 96,  232};
+    MultiContext mc(std::vector<int>(n_slots, 0));
+    const bool want_rccl = n_slots > 1 || (getenv("FRIEDA_MULTI_FORCE_RCCL") && getenv("FRIEDA_MULTI_FORCE_RCCL")[0] == '1');
+    CHECK(mc.uses_rccl() == want_rccl);
+    auto roots = mc.commit_many(blobs, 4);
+    CHECK(roots.size() == blobs.size());
+    CHECK(std::memcmp(roots[0].data(), golden, 32) == 0);
+    for (size_t i = 0; i < blobs.size(); i++) CHECK(roots[i] == api::commit(blobs[i], 4));
+    std::vector<uint64_t> seeds;
+    std::vector<std::vector<uint8_t>> provable;  // the empty blob is too small for the FRI configuration
+    for (size_t i = 0; i < blobs.size(); i++)
+        if (!blobs[i].empty()) provable.push_back(blobs[i]), seeds.push_back(1000 + i);
+    auto proofs = mc.prove_many(provable, seeds.data(), PCS_CONFIG);
+    CHECK(proofs.size() == provable.size());
+    for (size_t i = 0; i < proofs.size(); i++) {
+        auto single = proof::commit_and_generate_proof(provable[i], seeds[i], PCS_CONFIG);
+        CHECK(proofs[i].first == single.first);
+        CHECK(proofs[i].second.serialize() == single.second.serialize());
+        CHECK(api::verify(proofs[i].second, seeds[i]));
+    }
+    auto unseeded = mc.prove_many(provable, nullptr, PCS_CONFIG);
+    for (size_t i = 0; i < unseeded.size(); i++) CHECK(api::verify(unseeded[i].second, std::nullopt) && unseeded[i].first == proofs[i].first);
+    CHECK(mc.gather_count() == (want_rccl ? 3u : 0u));
+    // a batch with a blob the reference panics on: the whole call reports it and hands out no proof
+    bool panicked = false;
+    try {
+        mc.prove_many(blobs, nullptr, PCS_CONFIG);
+    } catch (const Panic&) {
+        panicked = true;
+    }
+    CHECK(panicked);
+    CHECK(mc.commit_many({}, 4).empty());
+    // and the handle is usable afterwards
+    CHECK(mc.commit_many(blobs, 4) == roots);
+    std::printf("multi n_slots=%d rccl=%d gathers=%llu: %s (%d failures)\n", n_slots, (int)mc.uses_rccl(), (unsigned long long)mc.gather_count(),
+                failures ? "FAILED" : "ok", failures);
+    return failures ? 1 : 0;
+}
+
 int main(int argc, char** argv) {
     if (argc < 2) return 2;
     std::ifstream f(argv[1], std::ios::binary);
     std::vector<uint8_t> data((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
     CHECK(data.size() == 262146);
+    if (argc >= 4 && std::strcmp(argv[2], "multi") == 0) return multi_mode(data, std::atoi(argv[3]));
 
     // test_commit (src/commit.rs:28-38): the golden root
     const uint8_t golden[32] = {209, 162, 213, 6,  157, 197, 135, 229, 93,  194, 156, 198, 37, 90, 249, 55,

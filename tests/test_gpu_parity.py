@@ -55,7 +55,7 @@ def test_unpack30_unaligned_pointer(gpu_ctx, oracle):
     assert np.array_equal(d_out.to_array(np.uint32, (coef.size,)), coef.ravel())
 
 
-@pytest.mark.parametrize("n", [1, 2, 3, 4, 5, 8, 11, 14, 17])
+@pytest.mark.parametrize("n", [1, 2, 3, 4, 5, 8, 11, 14, 17, 20, 22])
 def test_twiddles(gpu_ctx, oracle, n):
     tw, itw = oracle.precompute_twiddles(n)
     p_tw, p_itw = C.c_void_p(), C.c_void_p()
@@ -119,7 +119,7 @@ def test_merkle_commit_layer_general_shapes(gpu_ctx, oracle, ncols, with_prev):
     assert np.array_equal(d_out.to_array(np.uint8, (1 << log_size, 32)), exp)
 
 
-@pytest.mark.parametrize("n", [1, 2, 3, 6, 12, 16])
+@pytest.mark.parametrize("n", [1, 2, 3, 6, 12, 16, 20, 22])
 def test_fold_circle_into_line(gpu_ctx, oracle, n):
     rng = np.random.default_rng(400 + n)
     src = rand_m31(rng, (4, 1 << n))
@@ -131,7 +131,7 @@ def test_fold_circle_into_line(gpu_ctx, oracle, n):
         assert np.array_equal(d_d.to_array(np.uint32, (4, 1 << (n - 1))), exp)
 
 
-@pytest.mark.parametrize("n,m", [(2, 1), (3, 2), (6, 5), (6, 1), (12, 11), (12, 7), (16, 15), (16, 9)])
+@pytest.mark.parametrize("n,m", [(2, 1), (3, 2), (6, 5), (6, 1), (12, 11), (12, 7), (16, 15), (16, 9), (20, 19), (22, 21), (22, 13)])
 def test_fold_line(gpu_ctx, oracle, n, m):
     rng = np.random.default_rng(500 + 31 * n + m)
     src = rand_m31(rng, (4, 1 << m))
@@ -140,6 +140,54 @@ def test_fold_line(gpu_ctx, oracle, n, m):
     d_s, d_d = DevBuf.from_array(gpu_ctx, src), DevBuf(gpu_ctx, 16 << (m - 1))
     _check(gpu_ctx, gpu_ctx._L.frieda_fold_line(gpu_ctx._h, d_s.ptr, m, n, alpha.ctypes.data, d_d.ptr))
     assert np.array_equal(d_d.to_array(np.uint32, (4, 1 << (m - 1))), exp)
+
+
+@pytest.mark.parametrize("log_size", [0, 1, 2, 5, 11, 12, 13, 16, 20, 22])
+@pytest.mark.parametrize("ncols", [1, 4])
+def test_bit_reverse_column(gpu_ctx, oracle, log_size, ncols):
+    """ColumnOps::bit_reverse_column for a BaseField column (ncols 1) and a SecureColumn (4 SoA coordinates), in place."""
+    rng = np.random.default_rng(300 + log_size)
+    cols = rand_m31(rng, (ncols, 1 << log_size))
+    d = DevBuf.from_array(gpu_ctx, cols)
+    _check(gpu_ctx, gpu_ctx._L.frieda_bit_reverse_column(gpu_ctx._h, d.ptr, 1 << log_size, ncols, log_size))
+    got = d.to_array(np.uint32, (ncols, 1 << log_size))
+    for c in range(ncols):
+        assert np.array_equal(got[c], oracle.bit_reverse_column(cols[c]))
+    # an involution: twice is the identity
+    _check(gpu_ctx, gpu_ctx._L.frieda_bit_reverse_column(gpu_ctx._h, d.ptr, 1 << log_size, ncols, log_size))
+    assert np.array_equal(d.to_array(np.uint32, (ncols, 1 << log_size)), cols)
+
+
+def test_bit_reverse_column_strided_and_errors(gpu_ctx, oracle):
+    rng = np.random.default_rng(7)
+    buf = rand_m31(rng, (3, 5000))  # columns of 2^12 words inside rows of 5000
+    d = DevBuf.from_array(gpu_ctx, buf)
+    _check(gpu_ctx, gpu_ctx._L.frieda_bit_reverse_column(gpu_ctx._h, d.ptr, 5000, 3, 12))
+    got = d.to_array(np.uint32, (3, 5000))
+    for c in range(3):
+        assert np.array_equal(got[c, :4096], oracle.bit_reverse_column(buf[c, :4096]))
+        assert np.array_equal(got[c, 4096:], buf[c, 4096:])
+    assert gpu_ctx._L.frieda_bit_reverse_column(gpu_ctx._h, d.ptr, 100, 3, 12) == 1  # stride smaller than the column
+    assert gpu_ctx._L.frieda_bit_reverse_column(gpu_ctx._h, None, 100, 1, 3) == 1
+    assert gpu_ctx._L.frieda_bit_reverse_column(gpu_ctx._h, d.ptr, 100, 1, 29) == 1
+
+
+def test_dev_at(gpu_ctx):
+    """Column::at on a BaseField column and on a SecureColumn."""
+    rng = np.random.default_rng(8)
+    cols = rand_m31(rng, (4, 1 << 10))
+    d = DevBuf.from_array(gpu_ctx, cols)
+    one = C.c_uint32()
+    four = (C.c_uint32 * 4)()
+    for idx in (0, 1, 511, 1023):
+        _check(gpu_ctx, gpu_ctx._L.frieda_dev_at(gpu_ctx._h, d.ptr, idx, C.byref(one)))
+        assert one.value == int(cols[0, idx])
+        _check(gpu_ctx, gpu_ctx._L.frieda_dev_at(gpu_ctx._h, d.ptr, 3 * 1024 + idx, C.byref(one)))
+        assert one.value == int(cols[3, idx])
+        _check(gpu_ctx, gpu_ctx._L.frieda_dev_at_secure(gpu_ctx._h, d.ptr, 1024, idx, four))
+        assert list(four) == [int(cols[c, idx]) for c in range(4)]
+    assert gpu_ctx._L.frieda_dev_at_secure(gpu_ctx._h, d.ptr, 1024, 1024, four) == 1  # index beyond the column
+    assert gpu_ctx._L.frieda_dev_at(gpu_ctx._h, None, 0, C.byref(one)) == 1
 
 
 @pytest.mark.parametrize("pow_bits,seed", [(0, 1), (5, 2), (12, 3), (20, 4), (22, 5)])
@@ -327,6 +375,40 @@ def test_reference_proof_tests_on_gpu(gpu_ctx, blob):
     assert not frieda_amd.verify(p1, 2) and not frieda_amd.verify(p2, 1)
 
 
+@pytest.mark.parametrize("host_channel", [False, True], ids=["devchannel", "hostchannel"])
+def test_device_transcript_reproduces_the_selfcheck_trace(gpu_ctx, blob, host_channel):
+    """tests/golden/trace_selfcheck.json (SELF-GENERATED from the oracle by tools/dump_trace.py, not reference-held): the HIP
+    path's transcript — roots, alphas, digest before the grind, nonce, query count, witness lengths, last-layer polynomial —
+    value by value, under both transcript policies."""
+    import json
+
+    import frieda_amd
+    from conftest import GOLDEN
+
+    doc = json.load(open(os.path.join(GOLDEN, "trace_selfcheck.json")))
+    gpu_ctx.set_host_channel(host_channel)
+    try:
+        for c in doc["cases"]:
+            data = resolve_input(c["input"] if c["input"] == "blob" else c["input"], blob)
+            k = c["config"]
+            cfg = _cfg(frieda_amd, k["pow_bits"], k["log_blowup_factor"], k["log_last_layer_degree_bound"], k["n_queries"])
+            root, proof = gpu_ctx.commit_and_generate_proof(data, c["seed"], cfg)
+            tr = gpu_ctx.last_transcript()
+            assert root.hex() == c["commitment"]
+            n_layers = 1 + proof.n_inner_layers
+            assert [proof.layer(i)["commitment"].hex() for i in range(n_layers)] == c["roots"]
+            assert tr["alphas"] == c["alphas"]
+            assert tr["digest_before_grind"].hex() == c["digest_before_grind"]
+            assert proof.proof_of_work == c["nonce"]
+            assert proof.evaluations.shape[0] == c["n_evaluations"] == len(c["queries"])
+            assert [int(x) for x in proof.last_layer_poly.ravel()] == c["last_layer_poly"]
+            got = [{"fri_witness": len(proof.layer(i)["fri_witness"]), "hash_witness": len(proof.layer(i)["hash_witness"]),
+                    "column_witness": len(proof.layer(i)["column_witness"])} for i in range(n_layers)]
+            assert got == c["witness_lengths"]
+    finally:
+        gpu_ctx.set_host_channel(False)
+
+
 def test_pipelined_proofs_match_sequential(gpu_ctx, oracle):
     """Several proofs in flight on separate contexts (frieda_prove_begin / _finish) give byte-identical proofs."""
     import torch
@@ -371,6 +453,52 @@ def test_cpp_api_harness(gpu_ctx):
     assert os.path.exists(exe), "run __graft_entry__.build() first"
     r = subprocess.run([exe, os.path.join(GOLDEN, "blob")], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
+
+
+@pytest.mark.parametrize("n_slots,mode", [(1, "plain"), (1, "rccl"), (2, "stub"), (3, "stub")])
+def test_cpp_multi_gpu_entry_points(gpu_ctx, n_slots, mode):
+    """frieda_multi_create / frieda_commit_many / frieda_prove_many from C++ (tests/cpp/test_api.cpp multi_mode): the no-exchange
+    path, the real one-rank RCCL collective (FRIEDA_MULTI_FORCE_RCCL=1), and the N > 1 gather layout against the RCCL test
+    double (this box has one GPU and real RCCL refuses a device listed twice)."""
+    import subprocess
+
+    from conftest import GOLDEN, ROOT
+
+    exe = os.path.join(ROOT, "tests", "cpp", "test_api.bin")
+    env = dict(os.environ)
+    env.pop("FRIEDA_RCCL_PATH", None)
+    env.pop("FRIEDA_MULTI_FORCE_RCCL", None)
+    if mode == "rccl":
+        env["FRIEDA_MULTI_FORCE_RCCL"] = "1"
+    if mode == "stub":
+        env["FRIEDA_RCCL_PATH"] = os.path.join(ROOT, "tests", "cpp", "librccl_stub.so")
+    r = subprocess.run([exe, os.path.join(GOLDEN, "blob"), "multi", str(n_slots)], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert f"rccl={0 if mode == 'plain' else 1}" in r.stdout
+
+
+def test_multi_context_python_and_rccl_failure_is_loud(gpu_ctx, oracle, monkeypatch):
+    import frieda_amd
+
+    blobs = [splitmix64_bytes(500 + i, 900 + 333 * i).tobytes() for i in range(5)]
+    cfg = _cfg(frieda_amd, 8, 4, 0, 10)
+    mc = frieda_amd.MultiContext([0])
+    assert mc.device_count == 1 and not mc.uses_rccl
+    assert mc.commit_many(blobs, 4) == [oracle.commit(b, 4) for b in blobs]
+    got = mc.prove_many(blobs, list(range(5)), cfg)
+    for i, (root, proof) in enumerate(got):
+        o_root, o_proof = oracle.commit_and_generate_proof(blobs[i], i, oracle.make_config(8, 4, 0, 10))
+        assert root == o_root and proof.serialize() == o_proof.serialize()
+    assert mc.prove_many([], None, cfg) == [] and mc.commit_many([], 4) == []
+    mc.close()
+    # an RCCL that cannot be loaded fails the creation of a multi-device handle instead of falling back to anything
+    monkeypatch.setenv("FRIEDA_RCCL_PATH", "/nonexistent/librccl.so")
+    with pytest.raises(frieda_amd.FriedaError):
+        frieda_amd.MultiContext([0, 0])
+    with pytest.raises(frieda_amd.FriedaError):
+        frieda_amd.MultiContext([])
+    with pytest.raises(frieda_amd.FriedaError):
+        frieda_amd.MultiContext([99])
 
 
 def test_panics_map_to_status(gpu_ctx):
@@ -464,6 +592,41 @@ def test_config3_prove_2p22_matches_oracle(gpu_ctx, oracle):
     g_root, g_proof = gpu_ctx.commit_and_generate_proof(data, data.size, _cfg(frieda_amd, 20, 4, 0, 20))
     assert g_root == o_root and g_proof.n_inner_layers == 17
     assert g_proof.serialize() == o_proof.serialize()
+
+
+def test_config4_eight_2p22_blobs_match_the_oracle(gpu_ctx, oracle):
+    """BASELINE.json configs[3] at N = 1: the batch of 8 independent 2^22-domain blobs (generator seeds 100..107, SURVEY.md §8d
+    config 4) through the sharding helpers (batch.commit_batch / prove_batch — world size 1 here, the same code the ranks run)
+    and through the C ABI's multi-GPU entry (frieda_commit_many / frieda_prove_many, one device slot): all 8 roots and all 8
+    proofs byte-identical to the oracle's (computed on 8 host threads)."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    import frieda_amd
+    from frieda_amd import batch
+
+    blobs = [splitmix64_bytes(100 + i, blob_len_for(22)).tobytes() for i in range(8)]
+    seeds = [len(b) for b in blobs]  # benches/proof.rs:23
+    cfg = _cfg(frieda_amd, 20, 4, 0, 20)
+    ocfg = oracle.make_config(20, 4, 0, 20)
+    with ThreadPoolExecutor(max_workers=8) as ex:
+        expected = list(ex.map(lambda a: oracle.commit_and_generate_proof(a[0], a[1], ocfg), zip(blobs, seeds)))
+    exp_roots = [r for r, _ in expected]
+    exp_proofs = [p.serialize() for _, p in expected]
+    assert len(set(exp_roots)) == 8
+    # sharding helpers
+    assert batch.commit_batch(blobs, 4) == exp_roots
+    roots, proofs = batch.prove_batch(blobs, seeds, cfg)
+    assert roots == exp_roots
+    assert [proofs[i].serialize() for i in range(8)] == exp_proofs
+    del proofs
+    # C ABI multi entry
+    mc = frieda_amd.MultiContext([0])
+    assert mc.commit_many(blobs, 4) == exp_roots
+    got = mc.prove_many(blobs, seeds, cfg)
+    assert [r for r, _ in got] == exp_roots
+    assert [p.serialize() for _, p in got] == exp_proofs
+    assert all(frieda_amd.verify(p, s) for (_, p), s in zip(got, seeds))
+    mc.close()
 
 
 def test_config5_prove_2p24_matches_oracle(gpu_ctx, oracle):

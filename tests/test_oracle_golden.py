@@ -233,3 +233,34 @@ def test_oracle_every_set_of_distinct_cells_reconstructs(oracle, L, n, m):
     for cs in itertools.combinations(range(1 << (n - m)), 1 << (L - m)):
         cells = np.stack([ev[:, c << m : (c + 1) << m] for c in cs])
         assert np.array_equal(oracle.reconstruct_cells(cells, np.array(cs, dtype=np.uint32), n, L, tw, itw), coef), cs
+
+
+def test_bit_reverse_column_is_the_index_permutation(oracle):
+    """ColumnOps::bit_reverse_column (stwo core/utils.rs bit_reverse): out[brev(i)] = in[i]."""
+    for lg in (0, 1, 2, 5, 9, 12):
+        v = np.arange(1 << lg, dtype=np.uint32) * 7 + 3
+        got = oracle.bit_reverse_column(v)
+        idx = np.array([int(format(i, f"0{lg}b")[::-1], 2) if lg else 0 for i in range(1 << lg)])
+        assert np.array_equal(got[idx], v)
+        assert np.array_equal(oracle.bit_reverse_column(got), v)
+
+
+def test_selfcheck_trace_is_reproduced_by_the_oracle(oracle):
+    """tests/golden/trace_selfcheck.json is SELF-GENERATED (tools/dump_trace.py), not reference-held: this only guards the oracle
+    against drifting away from the file a cargo-side diff would be made against."""
+    import json
+    import os
+    import sys
+
+    from conftest import GOLDEN, ROOT
+
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import dump_trace
+
+    doc = json.load(open(os.path.join(GOLDEN, "trace_selfcheck.json")))
+    assert "NOT reference-held" in doc["provenance"]
+    fresh = dump_trace.build_doc()
+    assert fresh["cases"] == doc["cases"]
+    # the tie the reference does test (src/proof.rs:126-135): first FRI root == commit() root, here the golden root for the blob
+    blob_case = [c for c in doc["cases"] if c["input"] == "blob"][0]
+    assert blob_case["roots"][0] == blob_case["commitment"] == "d1a2d5069dc587e55dc29cc6255af937ff7fed0ee41bdf5af98717f9d74f60e8"
