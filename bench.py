@@ -8,6 +8,12 @@ configuration): unpack -> 4 x circle NTT -> first Merkle tree -> every FRI fold 
 interpolation -> grind (pow_bits 20) -> 20 query openings.  value = M31 field elements committed per second =
 n_gpus * 4 * 2^n * steps / wall time, inputs already resident in HBM when the timed region starts.
 
+The K timed steps process K DISTINCT blobs per GPU (a stream of blobs, as a data-availability node sees them) with
+`--in-flight` proofs in flight (default 2: one context = stream + workspace each, so the Fiat-Shamir latency chain of one
+proof runs under the chip-filling kernels of the next).  Every one of the K timed proofs is verified after the timed region
+and the K roots must be distinct; `sequential` in the JSON line is the one-proof-at-a-time figure (`--in-flight 1` makes it
+the headline).
+
 Multi-GPU: one process per GPU (torch.distributed, backend nccl = RCCL), independent blobs sharded one per rank (weak
 scaling); nothing is exchanged while blobs are processed — every rank keeps the roots of its K blobs and the ranks exchange
 them in ONE all_gather of K x 32 bytes per rank after the last step, inside the timed region.  `python bench.py --gpus N`
@@ -210,11 +216,17 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-twiddle-cache", action="store_true", help="regenerate twiddles every call, as the reference does")
     ap.add_argument("--batch-extra", type=int, default=4, help="blobs per call for the extra 'batched' figure (0 = skip)")
-    ap.add_argument("--pipeline-depth", type=int, default=2, help="proofs in flight for the extra 'pipelined' figure (0 = skip)")
+    ap.add_argument("--in-flight", type=int, default=2,
+                    help="proofs in flight in the measured loop (one context each); 1 = one proof at a time")
+    ap.add_argument("--pipeline-depth", type=int, default=None, help="deprecated alias: 0 means --in-flight 1")
+    ap.add_argument("--sequential-extra", type=int, default=20, help="proofs for the extra one-at-a-time figure (0 = skip)")
     ap.add_argument("--dry-collective", choices=["gloo"], default=None,
                     help="CPU rehearsal of the N > 1 plumbing: launcher, rendezvous, barriers, root all_gather and max-reduce over gloo; GPU work stubbed")
     ap.add_argument("--launch-timeout", type=float, default=1500.0, help="seconds the self-launcher waits for its ranks")
-    return ap.parse_args(argv)
+    args = ap.parse_args(argv)
+    if args.pipeline_depth is not None:
+        args.in_flight = max(1, args.pipeline_depth)
+    return args
 
 
 def launch_ranks(args):
@@ -350,7 +362,12 @@ def main():
 
     n = args.log_domain
     blob_len = blob_len_for(n)
-    blob = torch.from_numpy(splitmix64_bytes(100 + rank, blob_len)).cuda()
+    K = args.steps
+    D = max(1, args.in_flight) if args.workload == "prove" else 1
+    # K DISTINCT blobs per rank, resident in HBM before the timed region (generator: splitmix64, seeds 100 + rank * K + i; the
+    # first blob of rank 0 is the seed-100 blob the CPU baseline proves, so the two roots can be compared)
+    blobs = [torch.from_numpy(splitmix64_bytes(100 + rank * K + i, blob_len)).cuda() for i in range(K)]
+    blob = blobs[0]
     stream = torch.cuda.Stream()
     ctx = frieda_amd.Context(local_rank, stream.cuda_stream)
     if args.no_twiddle_cache:
@@ -360,29 +377,44 @@ def main():
     roots_dev = torch.zeros(32, dtype=torch.uint8, device="cuda")
     # The blobs are independent: nothing is exchanged while they are processed.  Each rank keeps the roots of its K blobs and the
     # ranks exchange them once, after the last blob and inside the timed region: one all_gather (RCCL) of K x 32 bytes per rank.
-    K = args.steps
     roots_all = torch.zeros(32 * K, dtype=torch.uint8, device="cuda")
     gathered = torch.zeros(32 * K * world, dtype=torch.uint8, device="cuda")
-    host_roots = []
+    # `D` proofs in flight (one context = stream + workspace each): the Fiat-Shamir latency chain of one proof runs under the
+    # chip-filling kernels of the next.  D = 1 is one proof at a time.
+    pipe = frieda_amd.ProofPipeline(local_rank, D) if args.workload == "prove" else None
+    if pipe is not None and args.no_twiddle_cache:
+        for c in pipe.ctxs:
+            c.set_twiddle_cache(False)
 
-    def step(i=None):
+    def step(i=None):  # one proof / commit at a time on `ctx` (set-up, instrumented replay, the extra figures)
         if args.workload == "prove":
-            root, proof = ctx.commit_and_generate_proof_device(blob.data_ptr(), blob_len, seed, cfg)
-            if i is not None:
-                host_roots.append(root)
-            return root, proof
+            return ctx.commit_and_generate_proof_device(blob.data_ptr(), blob_len, seed, cfg)
         dst = roots_dev.data_ptr() if i is None else roots_all.data_ptr() + 32 * i
-        ctx.commit_device(blob.data_ptr(), blob_len, 4, dst)
+        ctx.commit_device(blobs[i if i is not None else 0].data_ptr(), blob_len, 4, dst)
         return None, None
 
-    def gather_roots():
+    def run_stream(n_blobs):
+        """the measured loop: blob i of this rank through the hot path, D proofs in flight; returns [(root, proof)] in order"""
+        if args.workload != "prove":
+            for i in range(n_blobs):
+                step(i)
+            return []
+        out = []
+        for i in range(n_blobs):
+            r = pipe.submit_device(blobs[i].data_ptr(), blob_len, seed, cfg)
+            if r is not None:
+                out.append(r)
+        out.extend(pipe.drain())
+        return out
+
+    def gather_roots(results):
         nonlocal gathered
         if not use_dist:
             return
         from frieda_amd import batch
 
         if args.workload == "prove":
-            roots_all.copy_(torch.frombuffer(bytearray(b"".join(host_roots)), dtype=torch.uint8))
+            roots_all.copy_(torch.frombuffer(bytearray(b"".join(r for r, _ in results)), dtype=torch.uint8))
         else:
             ctx.synchronize()  # the roots were written on the ctx stream; the collective runs on torch's
         gathered = batch.gather_rank_roots(roots_all, roots_all.device).view(-1)
@@ -393,21 +425,22 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # setup, outside the contract's warm-up: the first calls size the workspace arena, build the twiddle tables and load the
+    # setup, outside the contract's warm-up: the first calls size the workspace arenas, build the twiddle tables and load the
     # code objects; the chip also needs a few milliseconds of load before it settles on its clock
-    for _ in range(4):
+    for _ in range(2):
         step()
+    run_stream(min(K, 2 * D))
     torch.cuda.synchronize()
-    last = (None, None)
-    for _ in range(args.warmup):
-        last = step()
+    W = args.warmup
+    while W > 0:  # W untimed warm-up steps through the measured loop itself
+        run_stream(min(W, K))
+        W -= min(W, K)
     if use_dist:
         dist.all_gather_into_tensor(gathered, roots_all)  # warm the collective (communicator set-up happens on first use)
     fence()
     t0 = time.perf_counter()
-    for i in range(K):
-        last = step(i)
-    gather_roots()
+    results = run_stream(K)
+    gather_roots(results)
     fence()
     dt = time.perf_counter() - t0
     if use_dist:
@@ -419,18 +452,25 @@ def main():
         mine = bytes(gathered[32 * K * rank : 32 * K * (rank + 1)].cpu().numpy())
         assert mine == bytes(roots_all.cpu().numpy()), "root gather mismatch"
         if args.workload == "prove":
-            assert mine == b"".join(host_roots)
+            assert mine == b"".join(r for r, _ in results)
 
-    # correctness gate on what was just timed: the proof verifies and its first root equals commit()'s
+    # correctness gate on what was just timed: EVERY one of the K proofs verifies, the K roots are distinct, and the first FRI
+    # root of blob 0 equals commit()'s
+    verified = None
     if args.workload == "prove":
-        root, proof = last
-        assert frieda_amd.verify(proof, seed), "timed proof does not verify"
+        assert len(results) == K and len({r for r, _ in results}) == K, "the K timed blobs must give K distinct roots"
+        for r, p in results:
+            assert p.commitment == r and frieda_amd.verify(p, seed), "a timed proof does not verify"
+        verified = K
+        root, proof = results[0]
         ctx.commit_device(blob.data_ptr(), blob_len, 4, roots_dev.data_ptr())
         ctx.synchronize()
         assert bytes(roots_dev.cpu().numpy()) == root, "first FRI root != commit() root"
+        proof0_image = proof.serialize()
+        del results
     else:
         ctx.synchronize()
-        root = bytes(roots_all[32 * (K - 1) :].cpu().numpy())
+        root = bytes(roots_all[:32].cpu().numpy())
 
     host_phases = ctx.last_prove_phases() if args.workload == "prove" else None
     elems = 4.0 * (1 << n)
@@ -461,37 +501,27 @@ def main():
             "alg_bytes_per_launch": dom["alg_bytes"] / max(dom["launches"], 1),
             "measured": "HIP events on the ctx stream, instrumented replay of the timed K steps",
         }
-    # ---- extra figure: the same K proofs with `depth` of them in flight (one ctx = stream + workspace each) ----
-    pipelined = None
-    if args.workload == "prove" and args.pipeline_depth > 1 and world == 1:
-        pipe = frieda_amd.ProofPipeline(local_rank, args.pipeline_depth)
-        for _ in range(args.pipeline_depth + 1):
-            pipe.submit_device(blob.data_ptr(), blob_len, seed, cfg)
-        pipe.drain()
+    # ---- extra figure: one proof at a time (in flight 1) on blob 0 — what round 1 reported as `value` ----
+    sequential = None
+    if args.workload == "prove" and args.sequential_extra > 0 and world == 1:
+        reps = args.sequential_extra
+        step()
         torch.cuda.synchronize()
-        tp0 = time.perf_counter()
-        n_done = 0
-        last_p = None
-        for _ in range(args.steps):
-            r = pipe.submit_device(blob.data_ptr(), blob_len, seed, cfg)
-            if r is not None:
-                n_done += 1
-                last_p = r
-        for r in pipe.drain():
-            n_done += 1
-            last_p = r
+        ts0 = time.perf_counter()
+        for _ in range(reps):
+            r_seq, p_seq = step()
         torch.cuda.synchronize()
-        dtp = time.perf_counter() - tp0
-        assert n_done == args.steps and last_p[0] == root and frieda_amd.verify(last_p[1], seed)
-        pipelined = {
-            "depth": args.pipeline_depth,
-            "value": elems * args.steps / dtp,
+        dts = (time.perf_counter() - ts0) / reps
+        assert r_seq == root and p_seq.serialize() == proof0_image
+        sequential = {
+            "in_flight": 1,
+            "value": elems / dts,
             "unit": "M31 field-elems/s",
-            "ms_per_proof": 1e3 * dtp / args.steps,
-            "frac_of_hbm_peak": algorithmic_bytes(n, "prove") / (dtp / args.steps) / 1e9 / HBM_PEAK_GBS,
-            "note": "same K proofs, same blob and config, `depth` proofs in flight on separate streams; not the headline value",
+            "ms_per_proof": 1e3 * dts,
+            "frac_of_hbm_peak": algorithmic_bytes(n, "prove") / dts / 1e9 / HBM_PEAK_GBS,
+            "note": f"{reps} proofs of blob 0, one at a time on one context (latency of a lone proof); not the headline value",
         }
-        pipe.close()
+        host_phases = ctx.last_prove_phases()
 
     # ---- extra figure: the batched entry point (frieda_commit_and_generate_proof_batch_device): `batch` blobs of this size per
     # call, every kernel launched once for all of them, so the Fiat-Shamir / launch latency chain is paid once per batch ----
@@ -502,7 +532,7 @@ def main():
         bseeds = [seed] * bsz
         bctx = frieda_amd.Context(local_rank)
         res = bctx.commit_and_generate_proof_batch_device(many.data_ptr(), blob_len, blob_len, bsz, bseeds, cfg)  # sizes the workspace
-        assert all(r == root for r, _ in res) and res[-1][1].serialize() == proof.serialize()
+        assert all(r == root for r, _ in res) and res[-1][1].serialize() == proof0_image
         reps = max(2, args.steps // bsz)
         torch.cuda.synchronize()
         tb0 = time.perf_counter()
@@ -579,6 +609,8 @@ def main():
             "blob_bytes": blob_len,
             "pcs_config": {"pow_bits": 20, "log_last_layer_degree_bound": 0, "n_queries": 20},
             "parallelism": f"{world} independent blobs per step, one per GPU; one all_gather of the K x 32-byte roots per rank after the last step",
+            "blobs": f"{K} distinct blobs per GPU (splitmix64 seeds 100 + rank * K + i), resident in HBM; every timed proof verified after the timed region" if args.workload == "prove" else f"{K} distinct blobs per GPU",
+            "in_flight": D,
             "twiddles": "regenerated per call" if args.no_twiddle_cache else "cached per context",
         },
         "roofline": roofline,
@@ -597,8 +629,9 @@ def main():
             ],
         },
         "uncached_twiddles": uncached,
-        "pipelined": pipelined,
+        "sequential": sequential,
         "batched": batched,
+        "verified_proofs": verified,
         "root": root.hex() if root else None,
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

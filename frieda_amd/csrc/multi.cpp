@@ -160,6 +160,10 @@ int frieda_multi_create(const int* devices, uint32_t n_devices, frieda_multi** o
     if (!out) return FRIEDA_ERR_ARG;
     *out = nullptr;
     if (!devices || n_devices == 0 || n_devices > 64) return FRIEDA_ERR_ARG;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess) return FRIEDA_ERR_HIP;
+    for (uint32_t d = 0; d < n_devices; d++)
+        if (devices[d] < 0 || devices[d] >= ndev) return FRIEDA_ERR_ARG;  // before any HIP call could record a sticky error
     frieda_multi* m = new (std::nothrow) frieda_multi();
     if (!m) return FRIEDA_ERR_NOMEM;
     try {
