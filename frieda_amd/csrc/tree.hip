@@ -41,6 +41,11 @@ namespace k {
 
 namespace {
 
+// The latency-bound kernels (a chain of dependent compressions on a handful of waves) often share the chip with the
+// chip-filling kernels of another proof in flight.  A raised wave priority lets their few waves win the SIMD's issue arbitration
+// (priority, then age) against the co-resident throughput waves, which lose next to nothing: the chain is <= 8 waves per CU.
+__device__ __forceinline__ void latency_kernel_priority() { __builtin_amdgcn_s_setprio(3); }
+
 constexpr int T5_THREADS = 256;
 constexpr uint32_t T5_UNITS = 1024;
 constexpr uint32_t T5_LEVELS = 5;
@@ -564,6 +569,7 @@ template <int MODE>
 __global__ __launch_bounds__(256) void tree9_kernel(TreeArgs a) {
     __shared__ __attribute__((aligned(16))) uint32_t RA[8 * (256 + 4)];
     __shared__ __attribute__((aligned(16))) uint32_t QQ[2 * QBUF_WORDS];
+    latency_kernel_priority();
     tree_args_of_blob(a);
     const uint32_t t = threadIdx.x, q = t & 3, quad = t >> 2;
     QuadCtx x;
@@ -628,6 +634,7 @@ constexpr uint32_t T7Q_LEVELS = 7;
 
 __global__ __launch_bounds__(256) void tree7q_kernel(TreeArgs a) {
     __shared__ __attribute__((aligned(16))) uint32_t QQ[2 * QBUF_WORDS];
+    latency_kernel_priority();
     tree_args_of_blob(a);
     const uint32_t t = threadIdx.x, q = t & 3, quad = t >> 2;
     QuadCtx x;
@@ -675,6 +682,7 @@ __global__ __launch_bounds__(WG1_THREADS) void top_kernel(TopArgs a) {
     __shared__ __attribute__((aligned(16))) uint32_t S0[8 * (1024 + 4)];
     __shared__ __attribute__((aligned(16))) uint32_t S1[8 * (512 + 4)];
     __shared__ __attribute__((aligned(16))) uint32_t QQ[2 * QBUF_WORDS];
+    latency_kernel_priority();
     {
         const size_t off = (size_t)blockIdx.y * a.bstride;
         a.in += off;
@@ -767,6 +775,7 @@ __global__ __launch_bounds__(WG1_THREADS) void tail_kernel(TailArgs a) {
     __shared__ __attribute__((aligned(16))) uint32_t S1[8 * (TAIL_CAP / 2 + 4)];
     __shared__ __attribute__((aligned(16))) uint32_t QQ[2 * QBUF_WORDS];
     __shared__ uint32_t s_alpha[4];
+    latency_kernel_priority();
     uint32_t* const MSG = S0 + 4 * TAIL_CAP + 8;  // the upper half of S0 is free once the last layer is reached
     const uint32_t t = threadIdx.x, q = t & 3;
     const size_t boff = (size_t)blockIdx.y * a.bstride;  // this workgroup's blob
@@ -908,7 +917,7 @@ __global__ __launch_bounds__(WG1_THREADS) void tail_kernel(TailArgs a) {
 // sequential search; blobs that finish early release their workgroups to the others (in a batch the slowest blob needs
 // several times the mean).  Every loop is bounded: a claim consumes one of n_windows * batch windows, a fruitless walk over
 // all blobs ends the workgroup.
-constexpr uint32_t GRIND_WINDOW = 1024;  // nonces per claim: 4 per lane
+constexpr uint32_t GRIND_WINDOW = 256;  // nonces per claim: 1 per lane — the chip sweeps the nonces in (nearly) increasing order
 
 struct GrindArgs {
     DevTranscript* tr;  // array over the blobs of the batch
@@ -1214,8 +1223,9 @@ void grind_dev(const Launch& L, DevTranscript* tr, uint32_t* d_next, uint32_t po
     if (a.n_windows == 0) return;
     Scope scope(L, "grind", 0.0);
     if (!next_zeroed) (void)hipMemsetAsync(d_next, 0, sizeof(uint32_t) * L.batch, L.stream);
-    // workgroups in flight: the chip holds 2048 (8 per CU); a lone blob gets no more than cover about half the expected search
-    // (2^pow_bits nonces), so that the windows in flight when the first hit arrives are not mostly beyond it
+    // workgroups in flight: the chip holds 2048 (8 per CU) = 2^19 nonces of 256-nonce windows per sweep; a lone blob gets no more
+    // than cover about half the expected search (2^pow_bits nonces), so that the windows in flight when the first hit arrives
+    // are not mostly beyond it
     uint64_t want = (((uint64_t)1 << (pow_bits > 40 ? 40 : pow_bits)) / 2 / GRIND_WINDOW) * L.batch;
     if (want < 64) want = 64;
     if (want > 2048) want = 2048;
