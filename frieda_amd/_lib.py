@@ -9,7 +9,8 @@ import subprocess
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_PKG)
-LIB_PATH = os.path.join(_PKG, "lib", "libfrieda_hip.so")
+# FRIEDA_HIP_LIB: an alternative build of the same library (A/B experiments: tools/build_variant.sh); never a fallback
+LIB_PATH = os.environ.get("FRIEDA_HIP_LIB") or os.path.join(_PKG, "lib", "libfrieda_hip.so")
 HEADER_PATH = os.path.join(_ROOT, "include", "frieda_hip.h")
 
 OK, ERR_ARG, ERR_HIP, ERR_INVARIANT, ERR_NOMEM, ERR_FORMAT = 0, 1, 2, 3, 4, 5

@@ -48,7 +48,9 @@ __device__ __forceinline__ bool emit_of(const uint32_t* u, uint32_t nu, uint32_t
 }
 
 __global__ __launch_bounds__(DC_THREADS) void decommit_kernel(DecommitArgs a) {
+#ifndef FRIEDA_NO_LATENCY_PRIO
     __builtin_amdgcn_s_setprio(3);  // a latency chain that may share the chip with another proof's wide kernels (tree.hip)
+#endif
     __shared__ uint32_t s_q[DC_MAX_Q];        // raw draws, then sorted
     __shared__ uint32_t s_u[DC_MAX_Q];        // sorted unique queries
     __shared__ uint32_t s_scan[2][DC_MAX_Q];  // prefix sums of the "first occurrence" flags (more than 64 queries only)

@@ -73,6 +73,21 @@ void gen_twiddles(const Launch& L, uint32_t n, const TwiddleSeeds& seeds, uint32
 void circle_evaluate(const Launch& L_, const uint32_t* d_coef, size_t coef_stride, uint32_t ncols, uint32_t L, uint32_t n,
                      const uint32_t* d_tw, DomainScalars ds, uint32_t* d_out, size_t out_stride);
 
+// The same transform with its contiguous last pass fused with leaf hashing: when the shape allows it (4 columns, >= 12 real
+// layers, 16-byte aligned buffers) the last launch also produces the tree levels n .. n-6 of the Merkle tree over the 4 columns
+// (ENCODE_TREE_LEVELS levels, 2^(n-6) hashes at the top) and returns true; otherwise it is circle_evaluate and returns false.
+//   sink->layers   non-null: generate_proof shape — the evaluation is written to d_out and every level n-1 .. n-6 is stored at its
+//                  leaves-first offset in `layers` (the leaf hashes themselves are never written: nothing reads them);
+//   sink->layers   null: commit() shape — the evaluation is NOT written by the last pass (d_out only holds the strided passes'
+//                  intermediate), only the 2^(n-6) hashes of level n-6 go to sink->last_out.
+struct EncodeTreeSink {
+    uint8_t* layers;
+    uint8_t* last_out;
+};
+constexpr uint32_t ENCODE_TREE_LEVELS = 7;
+bool circle_evaluate_into_tree(const Launch& L_, const uint32_t* d_coef, size_t coef_stride, uint32_t ncols, uint32_t L, uint32_t n,
+                               const uint32_t* d_tw, DomainScalars ds, uint32_t* d_out, size_t out_stride, const EncodeTreeSink* sink);
+
 // ---- intt.hip (reconstruction side) ----
 // block `block` (2^L consecutive bit-reversed evaluations per column) -> the 2^L coefficients per column
 void circle_interpolate_block(const Launch& L_, const uint32_t* d_block, size_t in_stride, uint32_t ncols, uint32_t L, uint32_t n,
@@ -116,6 +131,14 @@ namespace k {
 // the finishing kernel reads it from there and initialises the device transcript itself — no copy in the stream
 void tree_first_layer(const Launch& L, const uint32_t* cols, size_t stride, uint32_t m, uint8_t* d_layers, DevTranscript* tr,
                       const DevTranscript* tr_init = nullptr, size_t tr_init_pitch = 0);
+// Encode + first tree in one call (commit(): src/commit.rs:16-21; FriProver::commit_first_layer: src/proof.rs:48-52): the
+// transform of the 4 coordinate columns with its last pass fused with leaf hashing where the shape allows
+// (circle_evaluate_into_tree), then the rest of the tree.  d_layers non-null: every level above the leaf hashes is kept and the
+// evaluation is written (generate_proof); null: only the root survives, d_scratch must hold merkle_root_scratch_bytes(n) and
+// d_root receives it (commit).  tr / tr_init as tree_first_layer.
+void encode_and_first_tree(const Launch& L, const uint32_t* d_coef, size_t coef_stride, uint32_t Lc, uint32_t n, const uint32_t* d_tw,
+                           DomainScalars ds, uint32_t* d_eval, size_t eval_stride, uint8_t* d_layers, uint8_t* d_scratch, uint8_t* d_root,
+                           DevTranscript* tr, const DevTranscript* tr_init = nullptr, size_t tr_init_pitch = 0);
 // fold the layer `src` (log size src_log; circle evaluation or line layer) with the alpha in tr into dst_vals and build the
 // tree of the folded layer in the same launches (leaf hashes not written, as above); finishes with the channel step
 void fold_and_tree(const Launch& L, bool circle, const uint32_t* src, size_t src_stride, uint32_t src_log, uint32_t n,

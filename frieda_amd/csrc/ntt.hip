@@ -30,11 +30,13 @@
 #include <cstdlib>
 
 #include "kernels.h"
+#include "tree_dev.h"
 
 namespace frieda {
 namespace k {
 
 namespace {
+using namespace treedev;
 
 constexpr int NTT_THREADS = 256;
 constexpr uint32_t TILE_LOG = 12;
@@ -317,6 +319,204 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_tile12_kernel(NttArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The last transform pass fused with leaf hashing (commit(): src/commit.rs:16-21; FriProver::commit_first_layer: src/proof.rs:48-52)
+// ------------------------------------------------------------------------------------------------
+// A workgroup of the contiguous last pass ends up holding the same 4096 points of all four coordinate columns — exactly the
+// 4096 leaves (4 column words each) of one subtree of the first Merkle tree.  Instead of writing the evaluation and having a
+// tree kernel read it straight back, the thread keeps its 16 consecutive points of every column in registers (it already holds
+// them after the last radix-16 stage), hashes the 16 leaves and the 15 nodes above them, and the workgroup adds two more
+// levels through LDS: seven tree levels (2^n leaves .. 2^(n-6) nodes) leave the kernel, 64 hashes per workgroup at the top.
+// The evaluation is written once (generate_proof folds and opens it) or not at all (commit() needs only the root); it is
+// never re-read.  The transform's memory and LDS phases of one workgroup run under the hashing of the others on the CU.
+// Hashing runs four leaves at a time in a rolled loop (the 7-compression body of tree5r, ~54 KB of code) over register arrays
+// that rotate by four each iteration, so that every index is static.
+struct NttTreeArgs {
+    NttArgs a;
+    uint8_t* layers;    // STORE_ALL: tree storage (leaves-first offsets); the leaf level itself is never written (nothing reads it)
+    uint8_t* last_out;  // !STORE_ALL: the 2^(n-6) hashes of the last level produced
+    size_t bstride;     // batch: bytes between blobs' workspaces (blob = blockIdx.z)
+};
+
+
+template <bool STORE_ALL>
+__global__ __launch_bounds__(NTT_THREADS) void ntt_last_tree_kernel(NttTreeArgs A) {
+    __shared__ uint32_t lds[TILE_WORDS];
+    __shared__ __attribute__((aligned(16))) uint32_t RC[8 * (256 + 4)];
+    __shared__ __attribute__((aligned(16))) uint32_t RD[8 * (128 + 4)];
+    const NttArgs& a = A.a;
+    const uint32_t g = threadIdx.x;
+    const uint32_t hblk = blockIdx.x;  // i_hi == 11, i_lo == 0, log_w == 0: one contiguous 4096-word tile per workgroup
+    const uint32_t gbase = hblk << TILE_LOG;
+    const uint32_t* in = a.in + blockIdx.z * a.bstride_w;
+    uint32_t* out = a.out + blockIdx.z * a.bstride_w;
+
+    uint32_t pbase[3];
+    uint32_t twd[3][15];
+#pragma unroll
+    for (int s = 0; s < 3; s++) {
+        const uint32_t lo = 8 - 4 * s;
+        const uint32_t base = ((g >> lo) << (lo + 4)) | (g & ((1u << lo) - 1));
+        pbase[s] = pad(base);
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const uint32_t b = lo + 3 - q;  // tile bit == global layer index
+            const uint32_t hbase = (hblk << (11 - b)) | (base >> (b + 1));
+            if (s == 2 && q == 3) {  // layer 0: the circle layer
+#pragma unroll
+                for (int u = 0; u < 8; u++) twd[s][7 + u] = circle_twiddle(a.tw, a.n, hbase + (uint32_t)u, a.init_y);
+            } else {
+                const uint32_t* lvl = a.tw + tw_level_offset_dev(a.n, b - 1) + hbase;
+#pragma unroll
+                for (int u = 0; u < (1 << q); u++) {
+                    uint32_t v = lvl[u];
+                    if (s == 0) v = (uint32_t)__builtin_amdgcn_readfirstlane((int)v);  // workgroup-uniform (ntt_tile12_kernel)
+                    twd[s][(1 << q) - 1 + u] = v;
+                }
+            }
+        }
+    }
+    auto piece_e = [&](int kk) { return 4u * g + 1024u * (uint32_t)kk; };
+
+    uint4 pre[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; kk++) pre[kk] = *reinterpret_cast<const uint4*>(in + ((gbase | piece_e(kk)) & a.in_mask));
+
+    uint32_t v[4][16];  // the thread's 16 consecutive points (tile elements 16 g .. 16 g + 15) of every column
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++) {
+            const uint32_t p = pad(piece_e(kk));
+            lds[p] = pre[kk].x;
+            lds[p + 1] = pre[kk].y;
+            lds[p + 2] = pre[kk].z;
+            lds[p + 3] = pre[kk].w;
+        }
+        __syncthreads();
+        if (c + 1 < 4) {
+            const uint32_t* src = in + (size_t)(c + 1) * a.in_stride;
+#pragma unroll
+            for (int kk = 0; kk < 4; kk++) pre[kk] = *reinterpret_cast<const uint4*>(src + ((gbase | piece_e(kk)) & a.in_mask));
+        }
+#pragma unroll
+        for (int s = 0; s < 3; s++) {
+            const uint32_t lo = 8 - 4 * s;
+            uint32_t* col = lds + pbase[s];
+            uint32_t* x = v[c];
+#pragma unroll
+            for (int r = 0; r < 16; r++) x[r] = col[pad((uint32_t)r << lo)];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int bit = 3 - q;
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    if (r & (1 << bit)) continue;
+                    const int u = r >> (bit + 1);
+                    const uint32_t t = m31_mul(x[r | (1 << bit)], twd[s][(1 << q) - 1 + u]);
+                    const uint32_t w = x[r];
+                    x[r] = m31_add(w, t);
+                    x[r | (1 << bit)] = m31_sub(w, t);
+                }
+            }
+            if (s < 2) {
+#pragma unroll
+                for (int r = 0; r < 16; r++) col[pad((uint32_t)r << lo)] = x[r];
+            }
+            __syncthreads();
+        }
+        if (STORE_ALL) {  // generate_proof folds and opens the evaluation; commit() never reads it
+            uint4* o = reinterpret_cast<uint4*>(out + (size_t)c * a.out_stride + gbase + 16u * g);
+            o[0] = make_uint4(v[c][0], v[c][1], v[c][2], v[c][3]);
+            o[1] = make_uint4(v[c][4], v[c][5], v[c][6], v[c][7]);
+            o[2] = make_uint4(v[c][8], v[c][9], v[c][10], v[c][11]);
+            o[3] = make_uint4(v[c][12], v[c][13], v[c][14], v[c][15]);
+        }
+    }
+
+    // ---- 16 leaves -> 1 node of level n - 4, in registers ----
+    const uint32_t m = a.n;
+    uint8_t* layers = A.layers + blockIdx.z * A.bstride;
+    uint8_t* out_b = STORE_ALL ? layers + layer_off(m, m - 1) : nullptr;
+    uint8_t* out_c = STORE_ALL ? layers + layer_off(m, m - 2) : nullptr;
+    uint8_t* out_d = STORE_ALL ? layers + layer_off(m, m - 3) : nullptr;
+    uint8_t* out_e = STORE_ALL ? layers + layer_off(m, m - 4) : nullptr;
+    const size_t leaf0 = (size_t)gbase + 16u * g;
+    uint32_t hprev[8], hdprev[8];
+#pragma unroll 1
+    for (int it = 0; it < 4; it++) {
+        const size_t l0 = leaf0 + 4u * (uint32_t)it;
+        uint32_t hb[2][8];
+#pragma unroll
+        for (int half = 0; half < 2; half++) {
+            uint32_t ha[2][8];
+            leaf_hash(v[0][2 * half], v[1][2 * half], v[2][2 * half], v[3][2 * half], ha[0]);
+            leaf_hash(v[0][2 * half + 1], v[1][2 * half + 1], v[2][2 * half + 1], v[3][2 * half + 1], ha[1]);
+            uint32_t mm[16];
+#pragma unroll
+            for (int w = 0; w < 8; w++) mm[w] = ha[0][w], mm[8 + w] = ha[1][w];
+            b2_merkle_block(mm, hb[half]);
+        }
+        if (STORE_ALL) {
+            store_hash(out_b, l0 >> 1, hb[0]);
+            store_hash(out_b, (l0 >> 1) + 1, hb[1]);
+        }
+        uint32_t hc[8];
+        {
+            uint32_t mm[16];
+#pragma unroll
+            for (int w = 0; w < 8; w++) mm[w] = hb[0][w], mm[8 + w] = hb[1][w];
+            b2_merkle_block(mm, hc);
+        }
+        if (STORE_ALL) store_hash(out_c, l0 >> 2, hc);
+        if ((it & 1) == 0) {
+#pragma unroll
+            for (int w = 0; w < 8; w++) hprev[w] = hc[w];
+        } else {
+            uint32_t hd[8], mm[16];
+#pragma unroll
+            for (int w = 0; w < 8; w++) mm[w] = hprev[w], mm[8 + w] = hc[w];
+            b2_merkle_block(mm, hd);
+            if (STORE_ALL) store_hash(out_d, l0 >> 3, hd);
+            if (it == 1) {
+#pragma unroll
+                for (int w = 0; w < 8; w++) hdprev[w] = hd[w];
+            } else {
+                uint32_t he[8];
+#pragma unroll
+                for (int w = 0; w < 8; w++) mm[w] = hdprev[w], mm[8 + w] = hd[w];
+                b2_merkle_block(mm, he);
+                if (STORE_ALL) store_hash(out_e, l0 >> 4, he);
+                lds_put(RC, 256 + 4, g, he);
+            }
+        }
+        // the next four leaves move to the front of the arrays (static indices only)
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+#pragma unroll
+            for (int r = 0; r < 12; r++) v[c][r] = v[c][r + 4];
+        }
+    }
+    __syncthreads();
+    // ---- levels n - 5 and n - 6 through LDS (as tree5r) ----
+    const size_t wg_e = (size_t)gbase >> 4;  // index of this workgroup's first node at level n - 4
+    if (g < 128) {
+        uint32_t mm[16], h[8];
+        lds_children(RC, 256 + 4, g, mm);
+        b2_merkle_block(mm, h);
+        if (STORE_ALL) store_hash(layers + layer_off(m, m - 5), (wg_e >> 1) + g, h);
+        lds_put(RD, 128 + 4, g, h);
+    }
+    __syncthreads();
+    if (g < 64) {
+        uint32_t mm[16], h[8];
+        lds_children(RD, 128 + 4, g, mm);
+        b2_merkle_block(mm, h);
+        uint8_t* dst = STORE_ALL ? layers + layer_off(m, m - 6) : A.last_out + blockIdx.z * A.bstride;
+        store_hash(dst, (wg_e >> 2) + g, h);
+    }
+}
+
 // pure replication (L == 0: a constant polynomial has no real layers)
 __global__ void ntt_broadcast_kernel(const uint32_t* __restrict__ in, size_t in_stride, uint32_t* __restrict__ out,
                                      size_t out_stride, size_t n_out, size_t bstride_w) {
@@ -340,6 +540,11 @@ void set_stages(NttArgs& a, uint32_t t) {
 
 void circle_evaluate(const Launch& L_, const uint32_t* d_coef, size_t coef_stride, uint32_t ncols, uint32_t L, uint32_t n,
                      const uint32_t* d_tw, DomainScalars ds, uint32_t* d_out, size_t out_stride) {
+    (void)circle_evaluate_into_tree(L_, d_coef, coef_stride, ncols, L, n, d_tw, ds, d_out, out_stride, nullptr);
+}
+
+bool circle_evaluate_into_tree(const Launch& L_, const uint32_t* d_coef, size_t coef_stride, uint32_t ncols, uint32_t L, uint32_t n,
+                               const uint32_t* d_tw, DomainScalars ds, uint32_t* d_out, size_t out_stride, const EncodeTreeSink* sink) {
     const size_t N = (size_t)1 << n;
     hipStream_t s = L_.stream;
     // algorithmic bytes of the encode: read 2^L, write 2^n words per column (16N(1 + 2^-B) for 4 columns),
@@ -349,7 +554,7 @@ void circle_evaluate(const Launch& L_, const uint32_t* d_coef, size_t coef_strid
         Scope scope(L_, "ntt_broadcast", enc_bytes);
         dim3 grid((unsigned)((N + 255) / 256), ncols, L_.batch);
         ntt_broadcast_kernel<<<grid, 256, 0, s>>>(d_coef, coef_stride, d_out, out_stride, N, L_.bstride / 4);
-        return;
+        return false;
     }
     // columns per workgroup: the largest divisor of ncols that is <= 4 (the 4 coordinate columns share every twiddle)
     static const uint32_t cpw_max = [] {
@@ -385,9 +590,30 @@ void circle_evaluate(const Launch& L_, const uint32_t* d_coef, size_t coef_strid
     uint32_t cpw4 = MAX_COLS_PER_WG;
     while (ncols % cpw4) cpw4--;
     // one pass over layers a.i_hi .. a.i_lo
+    bool fused = false;
     auto launch_pass = [&](uint32_t t, const char* name) {
         const bool aligned = ((a.in_stride | a.out_stride) & 3) == 0 && (a.in_mask & 3u) == 3u &&
                              ((reinterpret_cast<uintptr_t>(a.in) | reinterpret_cast<uintptr_t>(a.out) | L_.bstride) & 15) == 0;
+        if (sink && aligned && a.log_w == 0 && t == 12 && ncols == 4 && n >= TILE_LOG) {
+            // the contiguous last pass of 12 layers over the 4 coordinate columns: fused with leaf hashing + 6 tree levels
+            NttTreeArgs ta{};
+            ta.a = a;
+            ta.a.ncols = 4;
+            ta.layers = sink->layers;
+            ta.last_out = sink->last_out;
+            ta.bstride = L_.bstride;
+            // algorithmic bytes: this pass's share of the encode + leaves (16 B in, 32 B out) + 6 node levels (96 B per node)
+            double bytes = enc_bytes / (n_mid + 1) + 48.0 * (double)N;
+            for (uint32_t l = 1; l <= 6; l++) bytes += 96.0 * (double)(N >> l);
+            Scope scope(L_, "ntt_last_tree7", bytes);
+            const dim3 grid((unsigned)(N >> TILE_LOG), 1, L_.batch);
+            if (sink->layers)
+                ntt_last_tree_kernel<true><<<grid, NTT_THREADS, 0, s>>>(ta);
+            else
+                ntt_last_tree_kernel<false><<<grid, NTT_THREADS, 0, s>>>(ta);
+            fused = true;
+            return;
+        }
         Scope scope(L_, name, enc_bytes / (n_mid + 1));
         if (aligned && t + a.log_w == TILE_LOG && (t == 12 || t == 8)) {
             a.ncols = cpw4;
@@ -422,6 +648,7 @@ void circle_evaluate(const Launch& L_, const uint32_t* d_coef, size_t coef_strid
     a.i_lo = 0;
     a.log_w = 0;
     launch_pass(last_t, "ntt_pass_last");
+    return fused;
 }
 
 }  // namespace k

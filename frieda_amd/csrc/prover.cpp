@@ -128,8 +128,8 @@ int commit_device(Ctx* ctx, const uint8_t* d_data, size_t len, uint32_t log_blow
     uint32_t* coef = reinterpret_cast<uint32_t*>(ctx->arena + o_coef);
     uint32_t* eval = reinterpret_cast<uint32_t*>(ctx->arena + o_eval);
     k::unpack30(ctx->launch(), d_data, len, coef, sh.cs.n_padded);
-    k::circle_evaluate(ctx->launch(), coef, (size_t)1 << sh.L, 4, sh.L, sh.n, tw.d_tw, tw.ds, eval, sh.N);
-    k::merkle_root4(ctx->launch(), eval, eval + sh.N, eval + 2 * sh.N, eval + 3 * sh.N, sh.n, ctx->arena + o_scr, d_root);
+    k::encode_and_first_tree(ctx->launch(), coef, (size_t)1 << sh.L, sh.L, sh.n, tw.d_tw, tw.ds, eval, sh.N, nullptr, ctx->arena + o_scr, d_root,
+                             nullptr);
     FR_HIP(ctx, hipGetLastError());
     return FRIEDA_OK;
 }
@@ -199,8 +199,7 @@ int commit_batch(Ctx* ctx, const uint8_t* data, size_t data_stride, size_t len, 
     uint32_t* coef = reinterpret_cast<uint32_t*>(A + o_coef);
     uint32_t* eval = reinterpret_cast<uint32_t*>(A + o_eval);
     k::unpack30(LN, d_data, len, coef, sh.cs.n_padded, d_stride);
-    k::circle_evaluate(LN, coef, (size_t)1 << sh.L, 4, sh.L, sh.n, tw.d_tw, tw.ds, eval, sh.N);
-    k::merkle_root4(LN, eval, eval + sh.N, eval + 2 * sh.N, eval + 3 * sh.N, sh.n, A + o_scr, A + o_root);
+    k::encode_and_first_tree(LN, coef, (size_t)1 << sh.L, sh.L, sh.n, tw.d_tw, tw.ds, eval, sh.N, nullptr, A + o_scr, A + o_root, nullptr);
     FR_HIP(ctx, hipMemcpy2DAsync(ctx->pinned, 32, A + o_root, bstride, 32, count, hipMemcpyDeviceToHost, s));
     FR_HIP(ctx, hipStreamSynchronize(s));
     FR_HIP(ctx, hipGetLastError());
@@ -473,7 +472,6 @@ int prove_begin_batch(Ctx* ctx, const uint8_t* data, size_t data_stride, size_t 
     uint32_t* eval = reinterpret_cast<uint32_t*>(A + first.o_vals);
     k::unpack30(LN, d_data, len, coef, sh.cs.n_padded, d_data_stride);
     ctx->phase_ms[5] = ms_since(t_entry);  // set-up before the first launch (workspace plan, twiddle lookup, ...) + that launch call
-    k::circle_evaluate(LN, coef, (size_t)1 << sh.L, 4, sh.L, n, tw.d_tw, tw.ds, eval, N);
 
     for (uint32_t b = 0; b < count; b++) {
         J.blobs[b].ch.init();
@@ -502,8 +500,9 @@ int prove_begin_batch(Ctx* ctx, const uint8_t* data, size_t data_stride, size_t 
             // no copy in the stream: the kernel that finishes the first tree reads these few words from the pinned block itself
             // (the block is next written by the transcript download behind the grind, i.e. after that kernel)
         }
-        // FriProver::commit_first_layer
-        k::tree_first_layer(LN, eval, N, n, A + first.o_tree, d_tr, reinterpret_cast<const DevTranscript*>(ctx->pinned), tr_host_pitch);
+        // the encode's last pass runs fused with FriProver::commit_first_layer's leaf hashing (src/proof.rs:48-52)
+        k::encode_and_first_tree(LN, coef, (size_t)1 << sh.L, sh.L, n, tw.d_tw, tw.ds, eval, N, A + first.o_tree, nullptr, nullptr, d_tr,
+                                 reinterpret_cast<const DevTranscript*>(ctx->pinned), tr_host_pitch);
         // FriProver::commit_inner_layers: layers above 2^11 points, one fused fold + tree each
         const FriLayerDev* cur = &first;
         bool circle = true;
@@ -562,6 +561,7 @@ int prove_begin_batch(Ctx* ctx, const uint8_t* data, size_t data_stride, size_t 
         };
 
         // ---- FriProver::commit_first_layer ----
+        k::circle_evaluate(LN, coef, (size_t)1 << sh.L, 4, sh.L, n, tw.d_tw, tw.ds, eval, N);
         k::merkle_tree4(LN, cols(first, 0), cols(first, 1), cols(first, 2), cols(first, 3), n, A + first.o_tree);
         rc = fetch_root(first, roots[0]);
         if (rc) return rc;

@@ -35,6 +35,7 @@
 #include "blake2s.h"
 #include "dev_transcript.h"
 #include "kernels.h"
+#include "tree_dev.h"
 
 namespace frieda {
 namespace k {
@@ -44,47 +45,18 @@ namespace {
 // The latency-bound kernels (a chain of dependent compressions on a handful of waves) often share the chip with the
 // chip-filling kernels of another proof in flight.  A raised wave priority lets their few waves win the SIMD's issue arbitration
 // (priority, then age) against the co-resident throughput waves, which lose next to nothing: the chain is <= 8 waves per CU.
-__device__ __forceinline__ void latency_kernel_priority() { __builtin_amdgcn_s_setprio(3); }
+__device__ __forceinline__ void latency_kernel_priority() {
+#ifndef FRIEDA_NO_LATENCY_PRIO
+    __builtin_amdgcn_s_setprio(3);
+#endif
+}
 
 constexpr int T5_THREADS = 256;
 constexpr uint32_t T5_UNITS = 1024;
 constexpr uint32_t T5_LEVELS = 5;
 constexpr int WG1_THREADS = 512;  // single-workgroup kernels: 2 waves per SIMD saturate the VALU; 256 VGPRs per lane for the quad hash
 
-// ---- LDS hash levels, struct-of-arrays: word w of hash j at reg[w * stride + j], stride = count + 4 (even) ----
-__device__ __forceinline__ void lds_put(uint32_t* reg, uint32_t stride, uint32_t j, const uint32_t (&h)[8]) {
-#pragma unroll
-    for (int w = 0; w < 8; w++) reg[w * stride + j] = h[w];
-}
-__device__ __forceinline__ void lds_children(const uint32_t* reg, uint32_t stride, uint32_t j, uint32_t (&m)[16]) {
-#pragma unroll
-    for (int w = 0; w < 8; w++) {
-        uint2 v = *reinterpret_cast<const uint2*>(reg + w * stride + 2 * j);
-        m[w] = v.x;
-        m[8 + w] = v.y;
-    }
-}
-__device__ __forceinline__ void store_hash(uint8_t* out, size_t i, const uint32_t (&h)[8]) {
-    uint4* o = reinterpret_cast<uint4*>(out + 32 * i);
-    o[0] = make_uint4(h[0], h[1], h[2], h[3]);
-    o[1] = make_uint4(h[4], h[5], h[6], h[7]);
-}
-__device__ __forceinline__ void load_children(const uint8_t* prev, size_t i, uint32_t (&m)[16]) {
-    const uint4* p = reinterpret_cast<const uint4*>(prev + 64 * i);
-    uint4 a = p[0], b = p[1], c = p[2], d = p[3];
-    m[0] = a.x, m[1] = a.y, m[2] = a.z, m[3] = a.w;
-    m[4] = b.x, m[5] = b.y, m[6] = b.z, m[7] = b.w;
-    m[8] = c.x, m[9] = c.y, m[10] = c.z, m[11] = c.w;
-    m[12] = d.x, m[13] = d.y, m[14] = d.z, m[15] = d.w;
-}
-// leaf of 4 column words: the twelve zero message words are compile-time constants, so their adds fold away
-__device__ __forceinline__ void leaf_hash(uint32_t v0, uint32_t v1, uint32_t v2, uint32_t v3, uint32_t (&h)[8]) {
-    const uint32_t m[16] = {v0, v1, v2, v3, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    b2_merkle_block(m, h);
-}
-__device__ __forceinline__ size_t layer_off(uint32_t tree_log, uint32_t layer) {
-    return ((size_t)64 << tree_log) - ((size_t)64 << layer);
-}
+using namespace treedev;
 
 __device__ __forceinline__ uint32_t inv_circle_twiddle(const uint32_t* __restrict__ itw, uint32_t n, size_t i, uint32_t inv_init_y) {
     if (n < 3) return (i & 1u) ? m31_neg(inv_init_y) : inv_init_y;
@@ -917,7 +889,8 @@ __global__ __launch_bounds__(WG1_THREADS) void tail_kernel(TailArgs a) {
 // sequential search; blobs that finish early release their workgroups to the others (in a batch the slowest blob needs
 // several times the mean).  Every loop is bounded: a claim consumes one of n_windows * batch windows, a fruitless walk over
 // all blobs ends the workgroup.
-constexpr uint32_t GRIND_WINDOW = 256;  // nonces per claim: 1 per lane — the chip sweeps the nonces in (nearly) increasing order
+constexpr uint32_t GRIND_WINDOW = 1024;  // nonces per claim: 4 per lane (256-nonce windows were tried: the claim — an atomic and two
+                                         // barriers — then costs as much as the scan, 47 instead of 19 us on the bench blob)
 
 struct GrindArgs {
     DevTranscript* tr;  // array over the blobs of the batch
@@ -1079,27 +1052,13 @@ double node_levels_bytes(uint32_t la, uint32_t levels) {
 
 }  // namespace
 
-// Builds the tree of a layer whose level A is produced by `mode`; finishes with the root (and the channel step when tr).
-// `layers` non-null = keep every level (leaves-first); else only the root survives and `scratch` (>= 2 * 32 * 2^(m-4) B) is used.
-void build_tree(const Launch& L, int mode, TreeArgs a, uint32_t m, uint8_t* layers, uint8_t* scratch, uint8_t* root_out,
-                DevTranscript* tr, const DevTranscript* tr_init = nullptr, size_t tr_init_pitch = 0) {
-    a.level_a = m;
-    a.tree_log = m;
-    a.layers = layers;
-    a.store_all = layers != nullptr;
-    a.bstride = L.bstride;
-    uint8_t* s0 = scratch;
-    uint8_t* s1 = scratch ? scratch + ((size_t)32 << (m > 4 ? m - 4 : 0)) : nullptr;
-    a.last_out = s0;
-    // level A: leaves (16 B columns in, 32 B out) or fold+leaves (32 B pair in, 16 B values + 32 B hash out); nodes: 96 B each
-    auto bytes_of = [](int md, uint32_t la, uint32_t levels) -> double {
-        if (md == T_NODE) return node_levels_bytes(la, levels);
-        return (md == T_LEAF4 ? 48.0 : 80.0) * (double)((size_t)1 << la) + node_levels_bytes(la > 0 ? la - 1 : 0, levels - 1);
-    };
-    const char* nm = mode == T_LEAF4 ? "tree5_leaf" : (mode == T_FOLD_CIRCLE ? "tree5_fold_circle" : "tree5_fold_line");
-    const uint32_t lv = launch_tree_a(L, mode, a, nm, bytes_of);
-    uint32_t cur = m - (lv - 1);  // lowest-index (smallest) level produced so far
-    const uint8_t* cur_ptr = layers ? layers + merkle_layer_offset(m, cur) : s0;
+// The part of a tree above an already produced level: level `cur` (2^cur hashes per blob) sits at cur_ptr (inside `a.layers` at
+// its leaves-first offset when every level is kept, else in scratch half s0 or s1); node launches until the single-workgroup top
+// kernel can take over, which finishes with the root (and the channel step when tr).
+void finish_tree(const Launch& L, const TreeArgs& a, uint32_t m, uint32_t cur, const uint8_t* cur_ptr, uint8_t* s0, uint8_t* s1,
+                 uint8_t* root_out, DevTranscript* tr, const DevTranscript* tr_init, size_t tr_init_pitch) {
+    uint8_t* layers = a.store_all ? a.layers : nullptr;
+    auto bytes_of = [](int, uint32_t la, uint32_t levels) -> double { return node_levels_bytes(la, levels); };
     while (cur > TOP_MAX_LOG) {
         TreeArgs b = a;
         b.skip_a = 0;
@@ -1134,6 +1093,54 @@ void build_tree(const Launch& L, int mode, TreeArgs a, uint32_t m, uint8_t* laye
         Scope scope(L, "tree_top", node_levels_bytes(cur > 0 ? cur - 1 : 0, cur));
         top_kernel<<<dim3(1, L.batch), WG1_THREADS, 0, L.stream>>>(tp);
     }
+}
+
+// Builds the tree of a layer whose level A is produced by `mode`; finishes with the root (and the channel step when tr).
+// `layers` non-null = keep every level (leaves-first); else only the root survives and `scratch` (>= 2 * 32 * 2^(m-4) B) is used.
+void build_tree(const Launch& L, int mode, TreeArgs a, uint32_t m, uint8_t* layers, uint8_t* scratch, uint8_t* root_out,
+                DevTranscript* tr, const DevTranscript* tr_init = nullptr, size_t tr_init_pitch = 0) {
+    a.level_a = m;
+    a.tree_log = m;
+    a.layers = layers;
+    a.store_all = layers != nullptr;
+    a.bstride = L.bstride;
+    uint8_t* s0 = scratch;
+    uint8_t* s1 = scratch ? scratch + ((size_t)32 << (m > 4 ? m - 4 : 0)) : nullptr;
+    a.last_out = s0;
+    // level A: leaves (16 B columns in, 32 B out) or fold+leaves (32 B pair in, 16 B values + 32 B hash out); nodes: 96 B each
+    auto bytes_of = [](int md, uint32_t la, uint32_t levels) -> double {
+        if (md == T_NODE) return node_levels_bytes(la, levels);
+        return (md == T_LEAF4 ? 48.0 : 80.0) * (double)((size_t)1 << la) + node_levels_bytes(la > 0 ? la - 1 : 0, levels - 1);
+    };
+    const char* nm = mode == T_LEAF4 ? "tree5_leaf" : (mode == T_FOLD_CIRCLE ? "tree5_fold_circle" : "tree5_fold_line");
+    const uint32_t lv = launch_tree_a(L, mode, a, nm, bytes_of);
+    const uint32_t cur = m - (lv - 1);  // lowest-index (smallest) level produced so far
+    finish_tree(L, a, m, cur, layers ? layers + merkle_layer_offset(m, cur) : s0, s0, s1, root_out, tr, tr_init, tr_init_pitch);
+}
+
+void encode_and_first_tree(const Launch& L, const uint32_t* d_coef, size_t coef_stride, uint32_t Lc, uint32_t n, const uint32_t* d_tw,
+                           DomainScalars ds, uint32_t* d_eval, size_t eval_stride, uint8_t* d_layers, uint8_t* d_scratch, uint8_t* d_root,
+                           DevTranscript* tr, const DevTranscript* tr_init, size_t tr_init_pitch) {
+    static const bool no_fuse = getenv("FRIEDA_NO_ENCODE_TREE_FUSION") != nullptr;  // A/B knob
+    uint8_t* s0 = d_scratch;
+    uint8_t* s1 = d_scratch ? d_scratch + ((size_t)32 << (n > 4 ? n - 4 : 0)) : nullptr;
+    EncodeTreeSink sink{d_layers, s0};
+    const bool fused = circle_evaluate_into_tree(L, d_coef, coef_stride, 4, Lc, n, d_tw, ds, d_eval, eval_stride, no_fuse ? nullptr : &sink);
+    if (!fused) {
+        TreeArgs a{};
+        a.cols = d_eval;
+        a.col_stride = eval_stride;
+        a.skip_a = d_layers != nullptr && n >= 1;  // the prover never reads the leaf hashes (plan_merkle_decommit, prover.cpp)
+        build_tree(L, T_LEAF4, a, n, d_layers, d_scratch, d_root, tr, tr_init, tr_init_pitch);
+        return;
+    }
+    TreeArgs a{};
+    a.tree_log = n;
+    a.layers = d_layers;
+    a.store_all = d_layers != nullptr;
+    a.bstride = L.bstride;
+    const uint32_t cur = n - (ENCODE_TREE_LEVELS - 1);
+    finish_tree(L, a, n, cur, d_layers ? d_layers + merkle_layer_offset(n, cur) : s0, s0, s1, d_root, tr, tr_init, tr_init_pitch);
 }
 
 void merkle_tree4(const Launch& L, const uint32_t* c0, const uint32_t* c1, const uint32_t* c2, const uint32_t* c3, uint32_t m,
@@ -1223,9 +1230,8 @@ void grind_dev(const Launch& L, DevTranscript* tr, uint32_t* d_next, uint32_t po
     if (a.n_windows == 0) return;
     Scope scope(L, "grind", 0.0);
     if (!next_zeroed) (void)hipMemsetAsync(d_next, 0, sizeof(uint32_t) * L.batch, L.stream);
-    // workgroups in flight: the chip holds 2048 (8 per CU) = 2^19 nonces of 256-nonce windows per sweep; a lone blob gets no more
-    // than cover about half the expected search (2^pow_bits nonces), so that the windows in flight when the first hit arrives
-    // are not mostly beyond it
+    // workgroups in flight: the chip holds 2048 (8 per CU); a lone blob gets no more than cover about half the expected search
+    // (2^pow_bits nonces), so that the windows in flight when the first hit arrives are not mostly beyond it
     uint64_t want = (((uint64_t)1 << (pow_bits > 40 ? 40 : pow_bits)) / 2 / GRIND_WINDOW) * L.batch;
     if (want < 64) want = 64;
     if (want > 2048) want = 2048;
