@@ -170,7 +170,7 @@ class Context:
         )
 
     def reconstruct_from_cells(self, cells, cell_index, log_coef, log_domain, n_bytes):
-        """cells: uint32[R, 4, 2^m] (cell r = entries cell_index[r] * 2^m .. of every column), R = 2^(log_coef - m) <= 256
+        """cells: uint32[R, 4, 2^m] (cell r = entries cell_index[r] * 2^m .. of every column), R = 2^(log_coef - m) <= 4096
         distinct cells anywhere in the codeword -> the blob."""
         import numpy as np
 

@@ -2,6 +2,7 @@
 // No exception leaves this file: every entry point catches and maps to a status code.
 #include <string.h>
 
+#include <algorithm>
 #include <new>
 
 #include "host.h"
@@ -653,32 +654,51 @@ int interpolate_cells(frieda_ctx* ctx, const uint32_t* d_cells, const uint32_t* 
     FR_NO_JOB(&c);
     if (log_cell < 1 || log_cell > log_coef || log_coef > log_domain || log_domain > FRIEDA_MAX_LOG_DOMAIN)
         return c.fail(FRIEDA_ERR_ARG, "cells: need 1 <= log_cell <= log_coef <= log_domain");
-    if (log_coef - log_cell > 8 || n_cells != (1u << (log_coef - log_cell)))
-        return c.fail(FRIEDA_ERR_ARG, "cells: n_cells must be 2^(log_coef - log_cell) and at most 256");
+    if (log_coef - log_cell > FRIEDA_MAX_LOG_CELLS || n_cells != (1u << (log_coef - log_cell)))
+        return c.fail(FRIEDA_ERR_ARG, "cells: n_cells must be 2^(log_coef - log_cell) and at most 2^FRIEDA_MAX_LOG_CELLS");
     for (uint32_t r = 0; r < n_cells; r++)
         if ((uint64_t)cell_index[r] >= ((uint64_t)1 << (log_domain - log_cell))) return c.fail(FRIEDA_ERR_ARG, "cells: cell index out of range");
-    std::vector<uint32_t> vinv;
-    for (uint32_t r = 0; r < n_cells; r++)
-        for (uint32_t q = 0; q < r; q++)
-            if (cell_index[q] == cell_index[r]) return c.fail(FRIEDA_ERR_ARG, "cells: cell indices are not distinct");
-    if (!cells_matrix_inverse(cell_index, n_cells, log_cell, log_domain, vinv))
-        return c.fail(FRIEDA_ERR_ARG, "cells: these cells do not determine the polynomial (singular system)");
+    {
+        std::vector<uint32_t> sorted(cell_index, cell_index + n_cells);
+        std::sort(sorted.begin(), sorted.end());
+        if (std::adjacent_find(sorted.begin(), sorted.end()) != sorted.end()) return c.fail(FRIEDA_ERR_ARG, "cells: cell indices are not distinct");
+    }
     const size_t M = (size_t)1 << log_cell, w_words = (size_t)n_cells * ncols * M;
-    int rc = c.ensure_arena(arena_off + 4 * (w_words + vinv.size()) + 512);
-    if (rc) return rc;
+    const size_t w_bytes = (4 * w_words + 255) & ~(size_t)255;
     TwiddleSet ts;
+    const bool on_device = n_cells > 256;  // the cubic solve moves to the device beyond what the host does in milliseconds
+    std::vector<uint32_t> vinv;
+    if (!on_device && !cells_matrix_inverse(cell_index, n_cells, log_cell, log_domain, vinv))
+        return c.fail(FRIEDA_ERR_ARG, "cells: these cells do not determine the polynomial (singular system)");
+    const size_t solve_bytes = on_device ? k::cells_inverse_scratch_bytes(n_cells) : ((4 * vinv.size() + 255) & ~(size_t)255);
+    int rc = c.ensure_arena(arena_off + w_bytes + solve_bytes + 512);
+    if (rc) return rc;
     rc = c.get_twiddles(log_domain, ts);
     if (rc) return rc;
     uint32_t* d_w = reinterpret_cast<uint32_t*>(c.arena + arena_off);
-    uint32_t* d_vinv = d_w + ((w_words + 63) & ~(size_t)63);
-    FR_HIP(&c, hipMemcpyAsync(d_vinv, vinv.data(), 4 * vinv.size(), hipMemcpyHostToDevice, c.stream));
+    uint8_t* d_solve = c.arena + arena_off + w_bytes;
+    const uint32_t* d_vinv = reinterpret_cast<const uint32_t*>(d_solve);
+    size_t vinv_pitch = n_cells;
+    const uint32_t* d_state = nullptr;
+    if (on_device) {
+        // cell indices behind the solver's own scratch; the blocked Gauss-Jordan leaves V^-1 in the right half of [V | I]
+        uint32_t* d_idx = reinterpret_cast<uint32_t*>(d_solve + k::cells_inverse_scratch_bytes(n_cells) - 4 * (size_t)n_cells - 512);
+        FR_HIP(&c, hipMemcpyAsync(d_idx, cell_index, 4 * (size_t)n_cells, hipMemcpyHostToDevice, c.stream));
+        k::cells_matrix_inverse_device(c.launch(), d_idx, n_cells, log_coef - log_cell, log_cell, log_domain, ts.d_tw, d_solve, &d_vinv, &vinv_pitch,
+                                       &d_state);
+    } else {
+        FR_HIP(&c, hipMemcpyAsync(d_solve, vinv.data(), 4 * vinv.size(), hipMemcpyHostToDevice, c.stream));
+    }
     for (uint32_t r = 0; r < n_cells; r++)  // undo the block transform of every cell (layers log_cell-1 .. 0 with the cell's twiddles)
         k::circle_interpolate_block(c.launch(), d_cells + (size_t)r * ncols * M, M, ncols, log_cell, log_domain, cell_index[r], ts.d_itw, ts.ds,
                                     d_w + (size_t)r * ncols * M, M);
     k::cells_combine(c.launch(), d_w, d_vinv, n_cells, ncols, log_cell, d_coef ? d_coef : reinterpret_cast<uint32_t*>(c.arena),
-                     (size_t)1 << log_coef);
-    FR_HIP(&c, hipStreamSynchronize(c.stream));  // vinv is a local host vector
+                     (size_t)1 << log_coef, vinv_pitch);
+    uint32_t singular = 0;
+    if (d_state) FR_HIP(&c, hipMemcpyAsync(&singular, d_state, 4, hipMemcpyDeviceToHost, c.stream));
+    FR_HIP(&c, hipStreamSynchronize(c.stream));  // vinv / cell_index are host memory of this call
     FR_HIP(&c, hipGetLastError());
+    if (singular) return c.fail(FRIEDA_ERR_ARG, "cells: these cells do not determine the polynomial (singular system)");
     return FRIEDA_OK;
 }
 }  // namespace

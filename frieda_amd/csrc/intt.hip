@@ -206,12 +206,12 @@ void circle_interpolate_block(const Launch& L_, const uint32_t* d_block, size_t 
 
 // coef[col][u * M + t] = sum_r vinv[u][r] * w[r][col][t]   (M = 2^m words per cell and column, R cells; see cells_combine below)
 namespace {
-__global__ __launch_bounds__(256) void cells_combine_kernel(const uint32_t* __restrict__ w, const uint32_t* __restrict__ vinv, uint32_t R,
-                                                            uint32_t ncols, size_t M, uint32_t* __restrict__ coef, size_t coef_stride) {
+__global__ __launch_bounds__(256) void cells_combine_kernel(const uint32_t* __restrict__ w, const uint32_t* __restrict__ vinv, size_t vinv_pitch,
+                                                            uint32_t R, uint32_t ncols, size_t M, uint32_t* __restrict__ coef, size_t coef_stride) {
     const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
     const uint32_t u = blockIdx.y, col = blockIdx.z;
     if (t >= M) return;
-    const uint32_t* row = vinv + (size_t)u * R;
+    const uint32_t* row = vinv + (size_t)u * vinv_pitch;
     uint64_t acc = 0;
     uint32_t pending = 0;
     for (uint32_t r = 0; r < R; r++) {
@@ -229,11 +229,12 @@ __global__ __launch_bounds__(256) void cells_combine_kernel(const uint32_t* __re
 // their block transforms were undone, d_vinv[R][R] the inverse of the matrix V[c][u] = prod_{b in u} s_b(c); the coefficient
 // slice u (entries u * 2^m .. of every column) is the combination sum_r vinv[u][r] * w[r].
 void cells_combine(const Launch& L_, const uint32_t* d_w, const uint32_t* d_vinv, uint32_t R, uint32_t ncols, uint32_t m, uint32_t* d_coef,
-                   size_t coef_stride) {
+                   size_t coef_stride, size_t vinv_pitch) {
+    if (vinv_pitch == 0) vinv_pitch = R;
     const size_t M = (size_t)1 << m;
     Scope scope(L_, "cells_combine", 8.0 * ncols * (double)R * (double)M);
     dim3 grid((unsigned)((M + 255) / 256), R, ncols);
-    cells_combine_kernel<<<grid, 256, 0, L_.stream>>>(d_w, d_vinv, R, ncols, M, d_coef, coef_stride);
+    cells_combine_kernel<<<grid, 256, 0, L_.stream>>>(d_w, d_vinv, vinv_pitch, R, ncols, M, d_coef, coef_stride);
 }
 
 void pack30(const Launch& L_, const uint32_t* d_felts, size_t n_felts, uint8_t* d_out, size_t len) {
@@ -241,6 +242,200 @@ void pack30(const Launch& L_, const uint32_t* d_felts, size_t n_felts, uint8_t* 
     Scope scope(L_, "pack30", 4.0 * (double)n_felts + (double)len);
     size_t n_dw = (len + 3) / 4;
     pack30_kernel<<<(unsigned)((n_dw + 255) / 256), 256, 0, L_.stream>>>(d_felts, n_felts, d_out, len);
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// Reconstruction from MANY scattered cells: the R x R system on the device (257 <= R <= 4096)
+// ------------------------------------------------------------------------------------------------
+// The host inverts the cell matrix V[r][u] = prod_{b in u} s_b(c_r) by Gauss-Jordan for R <= 256 (capi.cpp).  Beyond that the
+// cubic cost belongs on the device: blocked Gauss-Jordan on the augmented matrix [V | I] (R x 2R words, row-major), NB pivots
+// per round, so that the matrix is streamed through the chip R / NB times instead of R times:
+//   panel   one workgroup runs Gauss-Jordan with row pivoting on the R x NB panel (a copy) augmented with the NB x NB identity
+//           on the pivot rows; it records the row swaps and ends with Q (R x NB): the inverse D of the pivot block on the pivot
+//           rows, -F D on every other row (F = that row's panel entries);
+//   swap    the recorded swaps are applied to the full rows and the NB pivot rows are saved;
+//   update  every row becomes (itself, unless it is a pivot row) + Q[row] x (saved pivot rows): one rank-NB update of the whole
+//           matrix, 64-bit accumulators reduced every third product.
+// The left half ends as the identity, the right half as V^-1 (row pitch 2R), which cells_combine consumes directly.
+namespace {
+constexpr uint32_t GJ_NB = 32;
+
+// V | I for the given cells: row r from cell index c = cell_index[r]; s_b(c) = +- T_{m+b-1}[c >> (b+1)], minus when bit b of c is set
+__global__ __launch_bounds__(256) void cells_matrix_kernel(const uint32_t* __restrict__ cell_index, uint32_t R, uint32_t j_bits, uint32_t m,
+                                                           uint32_t n, const uint32_t* __restrict__ tw, uint32_t* __restrict__ M) {
+    __shared__ uint32_t s[16];
+    const uint32_t r = blockIdx.x, c = cell_index[r];
+    if (threadIdx.x < j_bits) {
+        const uint32_t b = threadIdx.x;
+        uint32_t v = tw[tw_level_offset_dev(n, m + b - 1) + (c >> (b + 1))];
+        s[b] = ((c >> b) & 1u) ? m31_neg(v) : v;
+    }
+    __syncthreads();
+    uint32_t* row = M + (size_t)r * 2 * R;
+    for (uint32_t u = threadIdx.x; u < R; u += 256) {
+        uint32_t prod = 1;
+        for (uint32_t b = 0; b < j_bits; b++)
+            if ((u >> b) & 1u) prod = m31_mul(prod, s[b]);
+        row[u] = prod;
+        row[R + u] = u == r ? 1u : 0u;
+    }
+}
+
+struct GjArgs {
+    uint32_t* M;       // R x 2R
+    uint32_t* panel;   // R x 2 NB scratch: [panel copy | Q]
+    uint32_t* pivrows; // NB x 2R scratch: the saved pivot rows
+    uint32_t* state;   // [0] singular flag, [1 .. 1 + NB) the pivot row chosen for each panel column of this round
+    uint32_t R, k0;
+};
+
+__global__ __launch_bounds__(1024) void gj_panel_kernel(GjArgs a) {
+    __shared__ uint32_t s_p;
+    __shared__ uint32_t s_prow[2 * GJ_NB];
+    const uint32_t t = threadIdx.x, R = a.R, W = 2 * GJ_NB;
+    if (a.state[0]) return;
+    uint32_t* P = a.panel;
+    // copy: P[i] = [ M[i][k0 .. k0 + NB) | (i - k0 == j) ]
+    for (uint32_t e = t; e < R * W; e += 1024) {
+        const uint32_t i = e / W, j = e % W;
+        P[e] = j < GJ_NB ? a.M[(size_t)i * 2 * R + a.k0 + j] : ((i - a.k0) == (j - GJ_NB) ? 1u : 0u);
+    }
+    __syncthreads();
+    for (uint32_t j = 0; j < GJ_NB; j++) {
+        const uint32_t k = a.k0 + j;
+        if (t == 0) s_p = ~0u;
+        __syncthreads();
+        for (uint32_t i = k + t; i < R; i += 1024)
+            if (P[(size_t)i * W + j]) atomicMin(&s_p, i);
+        __syncthreads();
+        const uint32_t p = s_p;
+        if (p == ~0u) {  // no pivot: these cells do not determine the polynomial
+            if (t == 0) a.state[0] = 1;
+            return;
+        }
+        if (t == 0) a.state[1 + j] = p;
+        // Swap rows k and p, then scale the new row k by 1 / pivot (kept in LDS).  The right half accumulates Q = T' x Iaug, where
+        // T' is the elimination that plain Gauss-Jordan would perform on the ALREADY permuted panel (the full matrix gets the
+        // swaps first, then T').  A swap found late therefore has to commute past the eliminations done so far:
+        // swap . T = (swap T swap) . swap, and conjugating T by the swap moves rows k and p of (T - I) while the identity
+        // stays in place — so the right half is swapped with each row's own unit entry taken out before and put back after.
+        if (t < W) {
+            uint32_t vk = P[(size_t)k * W + t], vp = P[(size_t)p * W + t];
+            if (t >= GJ_NB && p != k) {
+                const uint32_t jj = t - GJ_NB;
+                const uint32_t ik = jj == j ? 1u : 0u, ip = (p - a.k0) == jj ? 1u : 0u;
+                const uint32_t zk = m31_sub(vk, ik), zp = m31_sub(vp, ip);  // rows of T - I
+                vk = m31_add(zk, ip);  // goes to row p
+                vp = m31_add(zp, ik);  // goes to row k
+            }
+            s_prow[t] = vp;
+            if (p != k) P[(size_t)p * W + t] = vk;
+        }
+        __syncthreads();
+        const uint32_t inv = m31_inv(s_prow[j]);
+        __syncthreads();
+        if (t < W) {
+            const uint32_t v = m31_mul(s_prow[t], inv);
+            s_prow[t] = v;
+            P[(size_t)k * W + t] = v;
+        }
+        __syncthreads();
+        // eliminate column j from every other row: 32 threads per row (one per pair of columns), 32 rows per sweep
+        const uint32_t lane = t & 31, rsub = t >> 5;
+        for (uint32_t i = rsub; i < R; i += 32) {
+            if (i == k) continue;
+            uint32_t* row = P + (size_t)i * W;
+            // the 32 lanes of a row are consecutive lanes of one wave: every lane has loaded f = row[j] (and its own two entries)
+            // before the lane that owns column j stores its zero
+            const uint32_t f = row[j];
+            if (f) {
+                const uint32_t c0 = lane, c1 = lane + 32;
+                const uint32_t v0 = m31_sub(row[c0], m31_mul(f, s_prow[c0]));
+                const uint32_t v1 = m31_sub(row[c1], m31_mul(f, s_prow[c1]));
+                row[c0] = v0;
+                row[c1] = v1;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// apply this round's row swaps to the full rows (in pivot order) and save the NB pivot rows
+__global__ __launch_bounds__(256) void gj_swap_kernel(GjArgs a) {
+    if (a.state[0]) return;
+    const uint32_t c = blockIdx.x * 256 + threadIdx.x, W = 2 * a.R;
+    if (c >= W) return;
+    for (uint32_t j = 0; j < GJ_NB; j++) {
+        const uint32_t k = a.k0 + j, p = a.state[1 + j];
+        uint32_t* rk = a.M + (size_t)k * W + c;
+        if (p != k) {
+            uint32_t* rp = a.M + (size_t)p * W + c;
+            const uint32_t vk = *rk, vp = *rp;
+            *rk = vp;
+            *rp = vk;
+        }
+        a.pivrows[(size_t)j * W + c] = *rk;
+    }
+}
+
+// M[i][c] = (i is a pivot row ? 0 : M[i][c]) + sum_j Q[i][j] * pivrows[j][c]; tile = 64 rows x 256 columns
+__global__ __launch_bounds__(256) void gj_update_kernel(GjArgs a) {
+    __shared__ uint32_t sQ[64 * GJ_NB];
+    if (a.state[0]) return;
+    const uint32_t W = 2 * a.R, c = blockIdx.x * 256 + threadIdx.x, r0 = blockIdx.y * 64;
+    for (uint32_t e = threadIdx.x; e < 64 * GJ_NB; e += 256) {
+        const uint32_t i = r0 + e / GJ_NB;
+        sQ[e] = i < a.R ? a.panel[(size_t)i * 2 * GJ_NB + GJ_NB + e % GJ_NB] : 0u;
+    }
+    __syncthreads();
+    if (c >= W) return;
+    uint32_t piv[GJ_NB];
+#pragma unroll
+    for (uint32_t j = 0; j < GJ_NB; j++) piv[j] = a.pivrows[(size_t)j * W + c];
+    for (uint32_t ii = 0; ii < 64 && r0 + ii < a.R; ii++) {
+        const uint32_t i = r0 + ii;
+        const bool is_piv = i >= a.k0 && i < a.k0 + GJ_NB;
+        uint64_t acc = is_piv ? 0u : a.M[(size_t)i * W + c];
+#pragma unroll
+        for (uint32_t j = 0; j < GJ_NB; j++) {
+            acc += (uint64_t)sQ[ii * GJ_NB + j] * piv[j];  // each product < 2^62
+            if (j % 3 == 2) acc = m31_reduce64(acc);       // three products + a reduced value stay below 2^64
+        }
+        a.M[(size_t)i * W + c] = m31_reduce64(acc);
+    }
+}
+}  // namespace
+
+size_t cells_inverse_scratch_bytes(uint32_t R) {
+    // [V | I] + panel scratch + saved pivot rows + state + device copy of the cell indices
+    return sizeof(uint32_t) * ((size_t)R * 2 * R + (size_t)R * 2 * GJ_NB + (size_t)GJ_NB * 2 * R + 64 + R) + 1024;
+}
+
+// d_scratch: cells_inverse_scratch_bytes(R) bytes, 256-byte aligned.  On return (asynchronously) the inverse sits at
+// *d_vinv_out with row pitch *pitch_out words; d_state_out[0] != 0 reports a singular system.  R a multiple of GJ_NB.
+void cells_matrix_inverse_device(const Launch& L_, const uint32_t* d_cell_index, uint32_t R, uint32_t j_bits, uint32_t m, uint32_t n,
+                                 const uint32_t* d_tw, uint8_t* d_scratch, const uint32_t** d_vinv_out, size_t* pitch_out,
+                                 const uint32_t** d_state_out) {
+    GjArgs a{};
+    a.M = reinterpret_cast<uint32_t*>(d_scratch);
+    a.panel = a.M + (size_t)R * 2 * R;
+    a.pivrows = a.panel + (size_t)R * 2 * GJ_NB;
+    a.state = a.pivrows + (size_t)GJ_NB * 2 * R;
+    a.R = R;
+    hipStream_t s = L_.stream;
+    Scope scope(L_, "cells_inverse", 8.0 * (double)R * 2.0 * (double)R * (double)(R / GJ_NB));
+    (void)hipMemsetAsync(a.state, 0, 64 * sizeof(uint32_t), s);
+    cells_matrix_kernel<<<R, 256, 0, s>>>(d_cell_index, R, j_bits, m, n, d_tw, a.M);
+    for (uint32_t k0 = 0; k0 < R; k0 += GJ_NB) {
+        a.k0 = k0;
+        gj_panel_kernel<<<1, 1024, 0, s>>>(a);
+        gj_swap_kernel<<<(2 * R + 255) / 256, 256, 0, s>>>(a);
+        gj_update_kernel<<<dim3((2 * R + 255) / 256, (R + 63) / 64), 256, 0, s>>>(a);
+    }
+    *d_vinv_out = a.M + R;
+    *pitch_out = 2 * (size_t)R;
+    *d_state_out = a.state;
 }
 
 }  // namespace k

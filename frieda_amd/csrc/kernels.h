@@ -93,8 +93,14 @@ bool circle_evaluate_into_tree(const Launch& L_, const uint32_t* d_coef, size_t 
 void circle_interpolate_block(const Launch& L_, const uint32_t* d_block, size_t in_stride, uint32_t ncols, uint32_t L, uint32_t n,
                               uint32_t block, const uint32_t* d_itw, DomainScalars ds, uint32_t* d_coef, size_t out_stride);
 // reconstruction from scattered cells, second half: coef slice u = sum_r vinv[u][r] * w[r] (w[R][ncols][2^m], vinv[R][R])
+// vinv_pitch: words between rows of d_vinv (0 = R)
 void cells_combine(const Launch& L_, const uint32_t* d_w, const uint32_t* d_vinv, uint32_t R, uint32_t ncols, uint32_t m, uint32_t* d_coef,
-                   size_t coef_stride);
+                   size_t coef_stride, size_t vinv_pitch = 0);
+// the R x R cell matrix inverted on the device (blocked Gauss-Jordan; R a multiple of 32, R <= 4096): see intt.hip
+size_t cells_inverse_scratch_bytes(uint32_t R);
+void cells_matrix_inverse_device(const Launch& L_, const uint32_t* d_cell_index, uint32_t R, uint32_t j_bits, uint32_t m, uint32_t n,
+                                 const uint32_t* d_tw, uint8_t* d_scratch, const uint32_t** d_vinv_out, size_t* pitch_out,
+                                 const uint32_t** d_state_out);
 // inverse of unpack30: felts (30 significant bits each) -> the first `len` bytes of the LSB-first bit stream
 void pack30(const Launch& L_, const uint32_t* d_felts, size_t n_felts, uint8_t* d_out, size_t len);
 

@@ -38,6 +38,7 @@ extern "C" {
 
 #define FRIEDA_ABI_VERSION 1
 #define FRIEDA_MAX_LOG_DOMAIN 28
+#define FRIEDA_MAX_LOG_CELLS 12 /* reconstruction from up to 2^12 scattered cells */
 
 typedef struct frieda_ctx frieda_ctx;
 typedef struct frieda_proof frieda_proof;
@@ -254,9 +255,10 @@ int frieda_reconstruct_device(frieda_ctx* ctx, const uint32_t* d_block, uint32_t
 
 /* Reconstruction from scattered cells — what a sampling client holds.  A cell is an aligned run of 2^log_cell consecutive
  * entries (log_cell >= 1) of the bit-reversed evaluation, the same run of every column: cell c = entries c * 2^log_cell ..
- * (c + 1) * 2^log_cell, c < 2^(log_domain - log_cell).  ANY n_cells = 2^(log_coef - log_cell) distinct cells (at most 256)
- * determine the polynomial: every cell's block transform is undone on the device, then a n_cells x n_cells linear system
- * (inverted once on the host) recombines the coefficient slices.  d_cells[n_cells][ncols][2^log_cell] (cell-major),
+ * (c + 1) * 2^log_cell, c < 2^(log_domain - log_cell).  ANY n_cells = 2^(log_coef - log_cell) distinct cells (at most
+ * 2^FRIEDA_MAX_LOG_CELLS = 4096) determine the polynomial: every cell's block transform is undone on the device, then a
+ * n_cells x n_cells linear system recombines the coefficient slices (inverted on the host up to 256 cells, by a blocked
+ * Gauss-Jordan on the device beyond: cubic in n_cells, ~50 ms at 4096).  d_cells[n_cells][ncols][2^log_cell] (cell-major),
  * cell_index: host array.  n_cells == 1 is frieda_circle_interpolate with block = cell_index[0].  FRIEDA_ERR_ARG for repeated or
  * out-of-range cells (and for a singular system, which distinct cells have never produced). */
 int frieda_circle_interpolate_cells(frieda_ctx* ctx, const uint32_t* d_cells, const uint32_t* cell_index, uint32_t n_cells, uint32_t ncols,

@@ -799,7 +799,36 @@ def test_circle_interpolate_scattered_cells(gpu_ctx, oracle, L, n, m):
     assert L_.frieda_circle_interpolate_cells(gpu_ctx._h, d_cells.ptr, idx.ctypes.data, R + 1, ncols, m, L, n, d_c.ptr) != 0
 
 
-@pytest.mark.parametrize("n_bytes,B,log_cell_below", [(58, 4, 1), (1024, 4, 3), (70001, 2, 6), (262146, 4, 8), (3932160, 4, 8)])
+@pytest.mark.parametrize("L,n,m,with_oracle", [(10, 14, 1, True), (10, 12, 1, False), (12, 16, 2, False), (13, 17, 1, False), (15, 19, 3, False)])
+def test_circle_interpolate_many_cells_device_solve(gpu_ctx, oracle, L, n, m, with_oracle):
+    """More than 256 cells (512 .. 4096): the cell matrix is inverted on the device by a blocked Gauss-Jordan with row pivoting.
+    The coefficients come back exactly; at 512 cells also against the oracle's fo_reconstruct_cells (cubic on the host)."""
+    rng = np.random.default_rng(1900 + 100 * L + 10 * n + m)
+    ncols = 4
+    coef = rand_m31(rng, (ncols, 1 << L))
+    ev = oracle.circle_evaluate(coef, n)
+    R = 1 << (L - m)
+    assert R > 256
+    for trial in range(2):
+        if trial == 0:
+            idx = rng.choice(1 << (n - m), size=R, replace=False).astype(np.uint32)
+        else:  # clustered cells: runs of neighbours share most of their twiddle path (zero pivots inside a panel are likelier)
+            base = rng.choice((1 << (n - m)) // 8, size=R // 8, replace=False).astype(np.uint32) * 8
+            idx = (base[:, None] + np.arange(8, dtype=np.uint32)[None, :]).ravel()[rng.permutation(R)].astype(np.uint32)
+        cells = np.ascontiguousarray(np.stack([ev[:, int(c) << m : (int(c) + 1) << m] for c in idx]))  # [R, ncols, 2^m]
+        if with_oracle and trial == 0:
+            assert np.array_equal(oracle.reconstruct_cells(cells[:, :1], idx, n, L), coef[:1])
+        d_cells, d_c = DevBuf.from_array(gpu_ctx, cells), DevBuf(gpu_ctx, 4 * ncols << L)
+        _check(gpu_ctx, gpu_ctx._L.frieda_circle_interpolate_cells(gpu_ctx._h, d_cells.ptr, idx.ctypes.data, R, ncols, m, L, n, d_c.ptr))
+        assert np.array_equal(d_c.to_array(np.uint32, (ncols, 1 << L)), coef), (trial, idx[:4])
+    bad = idx.copy()
+    bad[R - 1] = bad[3]  # repeated cell
+    assert gpu_ctx._L.frieda_circle_interpolate_cells(gpu_ctx._h, d_cells.ptr, bad.ctypes.data, R, ncols, m, L, n, d_c.ptr) != 0
+    # more cells than the solver takes
+    assert gpu_ctx._L.frieda_circle_interpolate_cells(gpu_ctx._h, d_cells.ptr, idx.ctypes.data, 8192, ncols, 1, 14, 18, d_c.ptr) != 0
+
+
+@pytest.mark.parametrize("n_bytes,B,log_cell_below", [(58, 4, 1), (1024, 4, 3), (70001, 2, 6), (262146, 4, 8), (3932160, 4, 8), (3932160, 4, 12), (983040, 4, 10)])
 def test_encode_sample_cells_reconstruct_round_trip(gpu_ctx, n_bytes, B, log_cell_below):
     """encode -> keep 2^j random cells scattered over the whole codeword (a sampling client's view) -> the original bytes."""
     import ctypes as C
