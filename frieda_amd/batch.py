@@ -16,12 +16,52 @@ def _chunk_size(length):
     return max(1, min(1024, (4 << 30) // (400 * max(length, 1) + 65536)))
 
 
+_multi = {}
+
+
+def _multi_for(device):
+    """The C ABI's multi-GPU handle (frieda_multi_create) over this process's one device: blobs of mixed lengths go through
+    frieda_commit_many / frieda_prove_many, which keeps two proofs in flight per device."""
+    from . import api
+
+    if device not in _multi:
+        _multi[device] = api.MultiContext([device])
+    return _multi[device]
+
+
+def commit_many_on_node(blobs, log_blowup_factor, devices=None):
+    """ONE process, every GPU of the node, through the C ABI (frieda_commit_many): blob i -> devices[i mod n]; the roots are gathered
+    with ncclAllGather on a single-process RCCL communicator.  The alternative to one process per GPU + torch.distributed below."""
+    from . import api
+
+    devs = list(range(torch.cuda.device_count())) if devices is None else list(devices)
+    mc = api.MultiContext(devs)
+    try:
+        return mc.commit_many(blobs, log_blowup_factor)
+    finally:
+        mc.close()
+
+
+def prove_many_on_node(blobs, seeds, pcs_config, devices=None):
+    """frieda_prove_many over the GPUs of the node from one process -> [(commitment, proof)] in blob order."""
+    from . import api
+
+    devs = list(range(torch.cuda.device_count())) if devices is None else list(devices)
+    mc = api.MultiContext(devs)
+    try:
+        return mc.prove_many(blobs, seeds, pcs_config)
+    finally:
+        mc.close()
+
+
 def _local_commit_many(ctx, blobs, log_blowup_factor):
     if len(blobs) > 1 and len({len(b) for b in blobs}) == 1:
         step, out = _chunk_size(len(blobs[0])), []
         for k in range(0, len(blobs), step):
             out += ctx.commit_batch(blobs[k : k + step], log_blowup_factor)
         return out
+    if len(blobs) > 1:
+        return _multi_for(ctx.device).commit_many(blobs, log_blowup_factor)
     return [ctx.commit(b, log_blowup_factor) for b in blobs]
 
 
@@ -33,6 +73,8 @@ def _local_prove_many(ctx, blobs, seeds, pcs_config):
         for k in range(0, len(blobs), step):
             out += ctx.commit_and_generate_proof_batch(blobs[k : k + step], None if seeds is None else seeds[k : k + step], pcs_config)
         return out
+    if len(blobs) > 1:  # mixed lengths (or a last layer beyond the batched kernels): the C ABI's multi entry, two proofs in flight
+        return _multi_for(ctx.device).prove_many(blobs, seeds, pcs_config)
     return [ctx.commit_and_generate_proof(b, None if seeds is None else seeds[i], pcs_config) for i, b in enumerate(blobs)]
 
 

@@ -614,10 +614,26 @@ bool cells_matrix_inverse(const uint32_t* cell_index, uint32_t R, uint32_t m, ui
         uint32_t* row = &A[(size_t)r * 2 * R];
         row[0] = 1;
         for (uint32_t b = 0; b < nb; b++) {
-            const uint32_t lv = m + b - 1;
-            Coset cs = Coset::half_odds(n - 1);
-            for (uint32_t i = 0; i < lv; i++) cs = cs.doubled();
-            uint32_t t = cs.at(bit_reverse(c >> (b + 1), n - 2 - lv)).x;
+            uint32_t t;
+            if (m + b == 0) {
+                // single points (m == 0): bit 0 of the index is the circle layer, twiddle Y[c >> 1] = [y, -y, -x, x][h & 3] of the
+                // pair (x, y) = (T_0[2 (h >> 2)], T_0[2 (h >> 2) + 1])
+                const uint32_t h = c >> 1;
+                const Coset cs = Coset::half_odds(n - 1);
+                if (n < 3) {
+                    const uint32_t y = point_from_index(cs.initial).y;
+                    t = (h & 1u) ? m31_neg(y) : y;
+                } else {
+                    const uint32_t jj = h >> 2, rr = h & 3u;
+                    const uint32_t v = cs.at(bit_reverse(2 * jj + (rr < 2 ? 1 : 0), n - 2)).x;
+                    t = (rr == 1 || rr == 2) ? m31_neg(v) : v;
+                }
+            } else {
+                const uint32_t lv = m + b - 1;
+                Coset cs = Coset::half_odds(n - 1);
+                for (uint32_t i = 0; i < lv; i++) cs = cs.doubled();
+                t = cs.at(bit_reverse(c >> (b + 1), n - 2 - lv)).x;
+            }
             if ((c >> b) & 1u) t = m31_neg(t);
             for (uint32_t u = 0; u < (1u << b); u++) row[(1u << b) + u] = m31_mul(row[u], t);
         }
@@ -652,8 +668,8 @@ int interpolate_cells(frieda_ctx* ctx, const uint32_t* d_cells, const uint32_t* 
                       uint32_t log_coef, uint32_t log_domain, uint32_t* d_coef, size_t arena_off) {
     Ctx& c = ctx->c;
     FR_NO_JOB(&c);
-    if (log_cell < 1 || log_cell > log_coef || log_coef > log_domain || log_domain > FRIEDA_MAX_LOG_DOMAIN)
-        return c.fail(FRIEDA_ERR_ARG, "cells: need 1 <= log_cell <= log_coef <= log_domain");
+    if (log_cell > log_coef || log_coef > log_domain || log_domain < 1 || log_domain > FRIEDA_MAX_LOG_DOMAIN)
+        return c.fail(FRIEDA_ERR_ARG, "cells: need log_cell <= log_coef <= log_domain");
     if (log_coef - log_cell > FRIEDA_MAX_LOG_CELLS || n_cells != (1u << (log_coef - log_cell)))
         return c.fail(FRIEDA_ERR_ARG, "cells: n_cells must be 2^(log_coef - log_cell) and at most 2^FRIEDA_MAX_LOG_CELLS");
     for (uint32_t r = 0; r < n_cells; r++)

@@ -268,7 +268,14 @@ __global__ __launch_bounds__(256) void cells_matrix_kernel(const uint32_t* __res
     const uint32_t r = blockIdx.x, c = cell_index[r];
     if (threadIdx.x < j_bits) {
         const uint32_t b = threadIdx.x;
-        uint32_t v = tw[tw_level_offset_dev(n, m + b - 1) + (c >> (b + 1))];
+        uint32_t v;
+        if (m + b == 0) {  // single points: bit 0 of the index is the circle layer, Y[c >> 1] = [y, -y, -x, x] of a level-0 pair (n >= 3 here)
+            const uint32_t h = c >> 1, rr = h & 3u;
+            v = tw[2 * (h >> 2) + (rr < 2 ? 1 : 0)];
+            if (rr == 1 || rr == 2) v = m31_neg(v);
+        } else {
+            v = tw[tw_level_offset_dev(n, m + b - 1) + (c >> (b + 1))];
+        }
         s[b] = ((c >> b) & 1u) ? m31_neg(v) : v;
     }
     __syncthreads();

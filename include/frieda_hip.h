@@ -254,7 +254,7 @@ int frieda_reconstruct_device(frieda_ctx* ctx, const uint32_t* d_block, uint32_t
                               size_t len, void* d_out_bytes);
 
 /* Reconstruction from scattered cells — what a sampling client holds.  A cell is an aligned run of 2^log_cell consecutive
- * entries (log_cell >= 1) of the bit-reversed evaluation, the same run of every column: cell c = entries c * 2^log_cell ..
+ * entries (log_cell >= 0; log_cell == 0: single sampled points, README.md:56-69's sample() flow) of the bit-reversed evaluation, the same run of every column: cell c = entries c * 2^log_cell ..
  * (c + 1) * 2^log_cell, c < 2^(log_domain - log_cell).  ANY n_cells = 2^(log_coef - log_cell) distinct cells (at most
  * 2^FRIEDA_MAX_LOG_CELLS = 4096) determine the polynomial: every cell's block transform is undone on the device, then a
  * n_cells x n_cells linear system recombines the coefficient slices (inverted on the host up to 256 cells, by a blocked

@@ -334,9 +334,21 @@ void fo_circle_interpolate_block(const uint32_t* block, uint32_t L, uint32_t n, 
  *   and its layers m-1 .. 0 are the block transform of fo_circle_interpolate_block(L = m, k = c).
  * So: undo the block transform of every cell, then solve the R x R system per t (row c of V is the tensor product of (1, s_b(c))
  * over b; Gauss-Jordan).  Returns 0, or -1 when the cells are not distinct / not in range / the system is singular. */
+/* twiddle of the circle layer (layer 0) for the pair (2h, 2h+1): [y, -y, -x, x] from the pairs (x, y) of the first line level */
+static uint32_t circle_layer_twiddle(uint32_t n, uint32_t h, const uint32_t* tw) {
+    if (n < 3) {
+        cpoint init = cp_from_index(coset_half_odds(n - 1).initial);
+        return (h & 1u) ? m31_neg(init.y) : init.y; /* n == 1: [y]; n == 2: [y, -y] */
+    }
+    const uint32_t j = h >> 2, r = h & 3u;
+    const uint32_t v = tw[2 * j + (r < 2 ? 1 : 0)];
+    return (r == 1 || r == 2) ? m31_neg(v) : v;
+}
+
+/* m == 0: the cells are single points of the codeword (what a client that sampled positions holds) */
 int fo_reconstruct_cells(const uint32_t* cells, const uint32_t* cell_index, uint32_t R, uint32_t m, uint32_t L, uint32_t n,
                          const uint32_t* tw, const uint32_t* itw, uint32_t* coef_out) {
-    if (m < 1 || m > L || L > n || R != (1u << (L - m))) return -1;
+    if (m > L || L > n || n < 1 || R != (1u << (L - m))) return -1;
     const size_t M = (size_t)1 << m;
     for (uint32_t r = 0; r < R; r++) {
         if ((uint64_t)cell_index[r] >= ((uint64_t)1 << (n - m))) return -1;
@@ -351,7 +363,7 @@ int fo_reconstruct_cells(const uint32_t* cells, const uint32_t* cell_index, uint
         uint32_t* row = A + (size_t)r * 2 * R;
         row[0] = 1;
         for (uint32_t b = 0; (1u << b) < R; b++) {
-            uint32_t t = tw[tw_level_offset(n, m + b - 1) + (c >> (b + 1))];
+            uint32_t t = (m + b == 0) ? circle_layer_twiddle(n, c >> 1, tw) : tw[tw_level_offset(n, m + b - 1) + (c >> (b + 1))];
             if ((c >> b) & 1u) t = m31_sub(0, t);
             for (uint32_t u = 0; u < (1u << b); u++) row[(1u << b) + u] = m31_mul(row[u], t);
         }

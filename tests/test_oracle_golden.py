@@ -264,3 +264,29 @@ def test_selfcheck_trace_is_reproduced_by_the_oracle(oracle):
     # the tie the reference does test (src/proof.rs:126-135): first FRI root == commit() root, here the golden root for the blob
     blob_case = [c for c in doc["cases"] if c["input"] == "blob"][0]
     assert blob_case["roots"][0] == blob_case["commitment"] == "d1a2d5069dc587e55dc29cc6255af937ff7fed0ee41bdf5af98717f9d74f60e8"
+
+
+@pytest.mark.parametrize("L,n,m", [(0, 1, 0), (1, 1, 0), (2, 2, 0), (3, 5, 0), (5, 9, 0), (4, 6, 2), (6, 8, 1)])
+def test_oracle_reconstructs_from_scattered_cells_and_points(oracle, L, n, m):
+    """fo_reconstruct_cells: any 2^(L-m) distinct cells of 2^m entries give the coefficients back; m == 0 = single sampled points
+    (the circle layer's twiddle enters the system).  Pinned through the transform itself (fo_circle_evaluate is golden-root pinned)."""
+    rng = np.random.default_rng(50 + 10 * L + n + m)
+    coef = rng.integers(0, 2**31 - 1, (2, 1 << L), dtype=np.uint32)
+    ev = oracle.circle_evaluate(coef, n)
+    R = 1 << (L - m)
+    solved = 0
+    for _ in range(12):
+        idx = rng.choice(1 << (n - m), size=R, replace=False).astype(np.uint32)
+        cells = np.ascontiguousarray(np.stack([ev[:, int(c) << m : (int(c) + 1) << m] for c in idx]))
+        try:
+            got = oracle.reconstruct_cells(cells, idx, n, L)
+        except ValueError:
+            # Cells of >= 2 entries hold whole conjugate pairs, the system splits into two Vandermonde systems in x and is never
+            # singular.  Single points can be: the 2^L-dimensional code space is one dimension short of the Riemann-Roch space,
+            # so a point set fails when the unique function vanishing on it falls into the code space (a few % of the sets at
+            # 2^5-point domains, ~1/P at real sizes).  The solver must say so — never return a wrong polynomial.
+            assert m == 0
+            continue
+        assert np.array_equal(got, coef)
+        solved += 1
+    assert solved >= 6
