@@ -14,7 +14,10 @@ t0 = rows[i0][0]
 prev_end = t0
 tot_gap = tot_busy = 0.0
 for s, e, name in rows[i0:i1]:
-    short = name.split("(")[0].replace("frieda::k::(anonymous namespace)::", "").replace("void ", "")
+    import re
+
+    short = re.sub(r"\(anonymous namespace\)::|frieda::k::|void ", "", name)
+    short = re.sub(r"\(.*$", "", short)[:40]
     gap = (s - prev_end) / 1e3
     tot_gap += max(gap, 0)
     tot_busy += (e - s) / 1e3

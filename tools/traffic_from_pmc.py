@@ -38,6 +38,8 @@ RULES = [
     (r"tail_kernel", "fri_tail", 2.0),
     (r"ntt_tile12_kernel<2, 4>", "ntt_pass_mid", 1.0),
     (r"ntt_tile12_kernel<3, 0>", "ntt_pass_last", 2.0),
+    # the fused last pass + leaf hashing reads the strided pass's output with 16-byte fully coalesced loads (the halved pattern)
+    (r"ntt_last_tree_kernel", "ntt_last_tree7", 2.0),
     (r"unpack30", "unpack30", 2.0),
     (r"grind_dev_kernel", "grind", 2.0),
     (r"gather_kernel", "gather", 2.0),
@@ -72,7 +74,14 @@ def main():
     fetch_dir, write_dir, out = sys.argv[1], sys.argv[2], sys.argv[3]
     fa, fraw, fc = collect(fetch_dir, True)
     wa, _, wc = collect(write_dir, False)
-    res = {"_units": "averages per launch of the kernel family over the profiled run; traffic_bytes_per_launch in bytes; "
+    import subprocess
+
+    try:
+        commit = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
+    except OSError:
+        commit = ""
+    res = {"collected_at_commit": (sys.argv[4] if len(sys.argv) > 4 else commit) or None,
+           "_units": "averages per launch of the kernel family over the profiled run; traffic_bytes_per_launch in bytes; "
                      "FETCH_SIZE corrected per kernel symbol (RULES in tools/traffic_from_pmc.py)", "kernels": {}}
     for fam in sorted(set(fa) | set(wa)):
         nf, nw = max(fc.get(fam, 0), 1), max(wc.get(fam, 0), 1)
