@@ -75,17 +75,18 @@ void circle_evaluate(const Launch& L_, const uint32_t* d_coef, size_t coef_strid
 
 // The same transform with its contiguous last pass fused with leaf hashing: when the shape allows it (4 columns, >= 12 real
 // layers, 16-byte aligned buffers) the last launch also produces the tree levels n .. n-6 of the Merkle tree over the 4 columns
-// (ENCODE_TREE_LEVELS levels, 2^(n-6) hashes at the top) and returns true; otherwise it is circle_evaluate and returns false.
+// (ENCODE_TREE_LEVELS levels, 2^(n-6) hashes at the top; 5 levels with the FRIEDA_NTT_TREE_REG_ONLY knob) and returns the number of
+// levels produced; otherwise it is circle_evaluate and returns 0.
 //   sink->layers   non-null: generate_proof shape — the evaluation is written to d_out and every level n-1 .. n-6 is stored at its
 //                  leaves-first offset in `layers` (the leaf hashes themselves are never written: nothing reads them);
 //   sink->layers   null: commit() shape — the evaluation is NOT written by the last pass (d_out only holds the strided passes'
-//                  intermediate), only the 2^(n-6) hashes of level n-6 go to sink->last_out.
+//                  intermediate), only the hashes of the last level produced go to sink->last_out.
 struct EncodeTreeSink {
     uint8_t* layers;
     uint8_t* last_out;
 };
 constexpr uint32_t ENCODE_TREE_LEVELS = 7;
-bool circle_evaluate_into_tree(const Launch& L_, const uint32_t* d_coef, size_t coef_stride, uint32_t ncols, uint32_t L, uint32_t n,
+uint32_t circle_evaluate_into_tree(const Launch& L_, const uint32_t* d_coef, size_t coef_stride, uint32_t ncols, uint32_t L, uint32_t n,
                                const uint32_t* d_tw, DomainScalars ds, uint32_t* d_out, size_t out_stride, const EncodeTreeSink* sink);
 
 // ---- intt.hip (reconstruction side) ----

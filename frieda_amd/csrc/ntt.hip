@@ -339,7 +339,8 @@ struct NttTreeArgs {
 };
 
 
-template <bool STORE_ALL>
+// REG_ONLY: stop after the five register levels (256 nodes of level n - 4 per workgroup): see tree5r_kernel in tree.hip
+template <bool STORE_ALL, bool REG_ONLY = false>
 __global__ __launch_bounds__(NTT_THREADS) void ntt_last_tree_kernel(NttTreeArgs A) {
     __shared__ uint32_t lds[TILE_WORDS];
     __shared__ __attribute__((aligned(16))) uint32_t RC[8 * (256 + 4)];
@@ -440,7 +441,7 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_last_tree_kernel(NttTreeArgs 
     uint8_t* out_b = STORE_ALL ? layers + layer_off(m, m - 1) : nullptr;
     uint8_t* out_c = STORE_ALL ? layers + layer_off(m, m - 2) : nullptr;
     uint8_t* out_d = STORE_ALL ? layers + layer_off(m, m - 3) : nullptr;
-    uint8_t* out_e = STORE_ALL ? layers + layer_off(m, m - 4) : nullptr;
+    uint8_t* out_e = STORE_ALL ? layers + layer_off(m, m - 4) : (REG_ONLY ? A.last_out + blockIdx.z * A.bstride : nullptr);
     const size_t leaf0 = (size_t)gbase + 16u * g;
     uint32_t hprev[8], hdprev[8];
 #pragma unroll 1
@@ -486,8 +487,8 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_last_tree_kernel(NttTreeArgs 
 #pragma unroll
                 for (int w = 0; w < 8; w++) mm[w] = hdprev[w], mm[8 + w] = hd[w];
                 b2_merkle_block(mm, he);
-                if (STORE_ALL) store_hash(out_e, l0 >> 4, he);
-                lds_put(RC, 256 + 4, g, he);
+                if (STORE_ALL || REG_ONLY) store_hash(out_e, l0 >> 4, he);
+                if (!REG_ONLY) lds_put(RC, 256 + 4, g, he);
             }
         }
         // the next four leaves move to the front of the arrays (static indices only)
@@ -497,6 +498,7 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_last_tree_kernel(NttTreeArgs 
             for (int r = 0; r < 12; r++) v[c][r] = v[c][r + 4];
         }
     }
+    if (REG_ONLY) return;
     __syncthreads();
     // ---- levels n - 5 and n - 6 through LDS (as tree5r) ----
     const size_t wg_e = (size_t)gbase >> 4;  // index of this workgroup's first node at level n - 4
@@ -543,7 +545,7 @@ void circle_evaluate(const Launch& L_, const uint32_t* d_coef, size_t coef_strid
     (void)circle_evaluate_into_tree(L_, d_coef, coef_stride, ncols, L, n, d_tw, ds, d_out, out_stride, nullptr);
 }
 
-bool circle_evaluate_into_tree(const Launch& L_, const uint32_t* d_coef, size_t coef_stride, uint32_t ncols, uint32_t L, uint32_t n,
+uint32_t circle_evaluate_into_tree(const Launch& L_, const uint32_t* d_coef, size_t coef_stride, uint32_t ncols, uint32_t L, uint32_t n,
                                const uint32_t* d_tw, DomainScalars ds, uint32_t* d_out, size_t out_stride, const EncodeTreeSink* sink) {
     const size_t N = (size_t)1 << n;
     hipStream_t s = L_.stream;
@@ -554,7 +556,7 @@ bool circle_evaluate_into_tree(const Launch& L_, const uint32_t* d_coef, size_t 
         Scope scope(L_, "ntt_broadcast", enc_bytes);
         dim3 grid((unsigned)((N + 255) / 256), ncols, L_.batch);
         ntt_broadcast_kernel<<<grid, 256, 0, s>>>(d_coef, coef_stride, d_out, out_stride, N, L_.bstride / 4);
-        return false;
+        return 0;
     }
     // columns per workgroup: the largest divisor of ncols that is <= 4 (the 4 coordinate columns share every twiddle)
     static const uint32_t cpw_max = [] {
@@ -590,7 +592,7 @@ bool circle_evaluate_into_tree(const Launch& L_, const uint32_t* d_coef, size_t 
     uint32_t cpw4 = MAX_COLS_PER_WG;
     while (ncols % cpw4) cpw4--;
     // one pass over layers a.i_hi .. a.i_lo
-    bool fused = false;
+    uint32_t fused_levels = 0;
     auto launch_pass = [&](uint32_t t, const char* name) {
         const bool aligned = ((a.in_stride | a.out_stride) & 3) == 0 && (a.in_mask & 3u) == 3u &&
                              ((reinterpret_cast<uintptr_t>(a.in) | reinterpret_cast<uintptr_t>(a.out) | L_.bstride) & 15) == 0;
@@ -603,15 +605,21 @@ bool circle_evaluate_into_tree(const Launch& L_, const uint32_t* d_coef, size_t 
             ta.last_out = sink->last_out;
             ta.bstride = L_.bstride;
             // algorithmic bytes: this pass's share of the encode + leaves (16 B in, 32 B out) + 6 node levels (96 B per node)
+            static const bool reg_only = getenv("FRIEDA_NTT_TREE_REG_ONLY") != nullptr;  // A/B knob
+            const uint32_t levels = reg_only ? 5u : ENCODE_TREE_LEVELS;
             double bytes = enc_bytes / (n_mid + 1) + 48.0 * (double)N;
-            for (uint32_t l = 1; l <= 6; l++) bytes += 96.0 * (double)(N >> l);
-            Scope scope(L_, "ntt_last_tree7", bytes);
+            for (uint32_t l = 1; l < levels; l++) bytes += 96.0 * (double)(N >> l);
+            Scope scope(L_, reg_only ? "ntt_last_tree5" : "ntt_last_tree7", bytes);
             const dim3 grid((unsigned)(N >> TILE_LOG), 1, L_.batch);
-            if (sink->layers)
+            if (sink->layers && reg_only)
+                ntt_last_tree_kernel<true, true><<<grid, NTT_THREADS, 0, s>>>(ta);
+            else if (sink->layers)
                 ntt_last_tree_kernel<true><<<grid, NTT_THREADS, 0, s>>>(ta);
+            else if (reg_only)
+                ntt_last_tree_kernel<false, true><<<grid, NTT_THREADS, 0, s>>>(ta);
             else
                 ntt_last_tree_kernel<false><<<grid, NTT_THREADS, 0, s>>>(ta);
-            fused = true;
+            fused_levels = levels;
             return;
         }
         Scope scope(L_, name, enc_bytes / (n_mid + 1));
@@ -648,7 +656,7 @@ bool circle_evaluate_into_tree(const Launch& L_, const uint32_t* d_coef, size_t 
     a.i_lo = 0;
     a.log_w = 0;
     launch_pass(last_t, "ntt_pass_last");
-    return fused;
+    return fused_levels;
 }
 
 }  // namespace k

@@ -183,7 +183,10 @@ __global__ __launch_bounds__(T5_THREADS) void tree5_kernel(TreeArgs a) {
 // their grandparent — seven compressions — without LDS or a barrier; inputs are one 16-byte load per column (or two for a
 // fold).  Only the 256 grandparents of the workgroup go through LDS for the last two levels (128 and 64 nodes), so a workgroup
 // needs 12 KB instead of 48 KB of LDS and the CU holds eight of them: while one is in its narrow levels the others fill the VALU.
-template <int MODE>
+// REG_ONLY: the three register levels alone (1024, 512, 256 nodes per workgroup; no LDS, no barrier).  The workgroups of a launch
+// start together and stay in step, so the two LDS levels — half, then a quarter of the waves busy — are phases in which the
+// whole chip runs at 50 % / 25 %; leaving them to the next (eight times smaller) launch keeps the big launch at full rate.
+template <int MODE, bool REG_ONLY = false>
 __global__ __launch_bounds__(T5_THREADS) void tree5r_kernel(TreeArgs a) {
     __shared__ __attribute__((aligned(16))) uint32_t RC[8 * (256 + 4)];
     __shared__ __attribute__((aligned(16))) uint32_t RD[8 * (128 + 4)];
@@ -193,7 +196,7 @@ __global__ __launch_bounds__(T5_THREADS) void tree5r_kernel(TreeArgs a) {
     const size_t g0 = wg_base + 4 * t;
     uint8_t* out_a = a.store_all && !a.skip_a ? a.layers + layer_off(a.tree_log, a.level_a) : nullptr;
     uint8_t* out_b = a.store_all ? a.layers + layer_off(a.tree_log, a.level_a - 1) : nullptr;
-    uint8_t* out_c = a.store_all ? a.layers + layer_off(a.tree_log, a.level_a - 2) : nullptr;
+    uint8_t* out_c = a.store_all ? a.layers + layer_off(a.tree_log, a.level_a - 2) : (REG_ONLY ? a.last_out : nullptr);
     uint8_t* out_d = a.store_all ? a.layers + layer_off(a.tree_log, a.level_a - 3) : nullptr;
     uint8_t* out_e = a.store_all ? a.layers + layer_off(a.tree_log, a.level_a - 4) : a.last_out;
 
@@ -275,6 +278,7 @@ __global__ __launch_bounds__(T5_THREADS) void tree5r_kernel(TreeArgs a) {
         b2_merkle_block(m, hc);
     }
     if (out_c) store_hash(out_c, g0 >> 2, hc);
+    if (REG_ONLY) return;
     lds_put(RC, 256 + 4, t, hc);
     __syncthreads();
     if (t < 128) {
@@ -977,7 +981,7 @@ __global__ __launch_bounds__(256) void grind_dev_kernel(GrindArgs a) {
 //   T_NINE   tree9, 256-node workgroups, nine levels: 2^8 .. 2^17 nodes per blob — a latency chain, fewest launches
 //   T_SMALL  tree5<256>, 256-node workgroups, five levels: everything else (unaligned Level B buffers; < 2^8 nodes: a partial
 //            workgroup)
-enum TreeKernel { T_WIDE, T_NINE, T_SMALL };
+enum TreeKernel { T_WIDE, T_WIDE3, T_NINE, T_SMALL };
 constexpr uint32_t T9_MIN_LOG = 8;
 uint32_t env_knob(const char* name, uint32_t dflt, uint32_t lo, uint32_t hi) {
     const char* e = getenv(name);
@@ -986,12 +990,15 @@ uint32_t env_knob(const char* name, uint32_t dflt, uint32_t lo, uint32_t hi) {
 }
 // tuning knobs (defaults = measured best): largest level-A size of the nine-level kernel; largest hand-over size of the top kernel
 const uint32_t T5_WIDE_LOG = env_knob("FRIEDA_T5_WIDE_LOG", 18, 16, 24);  // smallest launch (nodes) of the register-subtree kernel
+// smallest launch (level-A nodes) whose leaf / fold kernel stops after its three register levels (0 = never)
+const uint32_t T5_REG3_LOG = env_knob("FRIEDA_T5_REG3_LOG", 0, 0, 30);
 const uint32_t T9_MAX_LOG = env_knob("FRIEDA_T9_MAX_LOG", 17, 8, 19);
 const uint32_t TOP_MAX_LOG = env_knob("FRIEDA_TOP_MAX_LOG", 9, 9, 11);
 
-TreeKernel tree_kernel_for(uint32_t level_a, uint32_t batch, bool aligned16) {
+TreeKernel tree_kernel_for(uint32_t level_a, uint32_t batch, bool aligned16, bool reg3_ok = false) {
     uint32_t batch_log = 0;
     while ((2u << batch_log) <= batch) batch_log++;
+    if (reg3_ok && aligned16 && T5_REG3_LOG && level_a >= 10 && level_a + batch_log >= T5_REG3_LOG) return T_WIDE3;
     // the register-subtree kernel uses 16-byte column accesses; anything unaligned (Level B callers may pass any pointers)
     // takes a 256-unit kernel, which produces the same hashes
     if (aligned16 && level_a >= 10 && level_a + batch_log >= T5_WIDE_LOG) return T_WIDE;
@@ -1000,6 +1007,7 @@ TreeKernel tree_kernel_for(uint32_t level_a, uint32_t batch, bool aligned16) {
 }
 uint32_t tree_kernel_levels(TreeKernel k, uint32_t level_a) {
     if (k == T_NINE) return T9_LEVELS;
+    if (k == T_WIDE3) return 3;
     const uint32_t in_wg = level_a < (k == T_WIDE ? 10u : 8u) ? level_a : (k == T_WIDE ? 10u : 8u);  // log2 of a workgroup's A nodes
     return in_wg + 1 < T5_LEVELS ? in_wg + 1 : T5_LEVELS;
 }
@@ -1011,9 +1019,10 @@ bool tree_args_aligned16(const TreeArgs& a) {
 // launches level A (+ the levels its kernel yields) and returns the number of levels produced
 uint32_t launch_tree_a(const Launch& L, int mode, const TreeArgs& a, const char* name, double (*bytes_of)(int, uint32_t, uint32_t)) {
     const size_t total = (size_t)1 << a.level_a;
-    const TreeKernel k = tree_kernel_for(a.level_a, L.batch, tree_args_aligned16(a));
+    // the three-level form only where every level is kept (its last level is four times what the root-only scratch holds)
+    const TreeKernel k = tree_kernel_for(a.level_a, L.batch, tree_args_aligned16(a), mode != T_NODE && a.store_all);
     const uint32_t levels = tree_kernel_levels(k, a.level_a);
-    const uint32_t units = k == T_WIDE ? T5_UNITS : 256u;
+    const uint32_t units = (k == T_WIDE || k == T_WIDE3) ? T5_UNITS : 256u;
     const dim3 grid((unsigned)((total + units - 1) / units), L.batch);
     Scope scope(L, name, bytes_of(mode, a.level_a, levels));
     if (k == T_SMALL) {
@@ -1029,6 +1038,12 @@ uint32_t launch_tree_a(const Launch& L, int mode, const TreeArgs& a, const char*
             case T_NODE: tree9_kernel<T_NODE><<<grid, 256, 0, L.stream>>>(a); break;
             case T_FOLD_CIRCLE: tree9_kernel<T_FOLD_CIRCLE><<<grid, 256, 0, L.stream>>>(a); break;
             default: tree9_kernel<T_FOLD_LINE><<<grid, 256, 0, L.stream>>>(a); break;
+        }
+    } else if (k == T_WIDE3) {
+        switch (mode) {
+            case T_LEAF4: tree5r_kernel<T_LEAF4, true><<<grid, T5_THREADS, 0, L.stream>>>(a); break;
+            case T_FOLD_CIRCLE: tree5r_kernel<T_FOLD_CIRCLE, true><<<grid, T5_THREADS, 0, L.stream>>>(a); break;
+            default: tree5r_kernel<T_FOLD_LINE, true><<<grid, T5_THREADS, 0, L.stream>>>(a); break;
         }
     } else {
         switch (mode) {
@@ -1125,7 +1140,7 @@ void encode_and_first_tree(const Launch& L, const uint32_t* d_coef, size_t coef_
     uint8_t* s0 = d_scratch;
     uint8_t* s1 = d_scratch ? d_scratch + ((size_t)32 << (n > 4 ? n - 4 : 0)) : nullptr;
     EncodeTreeSink sink{d_layers, s0};
-    const bool fused = circle_evaluate_into_tree(L, d_coef, coef_stride, 4, Lc, n, d_tw, ds, d_eval, eval_stride, no_fuse ? nullptr : &sink);
+    const uint32_t fused = circle_evaluate_into_tree(L, d_coef, coef_stride, 4, Lc, n, d_tw, ds, d_eval, eval_stride, no_fuse ? nullptr : &sink);
     if (!fused) {
         TreeArgs a{};
         a.cols = d_eval;
@@ -1139,7 +1154,7 @@ void encode_and_first_tree(const Launch& L, const uint32_t* d_coef, size_t coef_
     a.layers = d_layers;
     a.store_all = d_layers != nullptr;
     a.bstride = L.bstride;
-    const uint32_t cur = n - (ENCODE_TREE_LEVELS - 1);
+    const uint32_t cur = n - (fused - 1);
     finish_tree(L, a, n, cur, d_layers ? d_layers + merkle_layer_offset(n, cur) : s0, s0, s1, d_root, tr, tr_init, tr_init_pitch);
 }
 
