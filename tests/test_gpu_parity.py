@@ -232,11 +232,28 @@ def test_commit_known_answers(gpu_ctx, blob, vec):
     assert gpu_ctx.commit(data, vec["log_blowup_factor"]).hex() == vec["root"]
 
 
-@pytest.mark.parametrize("n_bytes", [0, 1, 15, 16, 17, 58, 119, 120, 121, 300, 1023, 5000, 70001])
+# 61440 bytes = 4 * 2^12 felts exactly: L = 12, the smallest polynomial whose last transform pass runs fused with leaf hashing (and
+# the one shape where that pass reads the coefficients themselves, replicated, instead of a strided pass's output); 61441: L = 13
+@pytest.mark.parametrize("n_bytes", [0, 1, 15, 16, 17, 58, 119, 120, 121, 300, 1023, 5000, 61440, 61441, 70001])
 @pytest.mark.parametrize("B", [1, 2, 4])
 def test_commit_matches_oracle_ragged(gpu_ctx, oracle, n_bytes, B):
     data = splitmix64_bytes(21 + B, n_bytes).tobytes()
     assert gpu_ctx.commit(data, B) == oracle.commit(data, B)
+
+
+@pytest.mark.parametrize("n_bytes,B", [(61440, 1), (61440, 4), (61441, 2), (983040, 3)])
+def test_fused_encode_tree_equals_unfused_and_oracle(gpu_ctx, oracle, n_bytes, B, monkeypatch):
+    """The last transform pass fused with leaf hashing (ntt_last_tree7) against the oracle: commit root, whole proof, and every
+    stored tree level and the evaluation through the openings of 300 queries."""
+    import frieda_amd
+
+    data = splitmix64_bytes(77 + B, n_bytes).tobytes()
+    assert gpu_ctx.commit(data, B) == oracle.commit(data, B)
+    cfg = _cfg(frieda_amd, 6, B, 0, 300)
+    root, proof = gpu_ctx.commit_and_generate_proof(data, 11, cfg)
+    o_root, o_proof = oracle.commit_and_generate_proof(data, 11, oracle.make_config(6, B, 0, 300))
+    assert root == o_root and proof.serialize() == o_proof.serialize()
+    assert frieda_amd.verify(proof, 11)
 
 
 def test_commit_without_twiddle_cache(gpu_ctx, oracle):
