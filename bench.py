@@ -8,11 +8,13 @@ configuration): unpack -> 4 x circle NTT -> first Merkle tree -> every FRI fold 
 interpolation -> grind (pow_bits 20) -> 20 query openings.  value = M31 field elements committed per second =
 n_gpus * 4 * 2^n * steps / wall time, inputs already resident in HBM when the timed region starts.
 
-The K timed steps process K DISTINCT blobs per GPU (a stream of blobs, as a data-availability node sees them) with
-`--in-flight` proofs in flight (default 2: one context = stream + workspace each, so the Fiat-Shamir latency chain of one
-proof runs under the chip-filling kernels of the next).  Every one of the K timed proofs is verified after the timed region
-and the K roots must be distinct; `sequential` in the JSON line is the one-proof-at-a-time figure (`--in-flight 1` makes it
-the headline).
+The K timed steps process K DISTINCT blobs per GPU (a stream of blobs, as a data-availability node sees them), `--batch`
+consecutive blobs per call through the batched entry points (default 4: every kernel is launched once per batch, so the
+Fiat-Shamir latency chain is paid once per batch) with `--in-flight` calls in flight (default 2: one context = stream +
+workspace each, so that chain also runs under the chip-filling kernels of the other batch).  Results are those of K separate
+calls (tests/test_gpu_parity.py).  Every one of the K timed proofs is verified after the timed region and the K roots must be
+distinct; `sequential` in the JSON line is the one-proof-at-a-time figure (`--batch 1 --in-flight 1` makes it the headline;
+`--batch 1` is two single proofs in flight).
 
 Multi-GPU: one process per GPU (torch.distributed, backend nccl = RCCL), independent blobs sharded one per rank (weak
 scaling); nothing is exchanged while blobs are processed — every rank keeps the roots of its K blobs and the ranks exchange
@@ -217,7 +219,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-twiddle-cache", action="store_true", help="regenerate twiddles every call, as the reference does")
     ap.add_argument("--batch-extra", type=int, default=4, help="blobs per call for the extra 'batched' figure (0 = skip)")
     ap.add_argument("--in-flight", type=int, default=2,
-                    help="proofs in flight in the measured loop (one context each); 1 = one proof at a time")
+                    help="proofs (or batches) in flight in the measured loop (one context each); 1 = one at a time")
+    ap.add_argument("--batch", type=int, default=4,
+                    help="blobs per call in the measured loop: > 1 uses the batched entry points (every kernel launched once per batch); 1 = one blob per call")
     ap.add_argument("--pipeline-depth", type=int, default=None, help="deprecated alias: 0 means --in-flight 1")
     ap.add_argument("--sequential-extra", type=int, default=20, help="proofs for the extra one-at-a-time figure (0 = skip)")
     ap.add_argument("--dry-collective", choices=["gloo"], default=None,
@@ -364,9 +368,14 @@ def main():
     blob_len = blob_len_for(n)
     K = args.steps
     D = max(1, args.in_flight) if args.workload == "prove" else 1
+    BSZ = max(1, args.batch) if args.workload == "prove" else 1
     # K DISTINCT blobs per rank, resident in HBM before the timed region (generator: splitmix64, seeds 100 + rank * K + i; the
-    # first blob of rank 0 is the seed-100 blob the CPU baseline proves, so the two roots can be compared)
-    blobs = [torch.from_numpy(splitmix64_bytes(100 + rank * K + i, blob_len)).cuda() for i in range(K)]
+    # first blob of rank 0 is the seed-100 blob the CPU baseline proves, so the two roots can be compared).  One contiguous
+    # [K, blob_len] array: a batch is `batch` consecutive rows.
+    all_blobs = torch.empty((K, blob_len), dtype=torch.uint8, device="cuda")
+    for i in range(K):
+        all_blobs[i].copy_(torch.from_numpy(splitmix64_bytes(100 + rank * K + i, blob_len)))
+    blobs = [all_blobs[i] for i in range(K)]
     blob = blobs[0]
     stream = torch.cuda.Stream()
     ctx = frieda_amd.Context(local_rank, stream.cuda_stream)
@@ -381,7 +390,14 @@ def main():
     gathered = torch.zeros(32 * K * world, dtype=torch.uint8, device="cuda")
     # `D` proofs in flight (one context = stream + workspace each): the Fiat-Shamir latency chain of one proof runs under the
     # chip-filling kernels of the next.  D = 1 is one proof at a time.
-    pipe = frieda_amd.ProofPipeline(local_rank, D) if args.workload == "prove" else None
+    # `batch` > 1: the measured loop hands `batch` consecutive blobs to the batched entry points (every kernel launched once per
+    # batch: the chain is paid once per batch), `D` batches in flight.
+    if args.workload != "prove":
+        pipe = None
+    elif BSZ > 1:
+        pipe = frieda_amd.BatchPipeline(local_rank, D)
+    else:
+        pipe = frieda_amd.ProofPipeline(local_rank, D)
     if pipe is not None and args.no_twiddle_cache:
         for c in pipe.ctxs:
             c.set_twiddle_cache(False)
@@ -400,10 +416,17 @@ def main():
                 step(i)
             return []
         out = []
-        for i in range(n_blobs):
-            r = pipe.submit_device(blobs[i].data_ptr(), blob_len, seed, cfg)
-            if r is not None:
-                out.append(r)
+        if BSZ > 1:
+            for i in range(0, n_blobs, BSZ):
+                cnt = min(BSZ, n_blobs - i)
+                r = pipe.submit_device(blobs[i].data_ptr(), blob_len, blob_len, cnt, [seed] * cnt, cfg)
+                if r is not None:
+                    out.extend(r)
+        else:
+            for i in range(n_blobs):
+                r = pipe.submit_device(blobs[i].data_ptr(), blob_len, seed, cfg)
+                if r is not None:
+                    out.append(r)
         out.extend(pipe.drain())
         return out
 
@@ -429,7 +452,7 @@ def main():
     # code objects; the chip also needs a few milliseconds of load before it settles on its clock
     for _ in range(2):
         step()
-    run_stream(min(K, 2 * D))
+    run_stream(min(K, 2 * D * BSZ))
     torch.cuda.synchronize()
     W = args.warmup
     while W > 0:  # W untimed warm-up steps through the measured loop itself
@@ -549,6 +572,25 @@ def main():
             "note": "`batch` blobs of the same size per call through the batched entry point; not the headline value",
         }
         del res
+        # the same with two batches in flight (two contexts alternating begin / finish): chain hidden AND paid once per batch
+        bctx2 = frieda_amd.Context(local_rank)
+        ctxs2 = [bctx, bctx2]
+        bctx2.prove_batch_begin_device(many.data_ptr(), blob_len, blob_len, bsz, bseeds, cfg)
+        bctx2.prove_batch_finish(bsz)  # sizes the second workspace
+        torch.cuda.synchronize()
+        tb0 = time.perf_counter()
+        ctxs2[0].prove_batch_begin_device(many.data_ptr(), blob_len, blob_len, bsz, bseeds, cfg)
+        for i in range(1, reps):
+            ctxs2[i & 1].prove_batch_begin_device(many.data_ptr(), blob_len, blob_len, bsz, bseeds, cfg)
+            res = ctxs2[(i - 1) & 1].prove_batch_finish(bsz)
+        res = ctxs2[(reps - 1) & 1].prove_batch_finish(bsz)
+        torch.cuda.synchronize()
+        dtb2 = (time.perf_counter() - tb0) / (reps * bsz)
+        assert all(r == root for r, _ in res) and res[-1][1].serialize() == proof0_image
+        batched["two_batches_in_flight"] = {"ms_per_proof": 1e3 * dtb2, "value": elems / dtb2,
+                                            "frac_of_hbm_peak": algorithmic_bytes(n, "prove") / dtb2 / 1e9 / HBM_PEAK_GBS}
+        del res
+        bctx2.close()
         bctx.close()
 
     # ---- extra figure: twiddles regenerated on every call, as the reference does (src/commit.rs:15, src/proof.rs:47) ----
@@ -614,6 +656,9 @@ def main():
             "parallelism": f"{world} independent blobs per step, one per GPU; one all_gather of the K x 32-byte roots per rank after the last step",
             "blobs": f"{K} distinct blobs per GPU (splitmix64 seeds 100 + rank * K + i), resident in HBM; every timed proof verified after the timed region" if args.workload == "prove" else f"{K} distinct blobs per GPU",
             "in_flight": D,
+            "batch": BSZ,
+            "measured_loop": (f"{BSZ} consecutive blobs per call (frieda_prove_batch_begin_device / _finish), {D} calls in flight" if BSZ > 1 else
+                              f"one blob per call (frieda_prove_begin_device / _finish), {D} in flight") if args.workload == "prove" else "commit_device per blob, asynchronous",
             "twiddles": "regenerated per call" if args.no_twiddle_cache else "cached per context",
         },
         "roofline": roofline,
@@ -638,7 +683,7 @@ def main():
         "root": root.hex() if root else None,
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cb = cpu_baseline(args.cpu_sample_log, args.workload, 2 if args.cpu_sample_log <= 22 else 1)
+        cb = cpu_baseline(args.cpu_sample_log, args.workload, 2 if args.cpu_sample_log <= 22 else 1, all_cores_log=min(22, args.cpu_sample_log))
         if args.cpu_sample_log == n:  # the very same blob and configuration: the CPU root must be the GPU root
             assert cb["root"] == out["root"], "CPU baseline root differs from the GPU root"
             cb["root_equals_gpu_root"] = True

@@ -4,6 +4,7 @@ The package holds only what that path needs: `csrc/` (hand-written gfx950 kernel
 built into `lib/libfrieda_hip.so`) and this thin host-side mirror of the reference interface.
 """
 from .api import (  # noqa: F401
+    BatchPipeline,
     Context,
     FriConfig,
     FriedaError,
@@ -20,6 +21,7 @@ from .api import (  # noqa: F401
 )
 
 __all__ = [
+    "BatchPipeline",
     "Context",
     "FriConfig",
     "FriedaError",

@@ -487,6 +487,41 @@ class ProofPipeline:
             c.close()
 
 
+class BatchPipeline:
+    """ProofPipeline for batches: up to `depth` batches of equal-length blobs in flight on one GPU (frieda_prove_batch_begin_device /
+    _finish on one Context each).  The Fiat-Shamir chain is paid once per batch AND runs under the other batch's wide kernels —
+    the highest-throughput way through a stream of blobs.  submit returns the oldest finished batch's [(commitment, proof)] or None."""
+
+    def __init__(self, device=0, depth=2):
+        self.ctxs = [Context(device) for _ in range(depth)]
+        self.inflight = []  # (ctx, count), oldest first
+        self.free = list(self.ctxs)
+
+    def submit_device(self, d_ptr, stride, length, count, seeds, pcs_config):
+        done = None
+        if not self.free:
+            ctx, cnt = self.inflight.pop(0)
+            done = ctx.prove_batch_finish(cnt)
+            self.free.append(ctx)
+        ctx = self.free.pop(0)
+        ctx.prove_batch_begin_device(d_ptr, stride, length, count, seeds, pcs_config)
+        self.inflight.append((ctx, count))
+        return done
+
+    def drain(self):
+        out = []
+        while self.inflight:
+            ctx, cnt = self.inflight.pop(0)
+            out.extend(ctx.prove_batch_finish(cnt))
+            self.free.append(ctx)
+        return out
+
+    def close(self):
+        self.drain()
+        for c in self.ctxs:
+            c.close()
+
+
 # ---- module-level API with an implicit per-thread default context (frieda's free functions) ----
 _tls = threading.local()
 

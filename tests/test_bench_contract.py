@@ -1,0 +1,51 @@
+"""GPU: bench.py's JSON contract on a small domain (the driver runs bench.py at round end: a broken line is a lost measurement)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+REQUIRED = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+            "config", "roofline", "cpu_baseline"]
+
+
+def _bench(argv, env_extra=None):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(env_extra or {})
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + argv, capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]  # ONE JSON line on stdout, nothing else
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("extra", [[], ["--batch", "1"], ["--batch", "1", "--in-flight", "1"], ["--workload", "commit"], ["--no-twiddle-cache"]],
+                         ids=["default", "single_in_flight2", "one_at_a_time", "commit", "uncached"])
+def test_bench_line_small_domain(extra):
+    d = _bench(["--log-domain", "16", "--cpu-sample-log", "16", "--steps", "9", "--warmup", "2"] + extra)
+    for k in REQUIRED:
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 9 and d["warmup"] == 2 and d["higher_is_better"] is True and d["scaling"] == "weak"
+    assert d["vs_baseline"] is None and d["dtype"] == "u32" and d["data"] == "synthetic"
+    assert d["value"] > 0 and abs(d["value"] - 4.0 * (1 << 16) * 9 / (d["ms_per_step"] * 9e-3)) / d["value"] < 1e-6
+    rf = d["roofline"]
+    assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and rf["unit"] == "GB/s" and 0 < rf["frac"] < 1 and "traffic" in rf and rf["traffic_source"]
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0 and cb["root_equals_gpu_root"] is True
+    assert cb["all_cores"]["cores"] >= 1 and cb["all_cores"]["value"] > 0
+    assert len(cb["reference_bench_sizes"]) == 5 and all(r["roots_equal"] and r["proofs_equal"] for r in cb["reference_bench_sizes"])
+    if "commit" not in extra:
+        assert d["verified_proofs"] == 9
+        assert "commit_and_generate_proof" in d["config"]["workload"]
+
+
+def test_bench_forced_collective_one_rank():
+    """RCCL init, root all_gather, barrier and max-reduce with a single rank: the N > 1 code path on a one-GPU box."""
+    d = _bench(["--gpus", "1", "--log-domain", "16", "--steps", "6", "--warmup", "1", "--no-cpu-baseline", "--batch-extra", "0", "--sequential-extra", "0"],
+               env_extra={"FRIEDA_BENCH_FORCE_DIST": "1"})
+    assert d["n_gpus"] == 1 and d["verified_proofs"] == 6 and d["cpu_baseline"] is None
