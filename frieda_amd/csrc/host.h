@@ -151,11 +151,13 @@ int prove_finish(Ctx* ctx, uint8_t out_commitment[32], ProofData& out);
 // commit phase processes all blobs in one launch (Fiat-Shamir and launch latency are paid once per batch).  Needs the device
 // channel (last layer <= 2^11 points).  prove_finish_batch writes count * 32 bytes of commitments.
 int prove_begin_batch(Ctx* ctx, const uint8_t* data, size_t data_stride, size_t len, uint32_t count, bool data_on_device,
-                      const uint64_t* seeds, frieda_pcs_config cfg);
+                      const uint64_t* seeds, frieda_pcs_config cfg, const uint8_t* const* host_ptrs = nullptr);
+// `count` separate host blobs of one length
+int prove_begin_batch_ptrs(Ctx* ctx, const uint8_t* const* blobs, size_t len, uint32_t count, const uint64_t* seeds, frieda_pcs_config cfg);
 int prove_finish_batch(Ctx* ctx, uint8_t* out_commitments, std::vector<ProofData>& outs);
 uint32_t job_count(const Ctx* ctx);  // blobs of the job in flight (0: none)
 int commit_batch(Ctx* ctx, const uint8_t* data, size_t data_stride, size_t len, uint32_t count, bool data_on_device, uint32_t log_blowup,
-                 uint8_t* out_roots);
+                 uint8_t* out_roots, const uint8_t* const* host_ptrs = nullptr);
 // returns FRIEDA_OK with *ok set, or FRIEDA_ERR_INVARIANT where the reference panics
 int verify(const ProofData& proof, const uint64_t* seed, int* ok);
 

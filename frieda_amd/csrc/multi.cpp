@@ -3,7 +3,8 @@
 // What it replaces: a caller looping `api::commit` / `proof::commit_and_generate_proof` over blobs
 // (/root/reference/src/lib.rs:31-38; the bench loops of benches/commit.rs:11-15, benches/proof.rs:30-44).  The blobs are
 // independent, so the path shards at blob granularity: blob i -> device i mod n, one host thread and two
-// contexts per device (two proofs in flight: the latency chain of one runs under the wide kernels of the other), no data-path
+// contexts per device (two calls in flight: the latency chain of one runs under the wide kernels of the other; runs of
+// equal-length blobs go through the batched kernels MULTI_UNIT at a time, so the chain is also paid once per unit), no data-path
 // collective.  The only exchange is the gather of the 32-byte commitment roots: one `ncclAllGather` per device on a
 // single-process communicator (`ncclCommInitAll`) — RCCL over xGMI — after which every device holds every root (slot layout:
 // rank-major, blob i at rank i mod n, slot i div n); the host reads device 0's copy.  With one device there is nothing to
@@ -72,6 +73,8 @@ struct RcclApi {
 };
 
 }  // namespace
+
+constexpr uint32_t MULTI_UNIT = 4;  // equal-length blobs handed to a device per call (the batched kernels)
 
 struct frieda_multi {
     std::vector<int> devices;
@@ -252,14 +255,26 @@ int frieda_commit_many(frieda_multi* m, const uint8_t* const* blobs, const size_
             workers.emplace_back([&, d] {
                 frieda_ctx* c = m->ctx[2 * d];
                 try {
-                    size_t slot = 0;
-                    for (uint32_t i = (uint32_t)d; i < count && !abort.load(); i += (uint32_t)n, slot++) {
-                        const int rc = commit_host(&c->c, blobs[i], lens[i], log_blowup_factor, local[d][slot].data());
+                    // this device's blobs in order; runs of equal length go through the batched kernels, up to UNIT at a time
+                    const uint32_t mine = (uint32_t)local[d].size();
+                    for (uint32_t slot = 0; slot < mine && !abort.load();) {
+                        const uint32_t i0 = (uint32_t)d + slot * (uint32_t)n;
+                        uint32_t cnt = 1;
+                        while (cnt < MULTI_UNIT && slot + cnt < mine && lens[i0 + cnt * n] == lens[i0]) cnt++;
+                        int rc;
+                        if (cnt == 1) {
+                            rc = commit_host(&c->c, blobs[i0], lens[i0], log_blowup_factor, local[d][slot].data());
+                        } else {
+                            const uint8_t* ptrs[MULTI_UNIT];
+                            for (uint32_t k = 0; k < cnt; k++) ptrs[k] = blobs[i0 + k * n];
+                            rc = commit_batch(&c->c, ptrs[0], lens[i0], lens[i0], cnt, false, log_blowup_factor, local[d][slot].data(), ptrs);
+                        }
                         if (rc != FRIEDA_OK) {
                             status[d] = rc;
                             abort.store(true);
                             return;
                         }
+                        slot += cnt;
                     }
                 } catch (...) {  // nothing may unwind out of a worker thread
                     c->c.err = "host allocation failed";
@@ -299,45 +314,79 @@ int frieda_prove_many(frieda_multi* m, const uint8_t* const* blobs, const size_t
             local[d].resize((count + n - 1 - d) / n);
             workers.emplace_back([&, d] {
               try {
-                // two proofs in flight on this device: begin(k + 1) is enqueued before finish(k) waits
+                // This device's blobs in order, cut into units: a run of up to MULTI_UNIT blobs of one length is one call of the
+                // batched kernels (the Fiat-Shamir chain is paid once per unit), anything else a single proof.  Two units in
+                // flight: begin(u + 1) is enqueued on the other context before finish(u) waits.
                 frieda_ctx* cx[2] = {m->ctx[2 * d], m->ctx[2 * d + 1]};
                 const uint32_t mine = (uint32_t)local[d].size();
-                auto blob_of = [&](uint32_t slot) { return (uint32_t)d + slot * (uint32_t)n; };
-                auto begin = [&](uint32_t slot) {
-                    const uint32_t i = blob_of(slot);
-                    return prove_begin(&cx[slot & 1]->c, blobs[i], lens[i], false, seeds ? &seeds[i] : nullptr, cfg);
+                if (mine == 0) return;
+                const bool batchable = cfg.log_last_layer_degree_bound <= 11 && cfg.log_blowup_factor <= 11 &&
+                                       cfg.log_last_layer_degree_bound + cfg.log_blowup_factor <= 11;  // the device transcript (prover.cpp)
+                struct Unit {
+                    uint32_t slot, cnt;
+                };
+                std::vector<Unit> units;
+                for (uint32_t slot = 0; slot < mine;) {
+                    const uint32_t i0 = (uint32_t)d + slot * (uint32_t)n;
+                    uint32_t cnt = 1;
+                    while (batchable && cnt < MULTI_UNIT && slot + cnt < mine && lens[i0 + cnt * n] == lens[i0]) cnt++;
+                    units.push_back(Unit{slot, cnt});
+                    slot += cnt;
+                }
+                auto begin = [&](size_t u) {
+                    const Unit& un = units[u];
+                    const uint32_t i0 = (uint32_t)d + un.slot * (uint32_t)n;
+                    Ctx* c = &cx[u & 1]->c;
+                    if (un.cnt == 1) return prove_begin(c, blobs[i0], lens[i0], false, seeds ? &seeds[i0] : nullptr, cfg);
+                    const uint8_t* ptrs[MULTI_UNIT];
+                    uint64_t sd[MULTI_UNIT];
+                    for (uint32_t k = 0; k < un.cnt; k++) {
+                        ptrs[k] = blobs[i0 + k * n];
+                        sd[k] = seeds ? seeds[i0 + k * n] : 0;
+                    }
+                    return prove_begin_batch_ptrs(c, ptrs, lens[i0], un.cnt, seeds ? sd : nullptr, cfg);
+                };
+                auto finish = [&](size_t u) {  // -> status; fills local roots and out_proofs of the unit
+                    const Unit& un = units[u];
+                    frieda_ctx* c = cx[u & 1];
+                    std::vector<frieda_proof*> objs(un.cnt, nullptr);
+                    std::vector<ProofData> outs(un.cnt);
+                    for (uint32_t k = 0; k < un.cnt; k++) {
+                        objs[k] = c->pool->get();
+                        objs[k]->home = c->pool;
+                        outs[k] = std::move(objs[k]->p);
+                    }
+                    const int rf = prove_finish_batch(&c->c, local[d][un.slot].data(), outs);
+                    for (uint32_t k = 0; k < un.cnt; k++) {
+                        if (k < outs.size()) objs[k]->p = std::move(outs[k]);
+                        if (rf != FRIEDA_OK)
+                            c->pool->put(objs[k]);
+                        else
+                            out_proofs[(uint32_t)d + (un.slot + k) * (uint32_t)n] = objs[k];
+                    }
+                    return rf;
                 };
                 auto bail = [&](int rc, frieda_ctx* c) {
                     status[d] = rc;
                     what[d] = c->c.err;
                     abort.store(true);
                 };
-                if (mine == 0) return;
                 int rc = begin(0);
                 if (rc != FRIEDA_OK) return bail(rc, cx[0]);
-                for (uint32_t slot = 0; slot < mine; slot++) {
+                for (size_t u = 0; u < units.size(); u++) {
                     bool next_begun = false;
-                    if (slot + 1 < mine && !abort.load()) {
-                        rc = begin(slot + 1);
-                        if (rc != FRIEDA_OK) bail(rc, cx[(slot + 1) & 1]);
+                    if (u + 1 < units.size() && !abort.load()) {
+                        rc = begin(u + 1);
+                        if (rc != FRIEDA_OK) bail(rc, cx[(u + 1) & 1]);
                         next_begun = rc == FRIEDA_OK;
                     }
-                    frieda_ctx* c = cx[slot & 1];
-                    frieda_proof* p = c->pool->get();
-                    p->home = c->pool;
-                    const int rf = prove_finish(&c->c, local[d][slot].data(), p->p);
-                    if (rf != FRIEDA_OK) {
-                        c->pool->put(p);
-                        if (status[d] == FRIEDA_OK) bail(rf, c);
-                    } else {
-                        out_proofs[blob_of(slot)] = p;
-                    }
+                    const int rf = finish(u);
+                    if (rf != FRIEDA_OK && status[d] == FRIEDA_OK) bail(rf, cx[u & 1]);
                     if (status[d] != FRIEDA_OK || abort.load()) {
-                        if (next_begun) {  // drain the proof already enqueued so that the context is reusable
-                            frieda_ctx* c2 = cx[(slot + 1) & 1];
-                            ProofData scratch;
-                            uint8_t r[32];
-                            (void)prove_finish(&c2->c, r, scratch);
+                        if (next_begun) {  // drain the unit already enqueued so that the context is reusable
+                            std::vector<ProofData> scratch(units[u + 1].cnt);
+                            std::vector<uint8_t> r(32 * (size_t)units[u + 1].cnt);
+                            (void)prove_finish_batch(&cx[(u + 1) & 1]->c, r.data(), scratch);
                         }
                         return;
                     }

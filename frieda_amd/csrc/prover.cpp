@@ -162,7 +162,7 @@ int commit_host(Ctx* ctx, const uint8_t* data, size_t len, uint32_t log_blowup, 
 
 // commit() of `count` blobs of one length in one pass of launches (blob b at data + b * data_stride); roots to host memory
 int commit_batch(Ctx* ctx, const uint8_t* data, size_t data_stride, size_t len, uint32_t count, bool data_on_device, uint32_t log_blowup,
-                 uint8_t* out_roots) {
+                 uint8_t* out_roots, const uint8_t* const* host_ptrs) {
     FR_NO_JOB(ctx);
     if (count == 0 || count > 65535) return ctx->fail(FRIEDA_ERR_ARG, "batch count out of range");
     if (count > 1 && data_stride < len) return ctx->fail(FRIEDA_ERR_ARG, "batch stride smaller than the blob length");
@@ -192,7 +192,11 @@ int commit_batch(Ctx* ctx, const uint8_t* data, size_t data_stride, size_t len, 
     const uint8_t* d_data = data;
     size_t d_stride = data_stride;
     if (!data_on_device) {
-        if (len) FR_HIP(ctx, hipMemcpy2DAsync(A + o_data, bstride, data, count > 1 ? data_stride : len, len, count, hipMemcpyHostToDevice, s));
+        if (len && host_ptrs) {  // separate host blobs of one length (frieda_commit_many)
+            for (uint32_t b = 0; b < count; b++) FR_HIP(ctx, hipMemcpyAsync(A + o_data + (size_t)b * bstride, host_ptrs[b], len, hipMemcpyHostToDevice, s));
+        } else if (len) {
+            FR_HIP(ctx, hipMemcpy2DAsync(A + o_data, bstride, data, count > 1 ? data_stride : len, len, count, hipMemcpyHostToDevice, s));
+        }
         d_data = A + o_data;
         d_stride = bstride;
     }
@@ -366,9 +370,15 @@ int prove_begin(Ctx* ctx, const uint8_t* data, size_t len, bool data_on_device, 
     return prove_begin_batch(ctx, data, 0, len, 1, data_on_device, seed, cfg);
 }
 
-// `count` blobs of `len` bytes each, blob b at data + b * data_stride; seeds: null or one per blob
+// the same for `count` separate HOST blobs of one length (blob b at blobs[b]): what frieda_prove_many hands a device
+int prove_begin_batch_ptrs(Ctx* ctx, const uint8_t* const* blobs, size_t len, uint32_t count, const uint64_t* seeds, frieda_pcs_config cfg) {
+    if (!blobs || count == 0) return ctx->fail(FRIEDA_ERR_ARG, "null blob table");
+    return prove_begin_batch(ctx, blobs[0], len, len, count, false, seeds, cfg, blobs);
+}
+
+// `count` blobs of `len` bytes each, blob b at data + b * data_stride (or, host blobs only, at host_ptrs[b]); seeds: null or one per blob
 int prove_begin_batch(Ctx* ctx, const uint8_t* data, size_t data_stride, size_t len, uint32_t count, bool data_on_device,
-                      const uint64_t* seeds, frieda_pcs_config cfg) {
+                      const uint64_t* seeds, frieda_pcs_config cfg, const uint8_t* const* host_ptrs) {
     const auto t_entry = std::chrono::steady_clock::now();
     if (ctx->job) return ctx->fail(FRIEDA_ERR_ARG, "a proof is already in flight on this context");
     if (count == 0 || count > 65535) return ctx->fail(FRIEDA_ERR_ARG, "batch count out of range");
@@ -463,8 +473,12 @@ int prove_begin_batch(Ctx* ctx, const uint8_t* data, size_t data_stride, size_t 
     const uint8_t* d_data = data;
     size_t d_data_stride = data_stride;
     if (!data_on_device) {
-        if (len && count == 1) FR_HIP(ctx, hipMemcpyAsync(A + o_data, data, len, hipMemcpyHostToDevice, s));
-        if (len && count > 1) FR_HIP(ctx, hipMemcpy2DAsync(A + o_data, bstride, data, data_stride, len, count, hipMemcpyHostToDevice, s));
+        if (len && host_ptrs) {
+            for (uint32_t b = 0; b < count; b++) FR_HIP(ctx, hipMemcpyAsync(A + o_data + (size_t)b * bstride, host_ptrs[b], len, hipMemcpyHostToDevice, s));
+        } else {
+            if (len && count == 1) FR_HIP(ctx, hipMemcpyAsync(A + o_data, data, len, hipMemcpyHostToDevice, s));
+            if (len && count > 1) FR_HIP(ctx, hipMemcpy2DAsync(A + o_data, bstride, data, data_stride, len, count, hipMemcpyHostToDevice, s));
+        }
         d_data = A + o_data;
         d_data_stride = bstride;
     }

@@ -160,7 +160,8 @@ int frieda_verify(const frieda_proof* proof, const uint64_t* seed, int* ok);
 /* ---- multi-GPU: a batch of independent blobs across the GPUs of one node ---------------------------------------------
  * What a caller looping api::commit / commit_and_generate_proof over blobs gets on an 8 x MI355X node
  * (src/lib.rs:31-38; benches/commit.rs:11-15, benches/proof.rs:30-44).  The path shards at blob granularity: blob i runs
- * on devices[i mod n], one host thread and two contexts per device (two proofs in flight), no data-path collective.  The
+ * on devices[i mod n], one host thread and two contexts per device (two calls in flight; a run of equal-length blobs on a
+ * device goes through the batched kernels four blobs per call), no data-path collective.  The
  * only exchange is the gather of the 32-byte commitment roots: one ncclAllGather per device on a single-process
  * communicator (ncclCommInitAll; RCCL over xGMI), after which every device holds every root; the host reads device 0's
  * copy.  n == 1 needs no exchange and does not touch RCCL.  RCCL is bound at frieda_multi_create by dlopen("librccl.so.1")

@@ -36,6 +36,11 @@ static int multi_mode(const std::vector<uint8_t>& blob, int n_slots) {
         for (size_t j = 0; j < d.size(); j++) d[j] = (uint8_t)(j * 29 + i * 5 + (j >> 5));
         blobs.push_back(d);
     }
+    for (int i = 0; i < 11; i++) {  // a run of equal lengths: the devices take these through the batched kernels, four per call
+        std::vector<uint8_t> d(3000);
+        for (size_t j = 0; j < d.size(); j++) d[j] = (uint8_t)(j * 13 + i * 31 + (j >> 7));
+        blobs.push_back(d);
+    }
     const uint8_t golden[32] = {209, 162, 213, 6,  157, 197, 135, 229, 93,  194, 156, 198, 37, 90, 249, 55,
                                 255, 127, 237, 14, 228, 27,  223, 90,  249, 135, 23,  249, 215, 79, 96,  232};
     MultiContext mc(std::vector<int>(n_slots, 0));
