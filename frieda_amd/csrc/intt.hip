@@ -300,6 +300,7 @@ struct GjArgs {
 __global__ __launch_bounds__(1024) void gj_panel_kernel(GjArgs a) {
     __shared__ uint32_t s_p;
     __shared__ uint32_t s_prow[2 * GJ_NB];
+    __shared__ uint32_t s_f[4096];  // this step's elimination factors (R <= 2^FRIEDA_MAX_LOG_CELLS)
     const uint32_t t = threadIdx.x, R = a.R, W = 2 * GJ_NB;
     if (a.state[0]) return;
     uint32_t* P = a.panel;
@@ -348,20 +349,19 @@ __global__ __launch_bounds__(1024) void gj_panel_kernel(GjArgs a) {
             P[(size_t)k * W + t] = v;
         }
         __syncthreads();
-        // eliminate column j from every other row: 32 threads per row (one per pair of columns), 32 rows per sweep
+        // eliminate column j from every other row.  The factors (column j of the panel, R <= 4096 words) are staged in LDS first,
+        // so that no lane reads an entry another lane of the same sweep overwrites; then 32 threads per row (two columns each),
+        // 32 rows per sweep
+        for (uint32_t i = t; i < R; i += 1024) s_f[i] = i == k ? 0u : P[(size_t)i * W + j];
+        __syncthreads();
         const uint32_t lane = t & 31, rsub = t >> 5;
         for (uint32_t i = rsub; i < R; i += 32) {
-            if (i == k) continue;
-            uint32_t* row = P + (size_t)i * W;
-            // the 32 lanes of a row are consecutive lanes of one wave: every lane has loaded f = row[j] (and its own two entries)
-            // before the lane that owns column j stores its zero
-            const uint32_t f = row[j];
+            const uint32_t f = s_f[i];
             if (f) {
+                uint32_t* row = P + (size_t)i * W;
                 const uint32_t c0 = lane, c1 = lane + 32;
-                const uint32_t v0 = m31_sub(row[c0], m31_mul(f, s_prow[c0]));
-                const uint32_t v1 = m31_sub(row[c1], m31_mul(f, s_prow[c1]));
-                row[c0] = v0;
-                row[c1] = v1;
+                row[c0] = m31_sub(row[c0], m31_mul(f, s_prow[c0]));
+                row[c1] = m31_sub(row[c1], m31_mul(f, s_prow[c1]));
             }
         }
         __syncthreads();

@@ -2,26 +2,29 @@
 # Regenerates the measurements kept under profiles/ (run on the GPU box from the repo root; outputs under gpurun_out/refresh).
 # usage: bash tools/refresh_profiles.sh <tag> <commit>     e.g. r02 abc1234
 # Order: PMC passes first (their per-kernel traffic file is what bench.py reports as roofline.traffic), then the bench lines,
-# then the kernel-trace statistics of the same command line.  PMC and --stats runs use --in-flight 1 so that the per-launch
-# averages are those of single-blob launches with nothing else on the chip.
+# then the kernel-trace statistics of the same command line.  PMC and --stats runs use --batch 1 --in-flight 1 so that the per-launch
+# averages are those of single-blob launches with nothing else on the chip (what the bench line's instrumented replay times).
+# usage (only the profiler passes): ONLY_PROF=1 bash tools/refresh_profiles.sh r02 <commit>
 set -u
 TAG=${1:-r02}
 COMMIT=${2:-}
 OUT=gpurun_out/refresh
 mkdir -p $OUT
 export TMPDIR=/tmp
-ONE="--no-cpu-baseline --in-flight 1 --batch-extra 0 --sequential-extra 0"
+ONE="--no-cpu-baseline --batch 1 --in-flight 1 --batch-extra 0 --sequential-extra 0"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 bench.py --steps 2 --warmup 1 $ONE > /dev/null 2> $OUT/pmc_fetch_err.txt
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 bench.py --steps 2 --warmup 1 $ONE > /dev/null 2> $OUT/pmc_write_err.txt
 python tools/traffic_from_pmc.py $OUT/pmc_fetch $OUT/pmc_write $OUT/${TAG}_prove24_traffic.json $COMMIT
 cp $OUT/${TAG}_prove24_traffic.json profiles/${TAG}_prove24_traffic.json
 cp $(ls $OUT/pmc_fetch/*/*counter_collection.csv | head -1) $OUT/${TAG}_prove24_pmc_FETCH_SIZE.csv
 cp $(ls $OUT/pmc_write/*/*counter_collection.csv | head -1) $OUT/${TAG}_prove24_pmc_WRITE_SIZE.csv
+if [ -z "${ONLY_PROF:-}" ]; then
 python bench.py > $OUT/${TAG}_prove24_bench.json 2> $OUT/prove_err.txt
 python bench.py --workload commit > $OUT/${TAG}_commit24_bench.json 2> $OUT/commit_err.txt
 python bench.py --log-domain 22 --cpu-sample-log 22 > $OUT/${TAG}_prove22_bench.json 2> $OUT/prove22_err.txt
 python bench.py --log-domain 20 --cpu-sample-log 20 > $OUT/${TAG}_prove20_bench.json 2> $OUT/prove20_err.txt
 python bench.py --workload commit --log-domain 22 --cpu-sample-log 22 > $OUT/${TAG}_commit22_bench.json 2> $OUT/commit22_err.txt
+fi
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 bench.py --steps 10 --warmup 3 $ONE > $OUT/stats_run.json 2> $OUT/stats_err.txt
 cp $(ls $OUT/stats/*/*kernel_stats.csv | head -1) $OUT/${TAG}_prove24_kernel_stats.csv
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats22 -- python3 bench.py --log-domain 22 --steps 10 --warmup 3 $ONE > $OUT/stats22_run.json 2> $OUT/stats22_err.txt
