@@ -21,10 +21,10 @@ import sys
 # from L2/MALL.  (A variant of the fold kernel that read the same bytes as 16-byte loads 32 bytes apart was counted in full,
 # 34 N' — the halving really is a property of the access pattern, as the guide says.)
 RULES = [
-    (r"tree5r_kernel<0>", "tree5_leaf", 2.0),
-    (r"tree5r_kernel<1>", "tree5_node", 2.0),
-    (r"tree5r_kernel<2>", "tree5_fold_circle", 2.0),
-    (r"tree5r_kernel<3>", "tree5_fold_line", 2.0),
+    (r"tree5r_kernel<0", "tree5_leaf", 2.0),
+    (r"tree5r_kernel<1", "tree5_node", 2.0),
+    (r"tree5r_kernel<2", "tree5_fold_circle", 2.0),
+    (r"tree5r_kernel<3", "tree5_fold_line", 2.0),
     (r"tree5_kernel<0, ", "tree5_leaf", 2.0),
     (r"tree5_kernel<1, ", "tree5_node", 2.0),
     (r"tree5_kernel<2, ", "tree5_fold_circle", 2.0),
