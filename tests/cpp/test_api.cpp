@@ -28,7 +28,7 @@ static const PcsConfig PCS_CONFIG{20, FriConfig{4, 1, 20}};  // src/proof.rs:109
 // `test_api.bin <blob> multi <n_slots>`: the multi-GPU entry points over n_slots device slots, all of them device 0 (the test
 // box has one GPU).  n_slots == 1 takes the no-exchange path unless FRIEDA_MULTI_FORCE_RCCL=1 (then the real one-rank RCCL
 // collective runs); n_slots > 1 needs FRIEDA_RCCL_PATH = tests/cpp/librccl_stub.so (real RCCL refuses a device listed twice).
-static int multi_mode(const std::vector<uint8_t>& blob, int n_slots) {
+static int multi_mode(const std::vector<uint8_t>& blob, int n_slots, bool distinct_devices = false) {
     std::vector<std::vector<uint8_t>> blobs;
     blobs.push_back(blob);  // the reference's fixture: its root is the golden root
     for (int i = 0; i < 6; i++) {  // ragged lengths, an empty blob among them
@@ -43,7 +43,11 @@ static int multi_mode(const std::vector<uint8_t>& blob, int n_slots) {
     }
     const uint8_t golden[32] = {209, 162, 213, 6,  157, 197, 135, 229, 93,  194, 156, 198, 37, 90, 249, 55,
                                 255, 127, 237, 14, 228, 27,  223, 90,  249, 135, 23,  249, 215, 79, 96,  232};
-    MultiContext mc(std::vector<int>(n_slots, 0));
+    // distinct_devices: slots 0 .. n_slots-1 are devices 0 .. n_slots-1 (a real multi-GPU node, real RCCL with n > 1)
+    std::vector<int> devs(n_slots, 0);
+    if (distinct_devices)
+        for (int i = 0; i < n_slots; i++) devs[i] = i;
+    MultiContext mc(devs);
     const bool want_rccl = n_slots > 1 || (getenv("FRIEDA_MULTI_FORCE_RCCL") && getenv("FRIEDA_MULTI_FORCE_RCCL")[0] == '1');
     CHECK(mc.uses_rccl() == want_rccl);
     auto roots = mc.commit_many(blobs, 4);
@@ -87,6 +91,7 @@ int main(int argc, char** argv) {
     std::vector<uint8_t> data((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
     CHECK(data.size() == 262146);
     if (argc >= 4 && std::strcmp(argv[2], "multi") == 0) return multi_mode(data, std::atoi(argv[3]));
+    if (argc >= 4 && std::strcmp(argv[2], "multi_real") == 0) return multi_mode(data, std::atoi(argv[3]), true);
 
     // test_commit (src/commit.rs:28-38): the golden root
     const uint8_t golden[32] = {209, 162, 213, 6,  157, 197, 135, 229, 93,  194, 156, 198, 37, 90, 249, 55,

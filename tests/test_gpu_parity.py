@@ -494,6 +494,23 @@ def test_cpp_multi_gpu_entry_points(gpu_ctx, n_slots, mode):
     assert f"rccl={0 if mode == 'plain' else 1}" in r.stdout
 
 
+@pytest.mark.skipif(os.environ.get("FRIEDA_TEST_MULTI_GPU") != "1", reason="opt-in: needs a node with >= 2 GPUs (FRIEDA_TEST_MULTI_GPU=1)")
+def test_cpp_multi_gpu_real_rccl():
+    """frieda_commit_many / frieda_prove_many over every visible GPU with the real RCCL root gather (n > 1).  Opt-in: the builder's
+    and the driver's test boxes have one GPU; a maintainer with a node runs FRIEDA_TEST_MULTI_GPU=1 pytest -m gpu -k real_rccl."""
+    import subprocess
+
+    import torch
+
+    from conftest import GOLDEN, ROOT
+
+    n = min(torch.cuda.device_count(), 8)
+    assert n >= 2
+    exe = os.path.join(ROOT, "tests", "cpp", "test_api.bin")
+    r = subprocess.run([exe, os.path.join(GOLDEN, "blob"), "multi_real", str(n)], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "rccl=1" in r.stdout, r.stdout + r.stderr
+
+
 def test_multi_context_python_and_rccl_failure_is_loud(gpu_ctx, oracle, monkeypatch):
     import frieda_amd
 
