@@ -74,6 +74,27 @@ struct RcclApi {
 
 }  // namespace
 
+// joins whatever was started, on every exit path (a std::thread destroyed while joinable terminates the process)
+struct JoinAll {
+    std::vector<std::thread>& w;
+    ~JoinAll() {
+        for (auto& t : w)
+            if (t.joinable()) t.join();
+    }
+};
+
+// finishes (into scratch) whatever a context still has in flight, so that the handle stays usable after a failed call
+static void drain_ctx(frieda_ctx* c) {
+    try {
+        const uint32_t cnt = job_count(&c->c);
+        if (!cnt) return;
+        std::vector<ProofData> scratch(cnt);
+        std::vector<uint8_t> r(32 * (size_t)cnt);
+        (void)prove_finish_batch(&c->c, r.data(), scratch);
+    } catch (...) {
+    }
+}
+
 constexpr uint32_t MULTI_UNIT = 4;  // equal-length blobs handed to a device per call (the batched kernels)
 
 struct frieda_multi {
@@ -250,8 +271,9 @@ int frieda_commit_many(frieda_multi* m, const uint8_t* const* blobs, const size_
         std::vector<int> status(n, FRIEDA_OK);
         std::atomic<bool> abort{false};
         std::vector<std::thread> workers;
+        JoinAll join_guard{workers};
+        for (size_t d = 0; d < n; d++) local[d].resize((count + n - 1 - d) / n);
         for (size_t d = 0; d < n; d++) {
-            local[d].resize((count + n - 1 - d) / n);
             workers.emplace_back([&, d] {
                 frieda_ctx* c = m->ctx[2 * d];
                 try {
@@ -310,8 +332,9 @@ int frieda_prove_many(frieda_multi* m, const uint8_t* const* blobs, const size_t
         std::vector<std::string> what(n);
         std::atomic<bool> abort{false};
         std::vector<std::thread> workers;
+        JoinAll join_guard{workers};
+        for (size_t d = 0; d < n; d++) local[d].resize((count + n - 1 - d) / n);
         for (size_t d = 0; d < n; d++) {
-            local[d].resize((count + n - 1 - d) / n);
             workers.emplace_back([&, d] {
               try {
                 // This device's blobs in order, cut into units: a run of up to MULTI_UNIT blobs of one length is one call of the
@@ -383,11 +406,7 @@ int frieda_prove_many(frieda_multi* m, const uint8_t* const* blobs, const size_t
                     const int rf = finish(u);
                     if (rf != FRIEDA_OK && status[d] == FRIEDA_OK) bail(rf, cx[u & 1]);
                     if (status[d] != FRIEDA_OK || abort.load()) {
-                        if (next_begun) {  // drain the unit already enqueued so that the context is reusable
-                            std::vector<ProofData> scratch(units[u + 1].cnt);
-                            std::vector<uint8_t> r(32 * (size_t)units[u + 1].cnt);
-                            (void)prove_finish_batch(&cx[(u + 1) & 1]->c, r.data(), scratch);
-                        }
+                        if (next_begun) drain_ctx(cx[(u + 1) & 1]);  // the unit already enqueued: the context must stay reusable
                         return;
                     }
                 }
@@ -395,6 +414,8 @@ int frieda_prove_many(frieda_multi* m, const uint8_t* const* blobs, const size_t
                   status[d] = FRIEDA_ERR_NOMEM;
                   what[d] = "host allocation failed";
                   abort.store(true);
+                  drain_ctx(m->ctx[2 * d]);
+                  drain_ctx(m->ctx[2 * d + 1]);
               }
             });
         }
