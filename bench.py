@@ -610,10 +610,12 @@ def main():
                     "note": "same step with frieda_ctx_set_twiddle_cache(0): twiddle tables regenerated on the device every call"}
 
     # secondary ceiling: the path is bound by the integer VALU rate of Blake2s, not by HBM.  For the kernels that hash
-    # a whole layer compare with the chip's measured pure-compute rate (profiles/r01_blake2s_rate_mi355x.txt: 40.9 G leaf / 39.8 G
-    # node compressions per second): the first tree (fused with the last transform pass: its butterflies are NOT in the ideal
+    # a whole layer compare with the pure-compute compression rate of THIS device, measured here and now (frieda_ctx_blake2s_ceiling:
+    # the rate depends on the clock the chip holds under the load and on the device; round 1's box gave 40.9 G leaf / 39.8 G node
+    # compressions per second, profiles/r01_blake2s_rate_mi355x.txt): the first tree (fused with the last transform pass: its butterflies are NOT in the ideal
     # time, so this fraction is a lower bound on the hashing efficiency) and the fused fold + tree of the first FRI layer.
     valu = None
+    leaf_rate, node_rate = ctx.blake2s_ceiling()  # measured now, on this device (frieda_ctx_blake2s_ceiling)
 
     def valu_entry(name, n_leaf, n_levels, note):
         k = next((x for x in kern if x["name"] == name), None)
@@ -621,9 +623,11 @@ def main():
             return None
         n_node = sum(n_leaf / (1 << l) for l in range(1, n_levels))
         t_launch = k["total_ms"] * 1e-3 / k["launches"]
-        ideal = n_leaf / 40.9e9 + n_node / 39.8e9
+        ideal = n_leaf / leaf_rate + n_node / node_rate
         return {"kernel": name, "bound": "int32 VALU (Blake2s compression)", "achieved": (n_leaf + n_node) / t_launch / 1e9,
-                "peak": (n_leaf + n_node) / ideal / 1e9, "unit": "G compressions/s", "frac": ideal / t_launch, "note": note}
+                "peak": (n_leaf + n_node) / ideal / 1e9, "unit": "G compressions/s", "frac": ideal / t_launch, "note": note,
+                "peak_source": f"measured in this run on this device: {leaf_rate / 1e9:.2f} G leaf / {node_rate / 1e9:.2f} G node compressions/s "
+                               "on register-resident data (frieda_ctx_blake2s_ceiling)"}
 
     if n >= 16:
         first = valu_entry("ntt_last_tree7", float(1 << n), 7, "leaf + 6 node levels; the launch also runs 12 transform layers on 4 columns") or \

@@ -113,6 +113,12 @@ class Context:
         _check(self._L.frieda_ctx_last_prove_phases(self._h, a), self._h)
         return dict(zip(["enqueued", "device_done", "queries", "gathered", "assembled", "first_launch_after_entry"], list(a)[:6]))
 
+    def blake2s_ceiling(self):
+        """(leaf, node) compressions per second this device sustains right now on register-resident data (measurement aid)."""
+        a, b = C.c_double(), C.c_double()
+        _check(self._L.frieda_ctx_blake2s_ceiling(self._h, C.byref(a), C.byref(b)), self._h)
+        return a.value, b.value
+
     def last_transcript(self):
         """Diagnostic: alphas drawn per FRI layer and the channel digest the grind was keyed by, of the last finished proof."""
         n = C.c_uint32()

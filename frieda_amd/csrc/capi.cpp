@@ -115,6 +115,20 @@ int frieda_ctx_last_prove_phases(const frieda_ctx* ctx, double out_ms[8]) {
     return FRIEDA_OK;
 }
 
+int frieda_ctx_blake2s_ceiling(frieda_ctx* ctx, double* leaf_per_s, double* node_per_s) {
+    if (!ctx) return FRIEDA_ERR_ARG;
+    FR_NO_JOB(&ctx->c);
+    FR_GUARD_BEGIN
+    FR_HIP(&ctx->c, hipSetDevice(ctx->c.device));
+    int rc = ctx->c.ensure_arena((size_t)256 * 8 * 256 * 4);
+    if (rc) return rc;
+    if (k::blake2s_ceiling(ctx->c.stream, reinterpret_cast<uint32_t*>(ctx->c.arena), leaf_per_s, node_per_s))
+        return ctx->c.fail(FRIEDA_ERR_HIP, "blake2s_ceiling: event timing failed");
+    FR_HIP(&ctx->c, hipGetLastError());
+    return FRIEDA_OK;
+    FR_GUARD_END(ctx)
+}
+
 int frieda_ctx_last_transcript(const frieda_ctx* ctx, uint32_t* n_layers, uint32_t* alphas, size_t cap_layers, uint8_t digest_before_grind[32]) {
     if (!ctx || !n_layers) return FRIEDA_ERR_ARG;
     const Ctx::LastTranscript& t = ctx->c.last_transcript;
@@ -698,7 +712,7 @@ int interpolate_cells(frieda_ctx* ctx, const uint32_t* d_cells, const uint32_t* 
     const uint32_t* d_state = nullptr;
     if (on_device) {
         // cell indices behind the solver's own scratch; the blocked Gauss-Jordan leaves V^-1 in the right half of [V | I]
-        uint32_t* d_idx = reinterpret_cast<uint32_t*>(d_solve + k::cells_inverse_scratch_bytes(n_cells) - 4 * (size_t)n_cells - 512);
+        uint32_t* d_idx = k::cells_inverse_index_buffer(d_solve, n_cells);
         FR_HIP(&c, hipMemcpyAsync(d_idx, cell_index, 4 * (size_t)n_cells, hipMemcpyHostToDevice, c.stream));
         k::cells_matrix_inverse_device(c.launch(), d_idx, n_cells, log_coef - log_cell, log_cell, log_domain, ts.d_tw, d_solve, &d_vinv, &vinv_pitch,
                                        &d_state);

@@ -414,9 +414,12 @@ __global__ __launch_bounds__(256) void gj_update_kernel(GjArgs a) {
 }
 }  // namespace
 
-size_t cells_inverse_scratch_bytes(uint32_t R) {
-    // [V | I] + panel scratch + saved pivot rows + state + device copy of the cell indices
-    return sizeof(uint32_t) * ((size_t)R * 2 * R + (size_t)R * 2 * GJ_NB + (size_t)GJ_NB * 2 * R + 64 + R) + 1024;
+// scratch layout (words): [V | I] R x 2R, panel R x 2 NB, saved pivot rows NB x 2R, state 64, cell indices R
+static size_t cells_inverse_index_offset_words(uint32_t R) { return (size_t)R * 2 * R + (size_t)R * 2 * GJ_NB + (size_t)GJ_NB * 2 * R + 64; }
+size_t cells_inverse_scratch_bytes(uint32_t R) { return sizeof(uint32_t) * (cells_inverse_index_offset_words(R) + R) + 256; }
+// where the caller uploads the R cell indices (inside the scratch block)
+uint32_t* cells_inverse_index_buffer(uint8_t* d_scratch, uint32_t R) {
+    return reinterpret_cast<uint32_t*>(d_scratch) + cells_inverse_index_offset_words(R);
 }
 
 // d_scratch: cells_inverse_scratch_bytes(R) bytes, 256-byte aligned.  On return (asynchronously) the inverse sits at

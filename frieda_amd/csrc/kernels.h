@@ -54,6 +54,10 @@ struct DomainScalars {
 // d_bytes + b * src_bstride (the caller's layout); its felts go to d_out shifted by b * L.bstride bytes.
 void unpack30(const Launch& L, const uint8_t* d_bytes, size_t len, uint32_t* d_out, size_t n_out, size_t src_bstride = 0);
 
+// ---- diag.hip ----
+// pure-compute Blake2s compression rate of this device (measurement aid; see frieda_ctx_blake2s_ceiling)
+int blake2s_ceiling(hipStream_t s, uint32_t* d_scratch, double* leaf_per_s, double* node_per_s);
+
 // ---- column.hip ----
 // ColumnOps::bit_reverse_column in place on `ncols` columns of 2^log_size words, `stride` words apart (1 = BaseField column,
 // 4 = SecureColumn)
@@ -99,6 +103,7 @@ void cells_combine(const Launch& L_, const uint32_t* d_w, const uint32_t* d_vinv
                    size_t coef_stride, size_t vinv_pitch = 0);
 // the R x R cell matrix inverted on the device (blocked Gauss-Jordan; R a multiple of 32, R <= 4096): see intt.hip
 size_t cells_inverse_scratch_bytes(uint32_t R);
+uint32_t* cells_inverse_index_buffer(uint8_t* d_scratch, uint32_t R);  // the R-word slot of the scratch block for the cell indices
 void cells_matrix_inverse_device(const Launch& L_, const uint32_t* d_cell_index, uint32_t R, uint32_t j_bits, uint32_t m, uint32_t n,
                                  const uint32_t* d_tw, uint8_t* d_scratch, const uint32_t** d_vinv_out, size_t* pitch_out,
                                  const uint32_t** d_state_out);

@@ -90,6 +90,11 @@ int frieda_ctx_set_kernel_timing(frieda_ctx* ctx, int enabled);
  * planned the openings), [4] proof assembled, [5] host set-up before the first launch */
 int frieda_ctx_last_prove_phases(const frieda_ctx* ctx, double out_ms[8]);
 size_t frieda_ctx_kernel_timing_report(frieda_ctx* ctx, char* buf, size_t cap, int reset);
+/* measurement aid: the pure-compute rate of the Merkle compression on THIS device, now — compressions per second with every
+ * lane chaining Blake2s compressions on register-resident data (8 workgroups per CU), leaf-shaped (4 message words, 12 zero) and
+ * node-shaped (16 words).  The path is bound by this rate, which depends on the clock the chip holds under the load and on the
+ * device; bench.py quotes it beside the measured kernels (roofline_valu) instead of a constant.  ~5 ms; synchronises the stream. */
+int frieda_ctx_blake2s_ceiling(frieda_ctx* ctx, double* leaf_per_s, double* node_per_s);
 /* diagnostic: the Fiat-Shamir transcript of the last finished generate_proof on this ctx (blob 0 of a batch) — what
  * FriProver::commit derives between src/proof.rs:52 and :58 and the Proof does not carry: per FRI layer (first, then inner)
  * the folding alpha drawn after its root (4 u32 each; the roots themselves are the layer commitments of the Proof), and the

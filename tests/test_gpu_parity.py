@@ -172,6 +172,12 @@ def test_bit_reverse_column_strided_and_errors(gpu_ctx, oracle):
     assert gpu_ctx._L.frieda_bit_reverse_column(gpu_ctx._h, d.ptr, 100, 1, 29) == 1
 
 
+def test_blake2s_ceiling_is_plausible(gpu_ctx):
+    """frieda_ctx_blake2s_ceiling: tens of G compressions per second on an MI355X; leaf-shaped messages are cheaper than node-shaped."""
+    leaf, node = gpu_ctx.blake2s_ceiling()
+    assert 1e10 < node < 1e11 and 1e10 < leaf < 1e11 and leaf > 0.98 * node
+
+
 def test_dev_at(gpu_ctx):
     """Column::at on a BaseField column and on a SecureColumn."""
     rng = np.random.default_rng(8)
