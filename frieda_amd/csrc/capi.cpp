@@ -84,7 +84,7 @@ int frieda_ctx_synchronize(frieda_ctx* ctx) {
 
 int frieda_ctx_release_workspace(frieda_ctx* ctx) {
     if (!ctx) return FRIEDA_ERR_ARG;
-    if (ctx->c.job) return ctx->c.fail(FRIEDA_ERR_ARG, "a proof is in flight on this context");
+    FR_NO_JOB(&ctx->c);
     FR_HIP(&ctx->c, hipSetDevice(ctx->c.device));
     FR_HIP(&ctx->c, hipStreamSynchronize(ctx->c.stream));
     if (ctx->c.arena) FR_HIP(&ctx->c, hipFree(ctx->c.arena));

@@ -95,6 +95,7 @@ struct Ctx {
     double phase_ms[8] = {0};  // host wall-clock marks of the last prove() (ms since entry): enqueued, device done, queries, gather, assembled
     KernelTimerImpl* timer = nullptr;  // non-null while kernel timing is enabled
     std::unique_ptr<ProveJob, ProveJobDeleter> job;  // the proof in flight, if any
+    uint32_t commit_pending = 0;  // roots of a commit_batch_begin not yet collected by commit_batch_finish (they sit in `pinned`)
     // Fiat-Shamir transcript of the last finished proof (blob 0 of a batch), kept for frieda_ctx_last_transcript
     struct LastTranscript {
         std::vector<Hash32> roots;                      // one per FRI layer (first + inner)
@@ -125,7 +126,8 @@ struct Ctx {
 // them refuses to run meanwhile.
 #define FR_NO_JOB(ctx)                                                                                                 \
     do {                                                                                                               \
-        if ((ctx)->job) return (ctx)->fail(FRIEDA_ERR_ARG, "a proof is in flight on this context (finish it first, or use another context)"); \
+        if ((ctx)->job || (ctx)->commit_pending)                                                                        \
+            return (ctx)->fail(FRIEDA_ERR_ARG, "a proof is in flight on this context (finish it first, or use another context)"); \
     } while (0)
 
 // bump allocator over the ctx arena (sizes are planned before ensure_arena)
@@ -158,6 +160,11 @@ int prove_finish_batch(Ctx* ctx, uint8_t* out_commitments, std::vector<ProofData
 uint32_t job_count(const Ctx* ctx);  // blobs of the job in flight (0: none)
 int commit_batch(Ctx* ctx, const uint8_t* data, size_t data_stride, size_t len, uint32_t count, bool data_on_device, uint32_t log_blowup,
                  uint8_t* out_roots, const uint8_t* const* host_ptrs = nullptr);
+// split form (frieda_commit_many alternates two contexts: the upload of one unit runs under the kernels of the other): _begin
+// enqueues upload, kernels and the download of the roots into the pinned block; _finish waits and copies `count * 32` bytes out
+int commit_batch_begin(Ctx* ctx, const uint8_t* data, size_t data_stride, size_t len, uint32_t count, bool data_on_device, uint32_t log_blowup,
+                       const uint8_t* const* host_ptrs = nullptr);
+int commit_batch_finish(Ctx* ctx, uint8_t* out_roots);
 // returns FRIEDA_OK with *ok set, or FRIEDA_ERR_INVARIANT where the reference panics
 int verify(const ProofData& proof, const uint64_t* seed, int* ok);
 

@@ -269,45 +269,78 @@ int frieda_commit_many(frieda_multi* m, const uint8_t* const* blobs, const size_
         const size_t n = m->devices.size();
         std::vector<std::vector<Hash32>> local(n);
         std::vector<int> status(n, FRIEDA_OK);
+        std::vector<std::string> what(n);
         std::atomic<bool> abort{false};
         std::vector<std::thread> workers;
         JoinAll join_guard{workers};
         for (size_t d = 0; d < n; d++) local[d].resize((count + n - 1 - d) / n);
         for (size_t d = 0; d < n; d++) {
             workers.emplace_back([&, d] {
-                frieda_ctx* c = m->ctx[2 * d];
+                frieda_ctx* cx[2] = {m->ctx[2 * d], m->ctx[2 * d + 1]};
                 try {
-                    // this device's blobs in order; runs of equal length go through the batched kernels, up to UNIT at a time
+                    // This device's blobs in order, cut into units (a run of up to MULTI_UNIT blobs of one length = one call of the
+                    // batched kernels); two units in flight on the two contexts, so that the upload of one runs under the kernels of
+                    // the other.
                     const uint32_t mine = (uint32_t)local[d].size();
-                    for (uint32_t slot = 0; slot < mine && !abort.load();) {
+                    struct Unit {
+                        uint32_t slot, cnt;
+                    };
+                    std::vector<Unit> units;
+                    for (uint32_t slot = 0; slot < mine;) {
                         const uint32_t i0 = (uint32_t)d + slot * (uint32_t)n;
                         uint32_t cnt = 1;
                         while (cnt < MULTI_UNIT && slot + cnt < mine && lens[i0 + cnt * n] == lens[i0]) cnt++;
-                        int rc;
-                        if (cnt == 1) {
-                            rc = commit_host(&c->c, blobs[i0], lens[i0], log_blowup_factor, local[d][slot].data());
-                        } else {
-                            const uint8_t* ptrs[MULTI_UNIT];
-                            for (uint32_t k = 0; k < cnt; k++) ptrs[k] = blobs[i0 + k * n];
-                            rc = commit_batch(&c->c, ptrs[0], lens[i0], lens[i0], cnt, false, log_blowup_factor, local[d][slot].data(), ptrs);
-                        }
-                        if (rc != FRIEDA_OK) {
-                            status[d] = rc;
-                            abort.store(true);
-                            return;
-                        }
+                        units.push_back(Unit{slot, cnt});
                         slot += cnt;
                     }
+                    auto begin = [&](size_t u) {
+                        const uint32_t i0 = (uint32_t)d + units[u].slot * (uint32_t)n;
+                        const uint8_t* ptrs[MULTI_UNIT];
+                        for (uint32_t k = 0; k < units[u].cnt; k++) ptrs[k] = blobs[i0 + k * n];
+                        return commit_batch_begin(&cx[u & 1]->c, ptrs[0], lens[i0], lens[i0], units[u].cnt, false, log_blowup_factor, ptrs);
+                    };
+                    auto bail = [&](int rc, frieda_ctx* c) {
+                        if (status[d] == FRIEDA_OK) {
+                            status[d] = rc;
+                            what[d] = c->c.err;
+                        }
+                        abort.store(true);
+                    };
+                    if (units.empty()) return;
+                    int rc = begin(0);
+                    if (rc != FRIEDA_OK) return bail(rc, cx[0]);
+                    for (size_t u = 0; u < units.size(); u++) {
+                        bool next_begun = false;
+                        if (u + 1 < units.size() && !abort.load()) {
+                            rc = begin(u + 1);
+                            if (rc != FRIEDA_OK) bail(rc, cx[(u + 1) & 1]);
+                            next_begun = rc == FRIEDA_OK;
+                        }
+                        const int rf = commit_batch_finish(&cx[u & 1]->c, local[d][units[u].slot].data());
+                        if (rf != FRIEDA_OK) bail(rf, cx[u & 1]);
+                        if (status[d] != FRIEDA_OK || abort.load()) {
+                            if (next_begun) {
+                                std::vector<uint8_t> r(32 * (size_t)units[u + 1].cnt);
+                                (void)commit_batch_finish(&cx[(u + 1) & 1]->c, r.data());
+                            }
+                            return;
+                        }
+                    }
                 } catch (...) {  // nothing may unwind out of a worker thread
-                    c->c.err = "host allocation failed";
+                    what[d] = "host allocation failed";
                     status[d] = FRIEDA_ERR_NOMEM;
                     abort.store(true);
+                    for (frieda_ctx* c : cx)
+                        if (c->c.commit_pending) {
+                            (void)hipStreamSynchronize(c->c.stream);
+                            c->c.commit_pending = 0;
+                        }
                 }
             });
         }
         for (auto& w : workers) w.join();
         for (size_t d = 0; d < n; d++)
-            if (status[d] != FRIEDA_OK) return m->fail(status[d], "device " + std::to_string(m->devices[d]) + ": " + m->ctx[2 * d]->c.err);
+            if (status[d] != FRIEDA_OK) return m->fail(status[d], "device " + std::to_string(m->devices[d]) + ": " + what[d]);
         return m->gather_roots(local, count, out_roots);
     } catch (const std::bad_alloc&) {
         return m->fail(FRIEDA_ERR_NOMEM, "host allocation failed");

@@ -163,6 +163,24 @@ int commit_host(Ctx* ctx, const uint8_t* data, size_t len, uint32_t log_blowup, 
 // commit() of `count` blobs of one length in one pass of launches (blob b at data + b * data_stride); roots to host memory
 int commit_batch(Ctx* ctx, const uint8_t* data, size_t data_stride, size_t len, uint32_t count, bool data_on_device, uint32_t log_blowup,
                  uint8_t* out_roots, const uint8_t* const* host_ptrs) {
+    int rc = commit_batch_begin(ctx, data, data_stride, len, count, data_on_device, log_blowup, host_ptrs);
+    if (rc) return rc;
+    return commit_batch_finish(ctx, out_roots);
+}
+
+int commit_batch_finish(Ctx* ctx, uint8_t* out_roots) {
+    if (!ctx->commit_pending) return ctx->fail(FRIEDA_ERR_ARG, "no commit batch in flight on this context");
+    const uint32_t count = ctx->commit_pending;
+    ctx->commit_pending = 0;
+    FR_HIP(ctx, hipSetDevice(ctx->device));
+    FR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    FR_HIP(ctx, hipGetLastError());
+    memcpy(out_roots, ctx->pinned, 32 * (size_t)count);
+    return FRIEDA_OK;
+}
+
+int commit_batch_begin(Ctx* ctx, const uint8_t* data, size_t data_stride, size_t len, uint32_t count, bool data_on_device, uint32_t log_blowup,
+                       const uint8_t* const* host_ptrs) {
     FR_NO_JOB(ctx);
     if (count == 0 || count > 65535) return ctx->fail(FRIEDA_ERR_ARG, "batch count out of range");
     if (count > 1 && data_stride < len) return ctx->fail(FRIEDA_ERR_ARG, "batch stride smaller than the blob length");
@@ -205,9 +223,8 @@ int commit_batch(Ctx* ctx, const uint8_t* data, size_t data_stride, size_t len, 
     k::unpack30(LN, d_data, len, coef, sh.cs.n_padded, d_stride);
     k::encode_and_first_tree(LN, coef, (size_t)1 << sh.L, sh.L, sh.n, tw.d_tw, tw.ds, eval, sh.N, nullptr, A + o_scr, A + o_root, nullptr);
     FR_HIP(ctx, hipMemcpy2DAsync(ctx->pinned, 32, A + o_root, bstride, 32, count, hipMemcpyDeviceToHost, s));
-    FR_HIP(ctx, hipStreamSynchronize(s));
     FR_HIP(ctx, hipGetLastError());
-    memcpy(out_roots, ctx->pinned, 32 * (size_t)count);
+    ctx->commit_pending = count;
     return FRIEDA_OK;
 }
 
