@@ -82,7 +82,7 @@ static inline int qm_eq(qm31 x, qm31 y) {
     return x.c0.a == y.c0.a && x.c0.b == y.c0.b && x.c1.a == y.c1.a && x.c1.b == y.c1.b;
 }
 static inline int qm_is_zero(qm31 x) { return !(x.c0.a | x.c0.b | x.c1.a | x.c1.b); }
-static const qm31 QM_ZERO = {{0, 0}, {0, 0}};
+static const qm31 QM_ZERO __attribute__((unused)) = {{0, 0}, {0, 0}};
 
 void fo_qm31_mul(const uint32_t a[4], const uint32_t b[4], uint32_t out[4]) { qm_to(qm_mul(qm_from(a), qm_from(b)), out); }
 
