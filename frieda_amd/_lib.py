@@ -129,6 +129,7 @@ def lib():
         "frieda_pack30": (C.c_int, [vp, vp, sz, vp, sz]),
         "frieda_reconstruct_device": (C.c_int, [vp, vp, u32, u32, u32, sz, vp]),
         "frieda_circle_interpolate_cells": (C.c_int, [vp, vp, vp, u32, u32, u32, u32, u32, vp]),
+        "frieda_circle_interpolate_cells_any": (C.c_int, [vp, vp, vp, u32, u32, u32, u32, u32, vp, vp]),
         "frieda_reconstruct_cells_device": (C.c_int, [vp, vp, vp, u32, u32, u32, u32, sz, vp]),
         "frieda_merkle_commit_layer": (C.c_int, [vp, u32, vp, pp, u32, vp]),
         "frieda_merkle_commit": (C.c_int, [vp, vp, u32, vp]),

@@ -619,38 +619,71 @@ namespace {
 // T_l[h] = x-coordinate of C_l.at(brev(h, n-2-l)), C_l = half_odds(n-1) doubled l times (oracle: fo_reconstruct_cells).
 // Gauss-Jordan over M31 on the host: R <= 256.  false: singular matrix (repeated cells; no singular set of distinct cells has been
 // observed — the code is MDS up to one dimension — but the solve reports it rather than assuming it away).
+// row of the cell matrix for cell c: row[u] = prod over the set bits b of u of s_b(c), u < R = 2^nb
+void cells_matrix_row(uint32_t c, uint32_t nb, uint32_t m, uint32_t n, uint32_t* row) {
+    row[0] = 1;
+    for (uint32_t b = 0; b < nb; b++) {
+        uint32_t t;
+        if (m + b == 0) {
+            // single points (m == 0): bit 0 of the index is the circle layer, twiddle Y[c >> 1] = [y, -y, -x, x][h & 3] of the
+            // pair (x, y) = (T_0[2 (h >> 2)], T_0[2 (h >> 2) + 1])
+            const uint32_t h = c >> 1;
+            const Coset cs = Coset::half_odds(n - 1);
+            if (n < 3) {
+                const uint32_t y = point_from_index(cs.initial).y;
+                t = (h & 1u) ? m31_neg(y) : y;
+            } else {
+                const uint32_t jj = h >> 2, rr = h & 3u;
+                const uint32_t v = cs.at(bit_reverse(2 * jj + (rr < 2 ? 1 : 0), n - 2)).x;
+                t = (rr == 1 || rr == 2) ? m31_neg(v) : v;
+            }
+        } else {
+            const uint32_t lv = m + b - 1;
+            Coset cs = Coset::half_odds(n - 1);
+            for (uint32_t i = 0; i < lv; i++) cs = cs.doubled();
+            t = cs.at(bit_reverse(c >> (b + 1), n - 2 - lv)).x;
+        }
+        if ((c >> b) & 1u) t = m31_neg(t);
+        for (uint32_t u = 0; u < (1u << b); u++) row[(1u << b) + u] = m31_mul(row[u], t);
+    }
+}
+
+// Over-determined form: n_avail >= R cells are offered; picks, in the order given, R of them whose rows are linearly independent
+// (Gaussian elimination with the pivot taken from the first unused row that has a non-zero entry in the column).  false: the offered
+// cells do not span the R-dimensional space.  chosen[k] = position in the caller's list of the k-th cell taken.
+bool cells_select_independent(const uint32_t* cell_index, uint32_t n_avail, uint32_t R, uint32_t m, uint32_t n, std::vector<uint32_t>& chosen) {
+    uint32_t nb = 0;
+    while ((1u << nb) < R) nb++;
+    std::vector<uint32_t> A((size_t)n_avail * R);
+    for (uint32_t r = 0; r < n_avail; r++) cells_matrix_row(cell_index[r], nb, m, n, &A[(size_t)r * R]);
+    std::vector<uint8_t> used(n_avail, 0);
+    chosen.clear();
+    for (uint32_t col = 0; col < R; col++) {
+        uint32_t piv = 0;
+        while (piv < n_avail && (used[piv] || A[(size_t)piv * R + col] == 0)) piv++;
+        if (piv == n_avail) return false;
+        used[piv] = 1;
+        chosen.push_back(piv);
+        const uint32_t* prow = &A[(size_t)piv * R];
+        const uint32_t inv = m31_inv(prow[col]);
+        for (uint32_t r = 0; r < n_avail; r++) {
+            if (used[r]) continue;
+            uint32_t* row = &A[(size_t)r * R];
+            if (!row[col]) continue;
+            const uint32_t f = m31_mul(row[col], inv);
+            for (uint32_t j = col; j < R; j++) row[j] = m31_sub(row[j], m31_mul(f, prow[j]));
+        }
+    }
+    return true;
+}
+
 bool cells_matrix_inverse(const uint32_t* cell_index, uint32_t R, uint32_t m, uint32_t n, std::vector<uint32_t>& vinv) {
     std::vector<uint32_t> A((size_t)R * 2 * R, 0u);
     uint32_t nb = 0;
     while ((1u << nb) < R) nb++;
     for (uint32_t r = 0; r < R; r++) {
-        const uint32_t c = cell_index[r];
         uint32_t* row = &A[(size_t)r * 2 * R];
-        row[0] = 1;
-        for (uint32_t b = 0; b < nb; b++) {
-            uint32_t t;
-            if (m + b == 0) {
-                // single points (m == 0): bit 0 of the index is the circle layer, twiddle Y[c >> 1] = [y, -y, -x, x][h & 3] of the
-                // pair (x, y) = (T_0[2 (h >> 2)], T_0[2 (h >> 2) + 1])
-                const uint32_t h = c >> 1;
-                const Coset cs = Coset::half_odds(n - 1);
-                if (n < 3) {
-                    const uint32_t y = point_from_index(cs.initial).y;
-                    t = (h & 1u) ? m31_neg(y) : y;
-                } else {
-                    const uint32_t jj = h >> 2, rr = h & 3u;
-                    const uint32_t v = cs.at(bit_reverse(2 * jj + (rr < 2 ? 1 : 0), n - 2)).x;
-                    t = (rr == 1 || rr == 2) ? m31_neg(v) : v;
-                }
-            } else {
-                const uint32_t lv = m + b - 1;
-                Coset cs = Coset::half_odds(n - 1);
-                for (uint32_t i = 0; i < lv; i++) cs = cs.doubled();
-                t = cs.at(bit_reverse(c >> (b + 1), n - 2 - lv)).x;
-            }
-            if ((c >> b) & 1u) t = m31_neg(t);
-            for (uint32_t u = 0; u < (1u << b); u++) row[(1u << b) + u] = m31_mul(row[u], t);
-        }
+        cells_matrix_row(cell_index[r], nb, m, n, row);
         row[R + r] = 1;
     }
     for (uint32_t col = 0; col < R; col++) {
@@ -678,8 +711,9 @@ bool cells_matrix_inverse(const uint32_t* cell_index, uint32_t R, uint32_t m, ui
 
 // coefficients of `ncols` columns from n_cells scattered cells into d_coef[ncols][2^log_coef], or — d_coef == nullptr — into the
 // start of the arena (the caller reserved arena_off bytes there).  Scratch: the arena behind arena_off.
+// slot_of (optional): cell r of the system is the slot_of[r]-th cell of the caller's d_cells buffer (the over-determined entry)
 int interpolate_cells(frieda_ctx* ctx, const uint32_t* d_cells, const uint32_t* cell_index, uint32_t n_cells, uint32_t ncols, uint32_t log_cell,
-                      uint32_t log_coef, uint32_t log_domain, uint32_t* d_coef, size_t arena_off) {
+                      uint32_t log_coef, uint32_t log_domain, uint32_t* d_coef, size_t arena_off, const uint32_t* slot_of = nullptr) {
     Ctx& c = ctx->c;
     FR_NO_JOB(&c);
     if (log_cell > log_coef || log_coef > log_domain || log_domain < 1 || log_domain > FRIEDA_MAX_LOG_DOMAIN)
@@ -720,8 +754,8 @@ int interpolate_cells(frieda_ctx* ctx, const uint32_t* d_cells, const uint32_t* 
         FR_HIP(&c, hipMemcpyAsync(d_solve, vinv.data(), 4 * vinv.size(), hipMemcpyHostToDevice, c.stream));
     }
     for (uint32_t r = 0; r < n_cells; r++)  // undo the block transform of every cell (layers log_cell-1 .. 0 with the cell's twiddles)
-        k::circle_interpolate_block(c.launch(), d_cells + (size_t)r * ncols * M, M, ncols, log_cell, log_domain, cell_index[r], ts.d_itw, ts.ds,
-                                    d_w + (size_t)r * ncols * M, M);
+        k::circle_interpolate_block(c.launch(), d_cells + (size_t)(slot_of ? slot_of[r] : r) * ncols * M, M, ncols, log_cell, log_domain,
+                                    cell_index[r], ts.d_itw, ts.ds, d_w + (size_t)r * ncols * M, M);
     k::cells_combine(c.launch(), d_w, d_vinv, n_cells, ncols, log_cell, d_coef ? d_coef : reinterpret_cast<uint32_t*>(c.arena),
                      (size_t)1 << log_coef, vinv_pitch);
     uint32_t singular = 0;
@@ -739,6 +773,28 @@ int frieda_circle_interpolate_cells(frieda_ctx* ctx, const uint32_t* d_cells, co
     FR_GUARD_BEGIN
     FR_HIP(&ctx->c, hipSetDevice(ctx->c.device));
     return interpolate_cells(ctx, d_cells, cell_index, n_cells, ncols, log_cell, log_coef, log_domain, d_coef, 0);
+    FR_GUARD_END(ctx)
+}
+
+int frieda_circle_interpolate_cells_any(frieda_ctx* ctx, const uint32_t* d_cells, const uint32_t* cell_index, uint32_t n_avail, uint32_t ncols,
+                                        uint32_t log_cell, uint32_t log_coef, uint32_t log_domain, uint32_t* d_coef, uint32_t* out_used) {
+    if (!ctx || !d_cells || !cell_index || !d_coef || ncols == 0 || ncols > 1024) return FRIEDA_ERR_ARG;
+    if (log_cell > log_coef || log_coef > log_domain || log_domain < 1 || log_domain > FRIEDA_MAX_LOG_DOMAIN) return FRIEDA_ERR_ARG;
+    if (log_coef - log_cell > 8) return ctx->c.fail(FRIEDA_ERR_ARG, "cells (any): at most 256 cells are needed in this form (the host-side selection)");
+    const uint32_t R = 1u << (log_coef - log_cell);
+    if (n_avail < R || n_avail > 65536) return ctx->c.fail(FRIEDA_ERR_ARG, "cells (any): need between 2^(log_coef - log_cell) and 65536 cells");
+    FR_GUARD_BEGIN
+    for (uint32_t r = 0; r < n_avail; r++)
+        if ((uint64_t)cell_index[r] >= ((uint64_t)1 << (log_domain - log_cell))) return ctx->c.fail(FRIEDA_ERR_ARG, "cells: cell index out of range");
+    std::vector<uint32_t> chosen;
+    if (!cells_select_independent(cell_index, n_avail, R, log_cell, log_domain, chosen))
+        return ctx->c.fail(FRIEDA_ERR_ARG, "cells (any): the offered cells do not determine the polynomial");
+    std::vector<uint32_t> idx(R);
+    for (uint32_t k2 = 0; k2 < R; k2++) idx[k2] = cell_index[chosen[k2]];
+    FR_HIP(&ctx->c, hipSetDevice(ctx->c.device));
+    const int rc = interpolate_cells(ctx, d_cells, idx.data(), R, ncols, log_cell, log_coef, log_domain, d_coef, 0, chosen.data());
+    if (rc == FRIEDA_OK && out_used) memcpy(out_used, chosen.data(), 4 * (size_t)R);
+    return rc;
     FR_GUARD_END(ctx)
 }
 

@@ -846,6 +846,43 @@ def test_circle_interpolate_scattered_cells(gpu_ctx, oracle, L, n, m):
     assert L_.frieda_circle_interpolate_cells(gpu_ctx._h, d_cells.ptr, idx.ctypes.data, R + 1, ncols, m, L, n, d_c.ptr) != 0
 
 
+@pytest.mark.parametrize("L,n,m", [(3, 5, 0), (3, 6, 0), (4, 8, 0), (2, 2, 0), (5, 9, 1), (8, 12, 0)])
+def test_circle_interpolate_cells_over_determined(gpu_ctx, oracle, L, n, m):
+    """frieda_circle_interpolate_cells_any: a few cells more than needed, in any order, duplicates tolerated — the call picks an
+    independent subset, so the point sets that are singular as drawn (a few % at these tiny domains, m == 0) still reconstruct."""
+    rng = np.random.default_rng(4100 + 100 * L + 10 * n + m)
+    ncols = 4
+    coef = rand_m31(rng, (ncols, 1 << L))
+    ev = oracle.circle_evaluate(coef, n)
+    R = 1 << (L - m)
+    total = 1 << (n - m)
+    saw_singular_prefix = 0
+    for trial in range(40 if L <= 4 else 4):
+        n_avail = min(total, R + 4)
+        idx = rng.choice(total, size=n_avail, replace=False).astype(np.uint32)
+        if trial % 3 == 0 and n_avail > R:
+            idx[-1] = idx[0]  # a repeated cell among the spares
+        cells = np.ascontiguousarray(np.stack([ev[:, int(c) << m : (int(c) + 1) << m] for c in idx]))
+        d_cells, d_c = DevBuf.from_array(gpu_ctx, cells), DevBuf(gpu_ctx, 4 * ncols << L)
+        used = (C.c_uint32 * R)()
+        _check(gpu_ctx, gpu_ctx._L.frieda_circle_interpolate_cells_any(gpu_ctx._h, d_cells.ptr, idx.ctypes.data, n_avail, ncols, m, L, n, d_c.ptr, used))
+        assert np.array_equal(d_c.to_array(np.uint32, (ncols, 1 << L)), coef), (trial, idx)
+        u = list(used)
+        assert len(set(int(idx[k]) for k in u)) == R
+        # the oracle on exactly the subset the product used gives the same coefficients
+        assert np.array_equal(oracle.reconstruct_cells(cells[u][:, :1], idx[u], n, L), coef[:1])
+        # was the first-R prefix singular by itself?  (then the exact-count entry refuses it and the over-determined one recovered)
+        rc = gpu_ctx._L.frieda_circle_interpolate_cells(gpu_ctx._h, d_cells.ptr, idx.ctypes.data, R, ncols, m, L, n, d_c.ptr)
+        saw_singular_prefix += rc != 0
+    # rank-deficient offers are refused: one cell repeated n_avail times; fewer cells than needed
+    same = np.full(R + 2, idx[0], dtype=np.uint32)
+    assert gpu_ctx._L.frieda_circle_interpolate_cells_any(gpu_ctx._h, d_cells.ptr, same.ctypes.data, min(R + 2, n_avail), ncols, m, L, n, d_c.ptr, None) == (1 if R > 1 else 0)
+    if R > 1:
+        assert gpu_ctx._L.frieda_circle_interpolate_cells_any(gpu_ctx._h, d_cells.ptr, idx.ctypes.data, R - 1, ncols, m, L, n, d_c.ptr, None) == 1
+    if (L, n, m) == (3, 5, 0):
+        assert saw_singular_prefix >= 1  # the case this entry exists for did occur
+
+
 @pytest.mark.parametrize("L,n,m,with_oracle", [(10, 14, 1, True), (10, 12, 1, False), (12, 16, 2, False), (13, 17, 1, False), (15, 19, 3, False),
                                                (9, 13, 0, True), (11, 15, 0, False), (12, 12, 0, False)])  # m == 0: single sampled points
 def test_circle_interpolate_many_cells_device_solve(gpu_ctx, oracle, L, n, m, with_oracle):
