@@ -880,7 +880,18 @@ def test_circle_interpolate_cells_over_determined(gpu_ctx, oracle, L, n, m):
     if R > 1:
         assert gpu_ctx._L.frieda_circle_interpolate_cells_any(gpu_ctx._h, d_cells.ptr, idx.ctypes.data, R - 1, ncols, m, L, n, d_c.ptr, None) == 1
     if (L, n, m) == (3, 5, 0):
-        assert saw_singular_prefix >= 1  # the case this entry exists for did occur
+        # the case this entry exists for, deterministically: these 8 points of the 32-point domain form a singular system
+        # (found by search with the oracle); the exact-count entry refuses them, two spare points repair it
+        sing = np.array([1, 3, 4, 8, 11, 14, 16, 27], dtype=np.uint32)
+        with pytest.raises(ValueError):
+            oracle.reconstruct_cells(np.ascontiguousarray(ev[:, sing].T.reshape(-1, ncols, 1)), sing, n, L)
+        offer = np.concatenate([sing, np.array([2, 30], dtype=np.uint32)])
+        cells = np.ascontiguousarray(ev[:, offer].T.reshape(-1, ncols, 1))
+        d_cells = DevBuf.from_array(gpu_ctx, cells)
+        assert gpu_ctx._L.frieda_circle_interpolate_cells(gpu_ctx._h, d_cells.ptr, offer.ctypes.data, R, ncols, m, L, n, d_c.ptr) == 1
+        used = (C.c_uint32 * R)()
+        _check(gpu_ctx, gpu_ctx._L.frieda_circle_interpolate_cells_any(gpu_ctx._h, d_cells.ptr, offer.ctypes.data, 10, ncols, m, L, n, d_c.ptr, used))
+        assert np.array_equal(d_c.to_array(np.uint32, (ncols, 1 << L)), coef) and max(used) >= 8
 
 
 @pytest.mark.parametrize("L,n,m,with_oracle", [(10, 14, 1, True), (10, 12, 1, False), (12, 16, 2, False), (13, 17, 1, False), (15, 19, 3, False),

@@ -290,3 +290,14 @@ def test_oracle_reconstructs_from_scattered_cells_and_points(oracle, L, n, m):
         assert np.array_equal(got, coef)
         solved += 1
     assert solved >= 6
+
+
+def test_known_singular_point_set_is_reported(oracle):
+    """8 of the 32 points of a 2^5 domain that do NOT determine a 2^3-coefficient polynomial (found by search): the solver says so."""
+    coef = np.arange(1, 9, dtype=np.uint32).reshape(1, 8) * 1234567
+    ev = oracle.circle_evaluate(coef, 5)
+    sing = np.array([1, 3, 4, 8, 11, 14, 16, 27], dtype=np.uint32)
+    with pytest.raises(ValueError):
+        oracle.reconstruct_cells(np.ascontiguousarray(ev[:, sing].T.reshape(-1, 1, 1)), sing, 5, 3)
+    ok = np.array([1, 3, 4, 8, 11, 14, 16, 30], dtype=np.uint32)  # one point exchanged
+    assert np.array_equal(oracle.reconstruct_cells(np.ascontiguousarray(ev[:, ok].T.reshape(-1, 1, 1)), ok, 5, 3), coef)
