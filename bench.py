@@ -674,6 +674,8 @@ def main():
             "achieved_GBps_wall": path_bytes / (dt / args.steps) / 1e9,
             "frac_of_hbm_peak_wall": path_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS,
             "gpu_kernel_ms_per_step": gpu_ms,
+            "launches_per_lone_proof": sum(k["launches"] for k in kern) / args.steps,
+            "launches_per_blob_in_measured_loop": sum(k["launches"] for k in kern) / args.steps / BSZ,
             "host_phase_marks_ms_last_step": host_phases,
             "frac_of_hbm_peak_kernels": (path_bytes / (gpu_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if gpu_ms > 0 else None,
             "kernels": [
