@@ -217,7 +217,15 @@ int Ctx::get_twiddles(uint32_t n, TwiddleSet& out) {
     ts.ds.inv_init_x = m31_inv(seeds.p0.x);
     ts.ds.inv_init_y = m31_inv(seeds.p0.y);
     k::gen_twiddles(launch(), n, seeds, ts.d_tw, ts.d_itw, ts.d_scratch);
-    FR_HIP(this, hipGetLastError());
+    if (const hipError_t e = hipGetLastError(); e != hipSuccess) {
+        // a cached entry must never describe tables that were not generated: drop it (and its buffers) before reporting
+        (void)hipStreamSynchronize(stream);
+        (void)hipFree(ts.d_tw);
+        (void)hipFree(ts.d_itw);
+        (void)hipFree(ts.d_scratch);
+        twiddles.erase(n);
+        return hip_fail(e, "gen_twiddles");
+    }
     twiddles[n] = ts;
     out = ts;
     return FRIEDA_OK;

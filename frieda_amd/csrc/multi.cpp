@@ -235,13 +235,14 @@ int frieda_multi_destroy(frieda_multi* m) {
     if (!m) return FRIEDA_ERR_ARG;
     for (size_t d = 0; d < m->devices.size(); d++) {
         (void)hipSetDevice(m->devices[d]);
+        // (each vector by its own size: creation may have failed between two of the assign() calls)
         if (d < m->comms.size() && m->comms[d]) (void)m->rccl.CommDestroy(m->comms[d]);
-        if (m->gstream[d]) {
+        if (d < m->gstream.size() && m->gstream[d]) {
             (void)hipStreamSynchronize(m->gstream[d]);
             (void)hipStreamDestroy(m->gstream[d]);
         }
-        if (m->d_send[d]) (void)hipFree(m->d_send[d]);
-        if (m->d_recv[d]) (void)hipFree(m->d_recv[d]);
+        if (d < m->d_send.size() && m->d_send[d]) (void)hipFree(m->d_send[d]);
+        if (d < m->d_recv.size() && m->d_recv[d]) (void)hipFree(m->d_recv[d]);
     }
     for (frieda_ctx* c : m->ctx)
         if (c) frieda_ctx_destroy(c);
@@ -376,8 +377,11 @@ int frieda_prove_many(frieda_multi* m, const uint8_t* const* blobs, const size_t
                 frieda_ctx* cx[2] = {m->ctx[2 * d], m->ctx[2 * d + 1]};
                 const uint32_t mine = (uint32_t)local[d].size();
                 if (mine == 0) return;
+                // batches need the device transcript (prover.cpp): small last layers, and neither context switched to the host channel
+                // through frieda_multi_ctx (then equal-length runs go as single proofs instead of failing)
                 const bool batchable = cfg.log_last_layer_degree_bound <= 11 && cfg.log_blowup_factor <= 11 &&
-                                       cfg.log_last_layer_degree_bound + cfg.log_blowup_factor <= 11;  // the device transcript (prover.cpp)
+                                       cfg.log_last_layer_degree_bound + cfg.log_blowup_factor <= 11 && !cx[0]->c.host_channel &&
+                                       !cx[1]->c.host_channel;
                 struct Unit {
                     uint32_t slot, cnt;
                 };
@@ -465,8 +469,17 @@ int frieda_prove_many(frieda_multi* m, const uint8_t* const* blobs, const size_t
             }
         return rc;
     } catch (const std::bad_alloc&) {
+        // (the workers have been joined by JoinAll; whatever they published is handed back to nobody)
+        for (uint32_t i = 0; i < count; i++) {
+            if (out_proofs[i]) frieda_proof_free(out_proofs[i]);
+            out_proofs[i] = nullptr;
+        }
         return m->fail(FRIEDA_ERR_NOMEM, "host allocation failed");
     } catch (const std::exception& e) {
+        for (uint32_t i = 0; i < count; i++) {
+            if (out_proofs[i]) frieda_proof_free(out_proofs[i]);
+            out_proofs[i] = nullptr;
+        }
         return m->fail(FRIEDA_ERR_INVARIANT, e.what());
     }
 }

@@ -27,6 +27,7 @@
 // twice its HBM time.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdlib>
 
 #include "kernels.h"
@@ -573,11 +574,20 @@ uint32_t circle_evaluate_into_tree(const Launch& L_, const uint32_t* d_coef, siz
     uint32_t cpw = cpw_max;
     while (ncols % cpw) cpw--;
     const size_t lds_bytes = (size_t)cpw * TILE_WORDS * sizeof(uint32_t);
-    static bool lds_opt_in = false;  // 4 column tiles = 68 KiB of dynamic LDS: above the 64 KiB default
-    if (!lds_opt_in) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ntt_tile_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)(MAX_COLS_PER_WG * TILE_WORDS * sizeof(uint32_t)));
-        lds_opt_in = true;
+    // 4 column tiles = 68 KiB of dynamic LDS: above the 64 KiB default.  The opt-in belongs to the current device's function
+    // object, and frieda_multi drives several devices from one process (one host thread each): one flag per device, set only
+    // after the attribute call has returned (a thread that loses the race repeats the call, which is harmless).
+    {
+        static std::atomic<bool> lds_opt_in[64];
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        const bool tracked = dev >= 0 && dev < 64;
+        if (!tracked || !lds_opt_in[dev].load(std::memory_order_acquire)) {
+            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ntt_tile_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                     (int)(MAX_COLS_PER_WG * TILE_WORDS * sizeof(uint32_t)));
+            if (e == hipSuccess && tracked) lds_opt_in[dev].store(true, std::memory_order_release);
+            if (e != hipSuccess) (void)hipGetLastError();  // the launch check behind the pass reports a refused launch
+        }
     }
 
     // real layers i = L-1 .. 0; the last pass takes up to 12 of them, the strided passes before it up to 8 each

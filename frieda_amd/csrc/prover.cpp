@@ -397,7 +397,7 @@ int prove_begin_batch_ptrs(Ctx* ctx, const uint8_t* const* blobs, size_t len, ui
 int prove_begin_batch(Ctx* ctx, const uint8_t* data, size_t data_stride, size_t len, uint32_t count, bool data_on_device,
                       const uint64_t* seeds, frieda_pcs_config cfg, const uint8_t* const* host_ptrs) {
     const auto t_entry = std::chrono::steady_clock::now();
-    if (ctx->job) return ctx->fail(FRIEDA_ERR_ARG, "a proof is already in flight on this context");
+    FR_NO_JOB(ctx);  // a proof or a commit batch in flight owns the arena and the pinned block
     if (count == 0 || count > 65535) return ctx->fail(FRIEDA_ERR_ARG, "batch count out of range");
     if (count > 1 && data_stride < len) return ctx->fail(FRIEDA_ERR_ARG, "batch stride smaller than the blob length");
     const uint32_t B = cfg.log_blowup_factor, last = cfg.log_last_layer_degree_bound;

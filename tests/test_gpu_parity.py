@@ -248,9 +248,10 @@ def test_commit_matches_oracle_ragged(gpu_ctx, oracle, n_bytes, B):
 
 
 @pytest.mark.parametrize("n_bytes,B", [(61440, 1), (61440, 4), (61441, 2), (983040, 3)])
-def test_fused_encode_tree_equals_unfused_and_oracle(gpu_ctx, oracle, n_bytes, B, monkeypatch):
+def test_fused_encode_tree_matches_oracle(gpu_ctx, oracle, n_bytes, B):
     """The last transform pass fused with leaf hashing (ntt_last_tree7) against the oracle: commit root, whole proof, and every
-    stored tree level and the evaluation through the openings of 300 queries."""
+    stored tree level and the evaluation through the openings of 300 queries.  (The unfused build variants behind the getenv
+    knobs are read once per process; tests/test_gpu_shapes.py::test_knob_variants_in_subprocess runs them.)"""
     import frieda_amd
 
     data = splitmix64_bytes(77 + B, n_bytes).tobytes()
@@ -500,21 +501,50 @@ def test_cpp_multi_gpu_entry_points(gpu_ctx, n_slots, mode):
     assert f"rccl={0 if mode == 'plain' else 1}" in r.stdout
 
 
-@pytest.mark.skipif(os.environ.get("FRIEDA_TEST_MULTI_GPU") != "1", reason="opt-in: needs a node with >= 2 GPUs (FRIEDA_TEST_MULTI_GPU=1)")
-def test_cpp_multi_gpu_real_rccl():
-    """frieda_commit_many / frieda_prove_many over every visible GPU with the real RCCL root gather (n > 1).  Opt-in: the builder's
-    and the driver's test boxes have one GPU; a maintainer with a node runs FRIEDA_TEST_MULTI_GPU=1 pytest -m gpu -k real_rccl."""
-    import subprocess
-
+def _visible_gpus():
     import torch
+
+    return torch.cuda.device_count()  # counts without initialising the GPU on this image
+
+
+@pytest.mark.skipif(_visible_gpus() < 2, reason="needs a node with >= 2 visible GPUs (runs unprompted wherever there are)")
+def test_cpp_multi_gpu_real_rccl():
+    """frieda_commit_many / frieda_prove_many over every visible GPU with the real RCCL root gather (n > 1), from C++: ragged
+    small blobs (the generic transform kernel's per-device LDS opt-in), the reference's fixture, runs of equal lengths."""
+    import subprocess
 
     from conftest import GOLDEN, ROOT
 
-    n = min(torch.cuda.device_count(), 8)
-    assert n >= 2
+    n = min(_visible_gpus(), 8)
     exe = os.path.join(ROOT, "tests", "cpp", "test_api.bin")
     r = subprocess.run([exe, os.path.join(GOLDEN, "blob"), "multi_real", str(n)], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "rccl=1" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.skipif(_visible_gpus() < 2, reason="needs a node with >= 2 visible GPUs (runs unprompted wherever there are)")
+def test_config4_eight_2p22_blobs_across_all_gpus_real_rccl(oracle):
+    """BASELINE.json configs[3] as written: 8 independent 2^22-domain blobs (generator seeds 100..107, benches/proof.rs:30-44 per
+    blob), one per GPU round-robin over every visible device, roots gathered by the real RCCL all-gather: all 8 roots and all 8
+    proofs byte-identical to the oracle's."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    import frieda_amd
+
+    n = min(_visible_gpus(), 8)
+    blobs = [splitmix64_bytes(100 + i, blob_len_for(22)).tobytes() for i in range(8)]
+    seeds = [len(b) for b in blobs]
+    cfg = _cfg(frieda_amd, 20, 4, 0, 20)
+    ocfg = oracle.make_config(20, 4, 0, 20)
+    with ThreadPoolExecutor(max_workers=8) as ex:
+        expected = list(ex.map(lambda a: oracle.commit_and_generate_proof(a[0], a[1], ocfg), zip(blobs, seeds)))
+    mc = frieda_amd.MultiContext(list(range(n)))
+    assert mc.device_count == n and mc.uses_rccl
+    assert mc.commit_many(blobs, 4) == [r for r, _ in expected]
+    got = mc.prove_many(blobs, seeds, cfg)
+    assert [r for r, _ in got] == [r for r, _ in expected]
+    assert [p.serialize() for _, p in got] == [p.serialize() for _, p in expected]
+    assert mc.gather_count == 2
+    mc.close()
 
 
 def test_multi_context_python_and_rccl_failure_is_loud(gpu_ctx, oracle, monkeypatch):
@@ -1187,12 +1217,12 @@ def test_openings_device_path_host_path_and_fallbacks(gpu_ctx, oracle, monkeypat
 
 
 def test_randomised_parity_short(gpu_ctx):
-    """Ten seconds of tools/fuzz_parity.py: random blob sizes, blow-ups, last-layer bounds, query counts, proof-of-work bits and
+    """Fifteen seconds of tools/fuzz_parity.py: random blob sizes (0 B .. 8 MB), blow-ups, last-layer bounds, query counts, proof-of-work bits and
     seeds, single proofs and batches, every proof byte-compared with the oracle's."""
     import importlib.util
 
     spec = importlib.util.spec_from_file_location("fuzz_parity", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "fuzz_parity.py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
-    n_single, n_batch, _ = mod.run(10.0, 20261003, gpu_ctx)
-    assert n_single > 20
+    n_single, n_batch, _, n_big = mod.run(15.0, 20261003, gpu_ctx)
+    assert n_single > 20 and n_big >= 1  # the first case of a run is a 0.4 - 8 MB blob (strided encode passes)

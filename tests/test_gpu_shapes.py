@@ -1,0 +1,195 @@
+"""GPU: the encode's pass planner (frieda_amd/csrc/ntt.hip, circle_evaluate_into_tree) at MB-scale blob sizes — every branch, against the
+oracle, bit-exact.
+
+`polynomial_from_bytes` (/root/reference/src/utils.rs:21-33) maps ANY byte length to a power-of-two polynomial: L = log2 of the
+coefficients per column, n = L + log_blowup_factor (/root/reference/src/commit.rs:14-16).  The planner splits the L real layers into a
+contiguous last pass of min(L, 12) layers and strided passes over the `rest = L - 12` layers above it, and picks a kernel per pass:
+
+  * `last12`            rest == 0 (L <= 12): only the contiguous pass (reads the coefficients themselves, replicated)
+  * `pad8(pad=k)`       one strided pass of 1..7 real layers run as the fast 8-layer kernel, its top k = 8 - rest layers being zero-padded
+                        layers executed against zero coefficients (needs k <= log_blowup_factor)
+  * `generic(t,w)`      one strided pass of t < 8 layers through the generic kernel with runs of 2^w words (k > log_blowup_factor)
+  * `fast8`             rest == 8: the 8-layer kernel on real layers only
+  * `two(t1+t2)`        rest > 8: two strided passes (generic unless a pass has exactly 8 layers)
+
+`encode_plan` below mirrors that decision so that every test id names the branch it reaches; the product is not told which branch to
+take (the mirror is only used for the ids and to assert that the matrix covers all of them).
+"""
+import ctypes as C
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+import pytest
+
+from conftest import splitmix64_bytes
+from util import DevBuf
+
+pytestmark = pytest.mark.gpu
+
+P = 2**31 - 1
+
+
+def encode_plan(L, B):
+    """Name of the planner branch for 2^L coefficients per column at blow-up 2^B (mirror of ntt.hip's decision, ids only)."""
+    if L <= 12:
+        return "last12"
+    rest = L - 12
+    if rest == 8:
+        return "fast8"
+    if rest < 8:
+        pad = 8 - rest
+        return f"pad8(pad={pad})" if pad <= B and L >= 4 else f"generic(t={rest},w={12 - rest})"
+    t1 = (rest + 1) // 2
+    return f"two({t1}+{rest - t1})"
+
+
+def exact_len(L):
+    """Bytes whose 30-bit felts exactly fill 4 columns of 2^L coefficients."""
+    return (4 << L) * 30 // 8
+
+
+def shape_lengths(L):
+    """exact fill; a ragged length inside the same L; the smallest length with that L (half + 1 byte: columns 2 and 3 all zero)."""
+    e = exact_len(L)
+    return {"exact": e, "ragged": e - 12345, "halfplus1": e // 2 + 1}
+
+
+COMMIT_CASES = []
+for _L in (16, 17, 18, 19, 20, 21):
+    for _B in (1, 2, 4):
+        for _kind, _len in shape_lengths(_L).items():
+            if _L == 21 and _B == 4 and _kind == "halfplus1":
+                continue  # 2^25 domain: two lengths are enough (the oracle needs ~25 s each)
+            COMMIT_CASES.append(pytest.param(_L, _B, _len, id=f"L{_L}-B{_B}-{encode_plan(_L, _B)}-{_kind}"))
+# the padded 8-layer pass with 5..7 zero layers needs a blow-up of at least 2^5; and rest 1..3 below it
+for _L, _B in ((13, 7), (14, 6), (15, 5), (13, 5), (14, 5), (15, 8)):
+    COMMIT_CASES.append(pytest.param(_L, _B, exact_len(_L) - 777, id=f"L{_L}-B{_B}-{encode_plan(_L, _B)}-ragged"))
+
+
+def test_matrix_reaches_every_planner_branch():
+    seen = {c.id.split("-")[2].split("(")[0] for c in COMMIT_CASES}
+    assert {"pad8", "generic", "fast8", "two"} <= seen
+    pads = {c.id.split("-")[2] for c in COMMIT_CASES if "pad8" in c.id}
+    assert {f"pad8(pad={k})" for k in range(1, 8)} <= pads
+    for L in (16, 17, 18, 19, 20, 21):
+        fp = 4
+        F = (8 * shape_lengths(L)["halfplus1"] + 29) // 30
+        while fp < F:
+            fp *= 2
+        assert fp == 4 << L  # half + 1 byte still has 2^L coefficients per column
+
+
+@pytest.fixture(scope="module")
+def oracle_roots(oracle):
+    """commit() roots of every case from the CPU oracle, computed on a few host threads (the C oracle releases the GIL)."""
+    keys = sorted({(c.values[2], c.values[1], c.values[0]) for c in COMMIT_CASES}, key=lambda k: -(k[2] + k[1]))
+
+    def one(k):
+        length, B, L = k
+        return k, oracle.commit(splitmix64_bytes(1000 + L * 8 + B, length).tobytes(), B)
+
+    with ThreadPoolExecutor(max_workers=6) as ex:  # <= 6 x 2.7 GB of oracle workspace at the 2^25 domain
+        return dict(ex.map(one, keys))
+
+
+@pytest.mark.parametrize("L,B,length", COMMIT_CASES)
+def test_commit_root_mb_scale_shapes(gpu_ctx, oracle, oracle_roots, L, B, length):
+    """commit() (/root/reference/src/commit.rs:11-22) at blob sizes 0.5 .. 8 MB, blow-ups 2, 4, 16: root equal to the oracle's."""
+    data = splitmix64_bytes(1000 + L * 8 + B, length)
+    coef, lg = oracle.polynomial_from_bytes(data[: min(length, 64)])  # cheap sanity of the helper itself
+    nf, npad, lgs = C.c_size_t(), C.c_size_t(), C.c_uint32()
+    gpu_ctx._L.frieda_codec_shape(length, C.byref(nf), C.byref(npad), C.byref(lgs))
+    assert lgs.value == L, "the length does not have the shape its id claims"
+    assert gpu_ctx.commit(data.tobytes(), B) == oracle_roots[(length, B, L)]
+
+
+PROVE_CASES = [
+    # (L, B, length kind, pow, last, queries)
+    (17, 4, "exact", 12, 0, 20),  # 2^21 domain
+    (19, 4, "ragged", 10, 0, 20),  # 2^23 domain
+    (17, 2, "ragged", 8, 1, 33),  # generic single pass (pad 3 > B)
+    (18, 1, "exact", 8, 0, 20),  # generic single pass (pad 2 > B), 2^19 domain
+    (21, 1, "ragged", 6, 2, 20),  # two strided passes, 2^22 domain
+    (16, 3, "halfplus1", 8, 0, 20),  # generic (pad 4 > B), 2^19 domain
+    (14, 6, "ragged", 6, 0, 20),  # pad 6
+    (15, 5, "exact", 6, 3, 20),  # pad 5
+    (13, 7, "ragged", 6, 0, 20),  # pad 7
+]
+
+
+@pytest.mark.parametrize("L,B,kind,pow_bits,last,nq", PROVE_CASES, ids=[f"L{c[0]}-B{c[1]}-{encode_plan(c[0], c[1])}-{c[2]}" for c in PROVE_CASES])
+def test_whole_proof_mb_scale_shapes(gpu_ctx, oracle, L, B, kind, pow_bits, last, nq):
+    """commit_and_generate_proof (/root/reference/src/proof.rs:32-77) on odd domains and ragged MB-scale lengths: the whole proof
+    byte-identical to the oracle's (the first tree after the fused kernel starts from 2^(n-6) hashes with n odd as well as even)."""
+    import frieda_amd
+
+    length = shape_lengths(L)[kind]
+    data = splitmix64_bytes(2000 + L * 8 + B, length).tobytes()
+    cfg = frieda_amd.PcsConfig(frieda_amd.FriConfig(B, last, nq), pow_bits)
+    g_root, g_proof = gpu_ctx.commit_and_generate_proof(data, length, cfg)
+    o_root, o_proof = oracle.commit_and_generate_proof(data, length, oracle.make_config(pow_bits, B, last, nq))
+    assert g_root == o_root
+    assert g_proof.n_inner_layers == L + B - 1 - B - last
+    assert g_proof.serialize() == o_proof.serialize()
+    assert frieda_amd.verify(g_proof, length)
+
+
+EVAL_CASES = [(17, 21), (19, 23), (17, 18), (19, 20), (21, 25), (21, 22), (18, 19), (16, 17), (22, 23), (20, 24)]
+
+
+@pytest.mark.parametrize("ncols", [1, 4])
+@pytest.mark.parametrize("L,n", EVAL_CASES, ids=[f"L{L}-n{n}-{encode_plan(L, n - L)}" for L, n in EVAL_CASES])
+def test_circle_evaluate_mb_scale_shapes(gpu_ctx, oracle, L, n, ncols):
+    """Level B `PolyOps::evaluate` (frieda_circle_evaluate) per column on the same shapes, 1 and 4 columns, every output word."""
+    if n == 25 and ncols == 4:
+        ncols = 2  # two columns share a workgroup (the 4-column shape is covered by commit() at L = 21, B = 4)
+    rng = np.random.default_rng(500 + 32 * L + n)
+    coef = rng.integers(0, P, (ncols, 1 << L), dtype=np.uint32)
+    tw, _ = oracle.precompute_twiddles(n)
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        exp = np.concatenate(list(ex.map(lambda c: oracle.circle_evaluate(coef[c : c + 1], n, tw), range(ncols))))
+    d_c = DevBuf.from_array(gpu_ctx, coef)
+    d_o = DevBuf(gpu_ctx, 4 * ncols << n)
+    from frieda_amd.api import _check
+
+    _check(gpu_ctx._L.frieda_circle_evaluate(gpu_ctx._h, d_c.ptr, ncols, L, n, d_o.ptr), gpu_ctx._h)
+    got = d_o.to_array(np.uint32, (ncols, 1 << n))
+    assert np.array_equal(got, exp)
+
+
+KNOB_SCRIPT = r"""
+import sys
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
+import frieda_amd
+from oracle import oracle as O
+from conftest import splitmix64_bytes
+ctx = frieda_amd.Context(0)
+for L, B in ((16, 4), (18, 2), (13, 7), (12, 4)):
+    length = (4 << L) * 30 // 8 - 4321
+    data = splitmix64_bytes(3000 + L, length).tobytes()
+    assert ctx.commit(data, B) == O.commit(data, B), ("commit", L, B)
+    cfg = frieda_amd.PcsConfig(frieda_amd.FriConfig(B, 0, 40), 6)
+    r, p = ctx.commit_and_generate_proof(data, 9, cfg)
+    o_r, o_p = O.commit_and_generate_proof(data, 9, O.make_config(6, B, 0, 40))
+    assert r == o_r and p.serialize() == o_p.serialize(), ("prove", L, B)
+print("knob ok")
+"""
+
+
+@pytest.mark.parametrize("knob", ["FRIEDA_NO_ENCODE_TREE_FUSION", "FRIEDA_NTT_NO_PAD8", "FRIEDA_NTT_TREE_REG_ONLY", "FRIEDA_T5_REG3_LOG=18", "FRIEDA_NTT_CPW=2",
+                                  "FRIEDA_HOST_DECOMMIT"])
+def test_knob_variants_in_subprocess(gpu_ctx, knob):
+    """The A/B knobs of DESIGN.md §8b select other kernels / templates for the same result (unfused encode + leaf launch, generic
+    strided pass instead of the padded 8-layer one, the register-only tree variants).  They are read once per process, so each
+    variant runs in a child process: commit root and whole proof against the oracle on four shapes."""
+    import os
+    import subprocess
+    import sys
+
+    from conftest import ROOT
+
+    env = dict(os.environ)
+    name, _, val = knob.partition("=")
+    env[name] = val or "1"
+    r = subprocess.run([sys.executable, "-c", KNOB_SCRIPT, ROOT], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and "knob ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
