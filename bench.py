@@ -98,18 +98,22 @@ def traffic_from_profiles(kernel, n, workload):
 
 
 def _host_threads():
-    """threads the CPU baseline may use: the cores this process may run on, capped at the GPU box's share per GPU (16)"""
+    """threads of the multi-core CPU baseline: the cores this process may run on (sched_getaffinity), capped at
+    FRIEDA_BENCH_CPU_THREADS (default 32 = one GPU's share of a 256-core, 8-GPU host; each thread holds ~0.7 GB of oracle workspace
+    at the 2^22 sample, so the cap also bounds host memory)"""
     try:
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
         avail = os.cpu_count() or 1
-    return max(1, min(avail, int(os.environ.get("FRIEDA_BENCH_CPU_THREADS", "16"))))
+    cap = int(os.environ.get("FRIEDA_BENCH_CPU_THREADS", "32"))
+    return max(1, min(avail, cap))
 
 
 def cpu_baseline(sample_log, workload, calls, all_cores_log=22):
     """The CPU oracle (oracle/, a restated port of the reference's single-threaded CPU path; the reference itself is Rust +
     un-vendored stwo and cannot be built here) timed on this host: (1) one thread — the reference has no parallelism at all
-    (stwo pulled without `parallel`, Cargo.toml:12); (2) all usable cores, one independent blob per core."""
+    (stwo pulled without `parallel`, Cargo.toml:12); (2) `multi_core`: one independent blob per thread on min(usable cores, 32)
+    threads (the line says how many and whether that is every usable core)."""
     from concurrent.futures import ThreadPoolExecutor
 
     from oracle import oracle as O
@@ -145,13 +149,19 @@ def cpu_baseline(sample_log, workload, calls, all_cores_log=22):
     with ThreadPoolExecutor(max_workers=threads) as ex:
         roots = list(ex.map(run, blobs))
     dta = time.perf_counter() - t0
-    out["all_cores"] = {
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except AttributeError:
+        usable = os.cpu_count() or 1
+    out["multi_core"] = {
         "value": 4.0 * (1 << all_cores_log) * threads / dta,
         "unit": "M31 field-elems/s",
         "cores": threads,
+        "usable_cores": usable,
+        "all_usable_cores": threads == usable,
         "nproc": os.cpu_count(),
-        "sample": f"{threads} distinct blobs, one {name} on a 2^{all_cores_log} domain per core, {threads} threads of the "
-        f"{os.cpu_count()} cores visible here (nproc), {dta:.1f} s wall",
+        "sample": f"{threads} distinct blobs, one {name} on a 2^{all_cores_log} domain per thread, {threads} threads = "
+        f"{'every core' if threads == usable else 'a capped share of the cores'} this process may run on ({usable} of {os.cpu_count()} on the host), {dta:.1f} s wall",
         "first_root": bytes(roots[0]).hex(),
     }
     return out
@@ -207,6 +217,160 @@ def reference_bench_sizes(ctx, frieda_amd, torch):
     return rows
 
 
+def measure_config(frieda_amd, torch, device, n, workload, K, BSZ, D, cfg):
+    """The measured loop of main() on another BASELINE configuration (benches/commit.rs:6-13,
+    benches/proof.rs:30-44): K distinct device-resident blobs of a 2^n domain (generator seeds 100 + i) through
+    `commit_and_generate_proof` (BSZ per call, D calls in flight) or `commit`, every proof verified; then the lone-call latency and the
+    dominant kernel of an instrumented replay.  Fractions are algorithmic bytes / time against the 8 TB/s HBM peak."""
+    blob_len = blob_len_for(n)
+    seed = blob_len
+    blobs = torch.empty((K, blob_len), dtype=torch.uint8, device="cuda")
+    for i in range(K):
+        blobs[i].copy_(torch.from_numpy(splitmix64_bytes(100 + i, blob_len)))
+    ctx = frieda_amd.Context(device)
+    roots_dev = torch.zeros(32 * K, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    elems = 4.0 * (1 << n)
+    path_bytes = algorithmic_bytes(n, workload)
+    out = {"log_domain": n, "workload": "commit_and_generate_proof" if workload == "prove" else "commit", "blob_bytes": blob_len, "blobs": K}
+    if workload == "prove":
+        pipe = frieda_amd.BatchPipeline(device, D) if BSZ > 1 else frieda_amd.ProofPipeline(device, D)
+
+        def run():
+            res = []
+            for i in range(0, K, BSZ):
+                cnt = min(BSZ, K - i)
+                if BSZ > 1:
+                    r = pipe.submit_device(blobs[i].data_ptr(), blob_len, blob_len, cnt, [seed] * cnt, cfg)
+                    if r is not None:
+                        res.extend(r)
+                else:
+                    r = pipe.submit_device(blobs[i].data_ptr(), blob_len, seed, cfg)
+                    if r is not None:
+                        res.append(r)
+            res.extend(pipe.drain())
+            return res
+
+        run()  # sizes the workspaces, builds the twiddles
+        run()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        res = run()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / K
+        assert len(res) == K and len({r for r, _ in res}) == K
+        for r, p in res:
+            assert p.commitment == r and frieda_amd.verify(p, seed), "a timed proof does not verify"
+        out["measured_loop"] = f"{BSZ} blobs per call, {D} calls in flight"
+        out["verified_proofs"] = K
+        root0 = res[0][0]
+        del res
+        pipe.close()
+
+        def lone():
+            return ctx.commit_and_generate_proof_device(blobs[0].data_ptr(), blob_len, seed, cfg)
+    else:
+        def run():
+            for i in range(K):
+                ctx.commit_device(blobs[i].data_ptr(), blob_len, 4, roots_dev.data_ptr() + 32 * i)
+            ctx.synchronize()
+
+        run()
+        run()
+        t0 = time.perf_counter()
+        run()
+        dt = (time.perf_counter() - t0) / K
+        out["measured_loop"] = "commit_device per blob, asynchronous, one context"
+        root0 = bytes(roots_dev[:32].cpu().numpy())
+        assert len({bytes(roots_dev[32 * i : 32 * i + 32].cpu().numpy()) for i in range(K)}) == K
+
+        def lone():
+            ctx.commit_device(blobs[0].data_ptr(), blob_len, 4, roots_dev.data_ptr())
+            ctx.synchronize()
+            return bytes(roots_dev[:32].cpu().numpy()), None
+
+    out.update({"ms_per_blob": 1e3 * dt, "value": elems / dt, "unit": "M31 field-elems/s", "frac_of_hbm_peak_wall": path_bytes / dt / 1e9 / HBM_PEAK_GBS,
+                "root": root0.hex()})
+    # a lone call: one blob at a time, synchronised
+    reps = 20
+    lone()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        r_l, _p = lone()
+    torch.cuda.synchronize()
+    dtl = (time.perf_counter() - t0) / reps
+    assert r_l == root0
+    out["lone_call"] = {"ms": 1e3 * dtl, "frac_of_hbm_peak": path_bytes / dtl / 1e9 / HBM_PEAK_GBS}
+    # dominant kernel of a lone call (HIP events on the context's stream)
+    ctx.set_kernel_timing(True)
+    for _ in range(5):
+        lone()
+    kern = ctx.kernel_timing_report(reset=True)
+    ctx.set_kernel_timing(False)
+    if kern:
+        kern.sort(key=lambda k: -k["total_ms"])
+        dom = kern[0]
+        ach = dom["alg_bytes"] / (dom["total_ms"] * 1e-3) / 1e9 if dom["total_ms"] > 0 else 0.0
+        out["dominant_kernel"] = {"kernel": dom["name"], "avg_launch_us": 1e3 * dom["total_ms"] / max(dom["launches"], 1), "achieved_GBps": ach,
+                                  "frac": ach / HBM_PEAK_GBS, "gpu_kernel_ms_per_call": sum(k["total_ms"] for k in kern) / 5,
+                                  "launches_per_call": sum(k["launches"] for k in kern) / 5}
+    ctx.close()
+    del blobs
+    return out
+
+
+def end_to_end(frieda_amd, torch, device, n, K, cfg, expect_roots=None):
+    """The reference API takes HOST bytes (`data: &[u8]`, /root/reference/src/lib.rs:31,36): the same stream of K distinct blobs
+    handed over in host memory — pageable (what a Rust caller has) and page-locked — through the C ABI's throughput entry points
+    (frieda_prove_many / frieda_commit_many on one device: uploads run ahead of the kernels on a copy stream), and one lone
+    `frieda_commit_and_generate_proof` call.  PCIe-inclusive; never `value`."""
+    blob_len = blob_len_for(n)
+    seeds = [blob_len] * K
+    pageable = [splitmix64_bytes(100 + i, blob_len) for i in range(K)]
+    mc = frieda_amd.MultiContext([device])
+    out = {"blobs": K, "blob_bytes": blob_len, "entry_points": "frieda_prove_many / frieda_commit_many (one device, host blobs), frieda_commit_and_generate_proof"}
+    mc.prove_many(pageable[: min(K, 8)], seeds[: min(K, 8)], cfg)  # sizes workspaces and the upload ring
+    mc.commit_many(pageable[: min(K, 8)], 4)
+
+    def timed(blobs):
+        t0 = time.perf_counter()
+        res = mc.prove_many(blobs, seeds, cfg)
+        dtp = (time.perf_counter() - t0) / K
+        roots = [r for r, _ in res]
+        assert len(set(roots)) == K and all(frieda_amd.verify(p, s) for (_, p), s in zip(res, seeds)), "an end-to-end proof does not verify"
+        del res
+        t0 = time.perf_counter()
+        croots = mc.commit_many(blobs, 4)
+        dtc = (time.perf_counter() - t0) / K
+        assert croots == roots
+        if expect_roots is not None:
+            assert roots[: len(expect_roots)] == expect_roots[: len(roots)], "host-blob roots differ from the device-resident run's"
+        return 1e3 * dtp, 1e3 * dtc
+
+    out["pageable_ms_per_blob"], out["pageable_commit_ms_per_blob"] = timed(pageable)
+    keep = [torch.from_numpy(b).pin_memory() for b in pageable]
+    out["pinned_ms_per_blob"], out["pinned_commit_ms_per_blob"] = timed([t.numpy() for t in keep])
+    del keep
+    mc.close()
+    ctx = frieda_amd.Context(device)
+    ctx.commit_and_generate_proof(pageable[0], blob_len, cfg)
+    reps = 10
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        ctx.commit_and_generate_proof(pageable[0], blob_len, cfg)
+    out["lone_call_ms"] = 1e3 * (time.perf_counter() - t0) / reps
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        ctx.commit(pageable[0], 4)
+    out["lone_commit_call_ms"] = 1e3 * (time.perf_counter() - t0) / reps
+    ctx.close()
+    elems = 4.0 * (1 << n)
+    out["pageable_value"] = elems / (out["pageable_ms_per_blob"] * 1e-3)
+    out["unit"] = "M31 field-elems/s"
+    return out
+
+
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -224,6 +388,8 @@ def parse_args(argv=None):
                     help="blobs per call in the measured loop: > 1 uses the batched entry points (every kernel launched once per batch); 1 = one blob per call")
     ap.add_argument("--pipeline-depth", type=int, default=None, help="deprecated alias: 0 means --in-flight 1")
     ap.add_argument("--sequential-extra", type=int, default=20, help="proofs for the extra one-at-a-time figure (0 = skip)")
+    ap.add_argument("--no-by-config", action="store_true", help="skip the by_config block (the other BASELINE configurations)")
+    ap.add_argument("--no-end-to-end", action="store_true", help="skip the end_to_end block (host blobs, PCIe-inclusive)")
     ap.add_argument("--dry-collective", choices=["gloo"], default=None,
                     help="CPU rehearsal of the N > 1 plumbing: launcher, rendezvous, barriers, root all_gather and max-reduce over gloo; GPU work stubbed")
     ap.add_argument("--launch-timeout", type=float, default=1500.0, help="seconds the self-launcher waits for its ranks")
@@ -240,6 +406,13 @@ def launch_ranks(args):
     import subprocess
 
     n = args.gpus
+    if not args.dry_collective:
+        import torch  # device_count() does not initialise the GPU on this image: the parent stays free to spawn
+
+        have = torch.cuda.device_count()
+        if have < n:
+            sys.stderr.write(f"bench.py: --gpus {n} but only {have} GPU(s) are visible (HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES?): not starting any rank\n")
+            return 2
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
@@ -348,8 +521,13 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: start one rank per GPU (or drop WORLD_SIZE and let bench.py launch them)")
+    visible = torch.cuda.device_count()
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    if visible < 1 or (visible < local_world and visible != 1):
+        # (exactly one visible device per rank is the launcher-narrowed case: every rank then uses device 0)
+        raise SystemExit(f"bench.py: {local_world} ranks on this node but only {visible} GPU(s) visible to rank {rank}: one GPU per rank is the contract")
     # one rank per GPU; if the launcher narrowed the visible devices per rank, index what is visible
-    local_rank = local_rank % max(torch.cuda.device_count(), 1)
+    local_rank = local_rank % max(visible, 1)
     torch.cuda.set_device(local_rank)
     dist = None
     # FRIEDA_BENCH_FORCE_DIST=1 exercises the collective path (RCCL init, all_gather of roots, barrier, max-reduce) with a
@@ -490,6 +668,7 @@ def main():
         ctx.synchronize()
         assert bytes(roots_dev.cpu().numpy()) == root, "first FRI root != commit() root"
         proof0_image = proof.serialize()
+        timed_roots = [r for r, _ in results]
         del results
     else:
         ctx.synchronize()
@@ -688,6 +867,21 @@ def main():
         "verified_proofs": verified,
         "root": root.hex() if root else None,
     }
+    if rank == 0 and world == 1 and not args.no_end_to_end and args.workload == "prove":
+        k_e2e = max(8, min(32, (K // 8) * 8))
+        out["end_to_end"] = end_to_end(frieda_amd, torch, local_rank, n, k_e2e, cfg, timed_roots)  # (same generator seeds: same roots)
+        out["end_to_end"]["device_resident_ms_per_blob"] = 1e3 * dt / args.steps
+    if rank == 0 and world == 1 and not args.no_by_config:
+        # the other BASELINE.json configurations through the same measured loop (configs[1]-[3]: 2^20 and 2^22 domains; commit() at
+        # the headline size), so that the driver-run line carries them
+        rows = []
+        for (cn, cw) in ((20, "prove"), (22, "prove"), (24, "prove"), (22, "commit"), (24, "commit")):
+            if cn == n and cw == args.workload and BSZ == 4 and D == 2:
+                continue  # that is `value` itself
+            if cn > n:
+                continue  # (small test runs: nothing above the headline size)
+            rows.append(measure_config(frieda_amd, torch, local_rank, cn, cw, 64 if cn <= 22 else 20, 4 if cw == "prove" else 1, 2 if cw == "prove" else 1, cfg))
+        out["by_config"] = rows
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cb = cpu_baseline(args.cpu_sample_log, args.workload, 2 if args.cpu_sample_log <= 22 else 1, all_cores_log=min(22, args.cpu_sample_log))
         if args.cpu_sample_log == n:  # the very same blob and configuration: the CPU root must be the GPU root

@@ -16,6 +16,7 @@
 #include <dlfcn.h>
 #include <string.h>
 
+#include <algorithm>
 #include <atomic>
 #include <cstdio>
 #include <cstdlib>
@@ -97,9 +98,25 @@ static void drain_ctx(frieda_ctx* c) {
 
 constexpr uint32_t MULTI_UNIT = 4;  // equal-length blobs handed to a device per call (the batched kernels)
 
+// Host blobs travel ahead of their kernels.  The two contexts of a device finish their units at about the same time (two launches
+// of the same kernel share the chip evenly), so an upload enqueued on a context's own stream at `begin` would run with the chip
+// idle (measured: 1.15 ms per unit of four 15.7 MB blobs, 0.3 ms per blob — profiles/r03_multi_trace_before.txt).  Instead
+// each device has a copy stream and three staging slots in device memory: the blobs of unit u + 2 are uploaded while units u and
+// u + 1 compute, an event orders the unit's first kernel behind its upload, and the kernels read the blobs where they landed.
+constexpr uint32_t RING_SLOTS = 3;
+struct UploadRing {
+    hipStream_t stream = nullptr;
+    hipEvent_t ready[RING_SLOTS] = {};
+    uint8_t* slot[RING_SLOTS] = {};
+    size_t cap = 0;  // bytes per slot
+};
+inline size_t ring_stride(size_t len) { return (len + 255) & ~(size_t)255; }
+
 struct frieda_multi {
     std::vector<int> devices;
     std::vector<frieda_ctx*> ctx;        // 2 per device: [2 d], [2 d + 1]
+    std::vector<UploadRing> ring;        // per device
+    bool prefetch = true;                // FRIEDA_MULTI_NO_PREFETCH=1: uploads on the contexts' own streams at begin (round 2's path; A/B knob)
     std::vector<hipStream_t> gstream;    // per device: the stream the gather runs on
     std::vector<uint8_t*> d_send, d_recv;
     size_t slot_cap = 0;                 // roots per device the gather buffers hold
@@ -114,8 +131,56 @@ struct frieda_multi {
         return code;
     }
     int ensure_gather_buffers(size_t slots);
+    // device d's worker thread only: slots of at least `bytes` each (grown between calls: nothing is in flight on the copy stream then)
+    int ensure_ring(size_t d, size_t bytes, std::string& what);
+    // enqueue the upload of `cnt` host blobs of `len` bytes (blob k at ptrs[k]) into slot `s` of device d; records ready[s]
+    int upload(size_t d, uint32_t s, const uint8_t* const* ptrs, size_t len, uint32_t cnt, std::string& what);
     int gather_roots(const std::vector<std::vector<Hash32>>& local, uint32_t count, uint8_t* out_roots);
 };
+
+int frieda_multi::ensure_ring(size_t d, size_t bytes, std::string& what) {
+    UploadRing& r = ring[d];
+    if (bytes < 256) bytes = 256;
+    if (r.cap >= bytes) return FRIEDA_OK;
+    if (hipSetDevice(devices[d]) != hipSuccess || hipStreamSynchronize(r.stream) != hipSuccess) {
+        what = "hipStreamSynchronize(upload stream)";
+        return FRIEDA_ERR_HIP;
+    }
+    size_t cap = (size_t)1 << 20;
+    while (cap < bytes) cap *= 2;
+    for (uint32_t k = 0; k < RING_SLOTS; k++) {
+        if (r.slot[k]) (void)hipFree(r.slot[k]);
+        r.slot[k] = nullptr;
+    }
+    r.cap = 0;
+    for (uint32_t k = 0; k < RING_SLOTS; k++)
+        if (hipMalloc((void**)&r.slot[k], cap) != hipSuccess) {
+            (void)hipGetLastError();
+            what = "hipMalloc(upload ring, " + std::to_string(cap) + " B)";
+            return FRIEDA_ERR_NOMEM;
+        }
+    r.cap = cap;
+    return FRIEDA_OK;
+}
+
+int frieda_multi::upload(size_t d, uint32_t s, const uint8_t* const* ptrs, size_t len, uint32_t cnt, std::string& what) {
+    UploadRing& r = ring[d];
+    const size_t stride = ring_stride(len);
+    if (stride * cnt > r.cap && len) {
+        what = "internal: upload ring slot too small";
+        return FRIEDA_ERR_INVARIANT;
+    }
+    for (uint32_t k = 0; k < cnt && len; k++)
+        if (hipMemcpyAsync(r.slot[s] + k * stride, ptrs[k], len, hipMemcpyHostToDevice, r.stream) != hipSuccess) {
+            what = "hipMemcpyAsync(blob upload)";
+            return FRIEDA_ERR_HIP;
+        }
+    if (hipEventRecord(r.ready[s], r.stream) != hipSuccess) {
+        what = "hipEventRecord(blob upload)";
+        return FRIEDA_ERR_HIP;
+    }
+    return FRIEDA_OK;
+}
 
 int frieda_multi::ensure_gather_buffers(size_t slots) {
     if (slots <= slot_cap) return FRIEDA_OK;
@@ -196,11 +261,19 @@ int frieda_multi_create(const int* devices, uint32_t n_devices, frieda_multi** o
         m->gstream.assign(n_devices, nullptr);
         m->d_send.assign(n_devices, nullptr);
         m->d_recv.assign(n_devices, nullptr);
+        m->ring.assign(n_devices, UploadRing{});
+        {
+            const char* np = getenv("FRIEDA_MULTI_NO_PREFETCH");
+            m->prefetch = !(np && *np == '1');
+        }
         int rc = FRIEDA_OK;
         for (uint32_t d = 0; d < n_devices && rc == FRIEDA_OK; d++) {
             for (int k = 0; k < 2 && rc == FRIEDA_OK; k++) rc = frieda_ctx_create(devices[d], nullptr, &m->ctx[2 * d + k]);
             if (rc == FRIEDA_OK && (hipSetDevice(devices[d]) != hipSuccess || hipStreamCreateWithFlags(&m->gstream[d], hipStreamNonBlocking) != hipSuccess))
                 rc = FRIEDA_ERR_HIP;
+            if (rc == FRIEDA_OK && hipStreamCreateWithFlags(&m->ring[d].stream, hipStreamNonBlocking) != hipSuccess) rc = FRIEDA_ERR_HIP;
+            for (uint32_t k = 0; k < RING_SLOTS && rc == FRIEDA_OK; k++)
+                if (hipEventCreateWithFlags(&m->ring[d].ready[k], hipEventDisableTiming) != hipSuccess) rc = FRIEDA_ERR_HIP;
         }
         const char* force = getenv("FRIEDA_MULTI_FORCE_RCCL");
         m->use_rccl = n_devices > 1 || (force && *force == '1');
@@ -233,6 +306,10 @@ int frieda_multi_create(const int* devices, uint32_t n_devices, frieda_multi** o
 
 int frieda_multi_destroy(frieda_multi* m) {
     if (!m) return FRIEDA_ERR_ARG;
+    for (frieda_ctx*& c : m->ctx) {  // first: a context synchronises its stream, whose kernels may read the upload ring
+        if (c) frieda_ctx_destroy(c);
+        c = nullptr;
+    }
     for (size_t d = 0; d < m->devices.size(); d++) {
         (void)hipSetDevice(m->devices[d]);
         // (each vector by its own size: creation may have failed between two of the assign() calls)
@@ -243,9 +320,16 @@ int frieda_multi_destroy(frieda_multi* m) {
         }
         if (d < m->d_send.size() && m->d_send[d]) (void)hipFree(m->d_send[d]);
         if (d < m->d_recv.size() && m->d_recv[d]) (void)hipFree(m->d_recv[d]);
+        if (d < m->ring.size()) {
+            UploadRing& r = m->ring[d];
+            if (r.stream) (void)hipStreamSynchronize(r.stream);
+            for (uint32_t k = 0; k < RING_SLOTS; k++) {
+                if (r.ready[k]) (void)hipEventDestroy(r.ready[k]);
+                if (r.slot[k]) (void)hipFree(r.slot[k]);
+            }
+            if (r.stream) (void)hipStreamDestroy(r.stream);
+        }
     }
-    for (frieda_ctx* c : m->ctx)
-        if (c) frieda_ctx_destroy(c);
     // the RCCL handle stays open: other users of the process (PyTorch) may share the instance
     delete m;
     return FRIEDA_OK;
@@ -278,37 +362,71 @@ int frieda_commit_many(frieda_multi* m, const uint8_t* const* blobs, const size_
         for (size_t d = 0; d < n; d++) {
             workers.emplace_back([&, d] {
                 frieda_ctx* cx[2] = {m->ctx[2 * d], m->ctx[2 * d + 1]};
+                const bool pf = m->prefetch;
+                struct DrainUploads {  // no upload may still be reading the caller's blobs when the worker returns
+                    frieda_multi* m;
+                    size_t d;
+                    bool on;
+                    ~DrainUploads() {
+                        if (on) (void)hipStreamSynchronize(m->ring[d].stream);
+                    }
+                } drain_uploads{m, d, pf};
                 try {
                     // This device's blobs in order, cut into units (a run of up to MULTI_UNIT blobs of one length = one call of the
-                    // batched kernels); two units in flight on the two contexts, so that the upload of one runs under the kernels of
-                    // the other.
+                    // batched kernels); two units in flight on the two contexts, the blobs of the unit after them being uploaded
+                    // meanwhile on the copy stream.
                     const uint32_t mine = (uint32_t)local[d].size();
                     struct Unit {
                         uint32_t slot, cnt;
                     };
                     std::vector<Unit> units;
+                    size_t ring_need = 0;
                     for (uint32_t slot = 0; slot < mine;) {
                         const uint32_t i0 = (uint32_t)d + slot * (uint32_t)n;
                         uint32_t cnt = 1;
                         while (cnt < MULTI_UNIT && slot + cnt < mine && lens[i0 + cnt * n] == lens[i0]) cnt++;
                         units.push_back(Unit{slot, cnt});
+                        ring_need = std::max(ring_need, ring_stride(lens[i0]) * cnt);
                         slot += cnt;
                     }
-                    auto begin = [&](size_t u) {
-                        const uint32_t i0 = (uint32_t)d + units[u].slot * (uint32_t)n;
-                        const uint8_t* ptrs[MULTI_UNIT];
-                        for (uint32_t k = 0; k < units[u].cnt; k++) ptrs[k] = blobs[i0 + k * n];
-                        return commit_batch_begin(&cx[u & 1]->c, ptrs[0], lens[i0], lens[i0], units[u].cnt, false, log_blowup_factor, ptrs);
-                    };
-                    auto bail = [&](int rc, frieda_ctx* c) {
+                    auto bail_msg = [&](int rc, const std::string& msg) {
                         if (status[d] == FRIEDA_OK) {
                             status[d] = rc;
-                            what[d] = c->c.err;
+                            what[d] = msg;
                         }
                         abort.store(true);
                     };
+                    auto bail = [&](int rc, frieda_ctx* c) { bail_msg(rc, c->c.err); };
                     if (units.empty()) return;
-                    int rc = begin(0);
+                    if (hipSetDevice(m->devices[d]) != hipSuccess) return bail_msg(FRIEDA_ERR_HIP, "hipSetDevice");
+                    std::string uw;
+                    if (pf) {
+                        const int rr = m->ensure_ring(d, ring_need, uw);
+                        if (rr != FRIEDA_OK) return bail_msg(rr, uw);
+                    }
+                    auto upload = [&](size_t u) {
+                        const uint32_t i0 = (uint32_t)d + units[u].slot * (uint32_t)n;
+                        const uint8_t* ptrs[MULTI_UNIT];
+                        for (uint32_t k = 0; k < units[u].cnt; k++) ptrs[k] = blobs[i0 + k * n];
+                        return m->upload(d, (uint32_t)(u % RING_SLOTS), ptrs, lens[i0], units[u].cnt, uw);
+                    };
+                    auto begin = [&](size_t u) {
+                        const uint32_t i0 = (uint32_t)d + units[u].slot * (uint32_t)n;
+                        Ctx* c = &cx[u & 1]->c;
+                        if (pf) {
+                            if (hipStreamWaitEvent(c->stream, m->ring[d].ready[u % RING_SLOTS], 0) != hipSuccess)
+                                return c->fail(FRIEDA_ERR_HIP, "hipStreamWaitEvent(blob upload)");
+                            return commit_batch_begin(c, m->ring[d].slot[u % RING_SLOTS], ring_stride(lens[i0]), lens[i0], units[u].cnt, true,
+                                                      log_blowup_factor, nullptr);
+                        }
+                        const uint8_t* ptrs[MULTI_UNIT];
+                        for (uint32_t k = 0; k < units[u].cnt; k++) ptrs[k] = blobs[i0 + k * n];
+                        return commit_batch_begin(c, ptrs[0], lens[i0], lens[i0], units[u].cnt, false, log_blowup_factor, ptrs);
+                    };
+                    int rc = FRIEDA_OK;
+                    for (size_t u = 0; pf && u < 2 && u < units.size() && rc == FRIEDA_OK; u++) rc = upload(u);
+                    if (rc != FRIEDA_OK) return bail_msg(rc, uw);
+                    rc = begin(0);
                     if (rc != FRIEDA_OK) return bail(rc, cx[0]);
                     for (size_t u = 0; u < units.size(); u++) {
                         bool next_begun = false;
@@ -316,6 +434,10 @@ int frieda_commit_many(frieda_multi* m, const uint8_t* const* blobs, const size_
                             rc = begin(u + 1);
                             if (rc != FRIEDA_OK) bail(rc, cx[(u + 1) & 1]);
                             next_begun = rc == FRIEDA_OK;
+                        }
+                        if (pf && u + 2 < units.size() && !abort.load()) {  // slot (u + 2) % 3 held unit u - 1, which has finished
+                            rc = upload(u + 2);
+                            if (rc != FRIEDA_OK) bail_msg(rc, uw);
                         }
                         const int rf = commit_batch_finish(&cx[u & 1]->c, local[d][units[u].slot].data());
                         if (rf != FRIEDA_OK) bail(rf, cx[u & 1]);
@@ -370,10 +492,20 @@ int frieda_prove_many(frieda_multi* m, const uint8_t* const* blobs, const size_t
         for (size_t d = 0; d < n; d++) local[d].resize((count + n - 1 - d) / n);
         for (size_t d = 0; d < n; d++) {
             workers.emplace_back([&, d] {
+              const bool pf = m->prefetch;
+              struct DrainUploads {  // no upload may still be reading the caller's blobs when the worker returns
+                  frieda_multi* m;
+                  size_t d;
+                  bool on;
+                  ~DrainUploads() {
+                      if (on) (void)hipStreamSynchronize(m->ring[d].stream);
+                  }
+              } drain_uploads{m, d, pf};
               try {
                 // This device's blobs in order, cut into units: a run of up to MULTI_UNIT blobs of one length is one call of the
                 // batched kernels (the Fiat-Shamir chain is paid once per unit), anything else a single proof.  Two units in
-                // flight: begin(u + 1) is enqueued on the other context before finish(u) waits.
+                // flight: begin(u + 1) is enqueued on the other context before finish(u) waits; the blobs of unit u + 2 are
+                // uploaded on the copy stream meanwhile.
                 frieda_ctx* cx[2] = {m->ctx[2 * d], m->ctx[2 * d + 1]};
                 const uint32_t mine = (uint32_t)local[d].size();
                 if (mine == 0) return;
@@ -386,24 +518,53 @@ int frieda_prove_many(frieda_multi* m, const uint8_t* const* blobs, const size_t
                     uint32_t slot, cnt;
                 };
                 std::vector<Unit> units;
+                size_t ring_need = 0;
                 for (uint32_t slot = 0; slot < mine;) {
                     const uint32_t i0 = (uint32_t)d + slot * (uint32_t)n;
                     uint32_t cnt = 1;
                     while (batchable && cnt < MULTI_UNIT && slot + cnt < mine && lens[i0 + cnt * n] == lens[i0]) cnt++;
                     units.push_back(Unit{slot, cnt});
+                    ring_need = std::max(ring_need, ring_stride(lens[i0]) * cnt);
                     slot += cnt;
                 }
+                auto bail_msg = [&](int rc, const std::string& msg) {
+                    if (status[d] == FRIEDA_OK) {
+                        status[d] = rc;
+                        what[d] = msg;
+                    }
+                    abort.store(true);
+                };
+                auto bail = [&](int rc, frieda_ctx* c) { bail_msg(rc, c->c.err); };
+                if (hipSetDevice(m->devices[d]) != hipSuccess) return bail_msg(FRIEDA_ERR_HIP, "hipSetDevice");
+                std::string uw;
+                if (pf) {
+                    const int rr = m->ensure_ring(d, ring_need, uw);
+                    if (rr != FRIEDA_OK) return bail_msg(rr, uw);
+                }
+                auto upload = [&](size_t u) {
+                    const uint32_t i0 = (uint32_t)d + units[u].slot * (uint32_t)n;
+                    const uint8_t* ptrs[MULTI_UNIT];
+                    for (uint32_t k = 0; k < units[u].cnt; k++) ptrs[k] = blobs[i0 + k * n];
+                    return m->upload(d, (uint32_t)(u % RING_SLOTS), ptrs, lens[i0], units[u].cnt, uw);
+                };
                 auto begin = [&](size_t u) {
                     const Unit& un = units[u];
                     const uint32_t i0 = (uint32_t)d + un.slot * (uint32_t)n;
                     Ctx* c = &cx[u & 1]->c;
-                    if (un.cnt == 1) return prove_begin(c, blobs[i0], lens[i0], false, seeds ? &seeds[i0] : nullptr, cfg);
                     const uint8_t* ptrs[MULTI_UNIT];
                     uint64_t sd[MULTI_UNIT];
                     for (uint32_t k = 0; k < un.cnt; k++) {
                         ptrs[k] = blobs[i0 + k * n];
                         sd[k] = seeds ? seeds[i0 + k * n] : 0;
                     }
+                    if (pf) {
+                        if (hipStreamWaitEvent(c->stream, m->ring[d].ready[u % RING_SLOTS], 0) != hipSuccess)
+                            return c->fail(FRIEDA_ERR_HIP, "hipStreamWaitEvent(blob upload)");
+                        const uint8_t* dev = m->ring[d].slot[u % RING_SLOTS];
+                        if (un.cnt == 1) return prove_begin(c, dev, lens[i0], true, seeds ? &seeds[i0] : nullptr, cfg);
+                        return prove_begin_batch(c, dev, ring_stride(lens[i0]), lens[i0], un.cnt, true, seeds ? sd : nullptr, cfg);
+                    }
+                    if (un.cnt == 1) return prove_begin(c, blobs[i0], lens[i0], false, seeds ? &seeds[i0] : nullptr, cfg);
                     return prove_begin_batch_ptrs(c, ptrs, lens[i0], un.cnt, seeds ? sd : nullptr, cfg);
                 };
                 auto finish = [&](size_t u) {  // -> status; fills local roots and out_proofs of the unit
@@ -426,12 +587,10 @@ int frieda_prove_many(frieda_multi* m, const uint8_t* const* blobs, const size_t
                     }
                     return rf;
                 };
-                auto bail = [&](int rc, frieda_ctx* c) {
-                    status[d] = rc;
-                    what[d] = c->c.err;
-                    abort.store(true);
-                };
-                int rc = begin(0);
+                int rc = FRIEDA_OK;
+                for (size_t u = 0; pf && u < 2 && u < units.size() && rc == FRIEDA_OK; u++) rc = upload(u);
+                if (rc != FRIEDA_OK) return bail_msg(rc, uw);
+                rc = begin(0);
                 if (rc != FRIEDA_OK) return bail(rc, cx[0]);
                 for (size_t u = 0; u < units.size(); u++) {
                     bool next_begun = false;
@@ -439,6 +598,10 @@ int frieda_prove_many(frieda_multi* m, const uint8_t* const* blobs, const size_t
                         rc = begin(u + 1);
                         if (rc != FRIEDA_OK) bail(rc, cx[(u + 1) & 1]);
                         next_begun = rc == FRIEDA_OK;
+                    }
+                    if (pf && u + 2 < units.size() && !abort.load()) {  // slot (u + 2) % 3 held unit u - 1, which has finished
+                        rc = upload(u + 2);
+                        if (rc != FRIEDA_OK) bail_msg(rc, uw);
                     }
                     const int rf = finish(u);
                     if (rf != FRIEDA_OK && status[d] == FRIEDA_OK) bail(rf, cx[u & 1]);

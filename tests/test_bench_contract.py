@@ -37,11 +37,27 @@ def test_bench_line_small_domain(extra):
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0 and cb["root_equals_gpu_root"] is True
-    assert cb["all_cores"]["cores"] >= 1 and cb["all_cores"]["value"] > 0
+    assert cb["multi_core"]["cores"] >= 1 and cb["multi_core"]["value"] > 0 and cb["multi_core"]["usable_cores"] >= cb["multi_core"]["cores"]
     assert len(cb["reference_bench_sizes"]) == 5 and all(r["roots_equal"] and r["proofs_equal"] for r in cb["reference_bench_sizes"])
     if "commit" not in extra:
         assert d["verified_proofs"] == 9
         assert "commit_and_generate_proof" in d["config"]["workload"]
+        e2e = d["end_to_end"]  # host blobs through frieda_prove_many / frieda_commit_many, pageable and page-locked, + a lone call
+        for k in ("pageable_ms_per_blob", "pinned_ms_per_blob", "lone_call_ms", "pageable_commit_ms_per_blob", "pinned_commit_ms_per_blob", "device_resident_ms_per_blob"):
+            assert e2e[k] > 0, k
+    assert d["by_config"] == []  # nothing at or below 2^16 in BASELINE.json's configurations
+
+
+def test_bench_line_carries_the_other_baseline_configs():
+    """by_config: the 2^20 proof stream and the 2^22 commit stream beside a 2^22 headline (the driver's default run carries 2^20, 2^22 and
+    the 2^24 commit beside the 2^24 headline)."""
+    d = _bench(["--log-domain", "22", "--cpu-sample-log", "16", "--steps", "8", "--warmup", "1", "--batch-extra", "0", "--sequential-extra", "4"])
+    rows = {(r["log_domain"], r["workload"]): r for r in d["by_config"]}
+    assert set(rows) == {(20, "commit_and_generate_proof"), (22, "commit")}
+    for r in rows.values():
+        assert r["ms_per_blob"] > 0 and 0 < r["frac_of_hbm_peak_wall"] < 1 and r["lone_call"]["ms"] >= r["ms_per_blob"] * 0.5 and r["dominant_kernel"]["frac"] > 0
+    assert rows[(20, "commit_and_generate_proof")]["verified_proofs"] == 64
+    assert d["roofline"]["traffic"] is None or d["roofline"]["traffic"] > 0
 
 
 def test_bench_forced_collective_one_rank():

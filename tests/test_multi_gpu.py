@@ -190,3 +190,14 @@ def test_bench_self_launch_reports_a_failing_rank():
     """A rank that dies takes the launch down with a non-zero status instead of leaving the others in the rendezvous."""
     r, docs = _run_bench(["--gpus", "2", "--steps", "2", "--dry-collective", "gloo"], env_extra={"FRIEDA_BENCH_TEST_FAIL_RANK": "1"}, timeout=120)
     assert r.returncode != 0 and docs == []
+
+
+def test_bench_refuses_more_ranks_than_visible_gpus():
+    """`python bench.py --gpus N` with fewer than N visible devices must say so and exit non-zero before starting any rank (on a
+    box with 8 GPUs the driver's `--gpus 8` then just works; on a box without, nobody waits in a rendezvous for missing ranks)."""
+    import torch
+
+    have = torch.cuda.device_count()
+    r, docs = _run_bench(["--gpus", str(have + 2), "--steps", "2"], timeout=120)
+    assert r.returncode == 2 and not docs
+    assert f"--gpus {have + 2} but only {have} GPU(s) are visible" in r.stderr

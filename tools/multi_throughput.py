@@ -1,5 +1,6 @@
 """Throughput of the C ABI's multi-GPU entry (frieda_prove_many / frieda_commit_many) with HOST blobs — the PCIe-inclusive rate a
-Rust caller of the drop-in sees.  usage: python tools/multi_throughput.py [log_domain] [n_blobs] [devices, comma separated]"""
+Rust caller of the drop-in sees.  usage: python tools/multi_throughput.py [log_domain] [n_blobs] [devices, comma separated] [pageable|pinned]
+pinned: the blobs sit in page-locked host memory (torch pin_memory = hipHostMalloc), so every upload is an asynchronous DMA."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -11,7 +12,12 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 24
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 24
 devices = [int(x) for x in sys.argv[3].split(",")] if len(sys.argv) > 3 else [0]
 blob_len = (4 << (n - 4)) * 30 // 8
+mode = sys.argv[4] if len(sys.argv) > 4 else "pageable"
 blobs = [splitmix64_bytes(100 + i, blob_len) for i in range(count)]  # pageable host memory
+if mode == "pinned":
+    import torch
+    _keep = [torch.from_numpy(b).pin_memory() for b in blobs]
+    blobs = [t.numpy() for t in _keep]
 cfg = frieda_amd.PcsConfig(frieda_amd.FriConfig(4, 0, 20), 20)
 seeds = [blob_len] * count
 mc = frieda_amd.MultiContext(devices)
@@ -26,7 +32,7 @@ roots = mc.commit_many(blobs, 4)
 dtc = time.perf_counter() - t1
 assert roots == [r for r, _ in res]
 el = 4.0 * (1 << n)
-print(f"frieda_prove_many : {count} host blobs of 2^{n} on devices {devices}: {1e3 * dt / count:.3f} ms per blob, {el * count / dt / 1e9:.2f} G M31 elems/s "
+print(f"frieda_prove_many : {count} {mode} host blobs of 2^{n} on devices {devices}: {1e3 * dt / count:.3f} ms per blob, {el * count / dt / 1e9:.2f} G M31 elems/s "
       f"(H2D of {blob_len / 1e6:.1f} MB per blob included; rccl={mc.uses_rccl})")
 print(f"frieda_commit_many: {1e3 * dtc / count:.3f} ms per blob, {el * count / dtc / 1e9:.2f} G M31 elems/s")
 mc.close()
