@@ -52,6 +52,7 @@ extern "C" {
     pub fn frieda_ctx_last_prove_phases(ctx: *const frieda_ctx, out_ms: *mut f64) -> c_int;
     /// measurement aid: pure-compute Blake2s compression rate of this device (leaf-shaped, node-shaped), compressions per second
     pub fn frieda_ctx_blake2s_ceiling(ctx: *mut frieda_ctx, leaf_per_s: *mut f64, node_per_s: *mut f64) -> c_int;
+    pub fn frieda_ctx_blake2s_ceiling_ex(ctx: *mut frieda_ctx, out: *mut f64) -> c_int;
     /// diagnostic: alphas per FRI layer and the pre-grind channel digest of the last finished proof
     pub fn frieda_ctx_last_transcript(ctx: *const frieda_ctx, n_layers: *mut u32, alphas: *mut u32, cap_layers: usize, digest_before_grind: *mut u8) -> c_int;
     pub fn frieda_ctx_kernel_timing_report(ctx: *mut frieda_ctx, buf: *mut c_char, cap: usize, reset: c_int) -> usize;

@@ -70,6 +70,7 @@ def lib():
         "frieda_ctx_set_kernel_timing": (C.c_int, [vp, C.c_int]),
         "frieda_ctx_last_prove_phases": (C.c_int, [vp, C.POINTER(C.c_double)]),
         "frieda_ctx_blake2s_ceiling": (C.c_int, [vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+        "frieda_ctx_blake2s_ceiling_ex": (C.c_int, [vp, C.POINTER(C.c_double)]),
         "frieda_ctx_last_transcript": (C.c_int, [vp, C.POINTER(u32), vp, sz, vp]),
         "frieda_ctx_kernel_timing_report": (sz, [vp, vp, sz, C.c_int]),
         "frieda_commit": (C.c_int, [vp, vp, sz, u32, vp]),

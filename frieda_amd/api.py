@@ -119,6 +119,13 @@ class Context:
         _check(self._L.frieda_ctx_blake2s_ceiling(self._h, C.byref(a), C.byref(b)), self._h)
         return a.value, b.value
 
+    def blake2s_ceiling_ex(self):
+        """The ceiling with the in-kernel clock: {leaf_per_s, node_per_s, leaf_clock_ghz, leaf_cycles, node_clock_ghz, node_cycles}
+        (cycles = SIMD cycles per wave-compression)."""
+        a = (C.c_double * 6)()
+        _check(self._L.frieda_ctx_blake2s_ceiling_ex(self._h, a), self._h)
+        return dict(zip(["leaf_per_s", "node_per_s", "leaf_clock_ghz", "leaf_cycles_per_wave_compression", "node_clock_ghz", "node_cycles_per_wave_compression"], list(a)))
+
     def last_transcript(self):
         """Diagnostic: alphas drawn per FRI layer and the channel digest the grind was keyed by, of the last finished proof."""
         n = C.c_uint32()

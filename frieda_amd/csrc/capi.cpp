@@ -120,11 +120,30 @@ int frieda_ctx_blake2s_ceiling(frieda_ctx* ctx, double* leaf_per_s, double* node
     FR_NO_JOB(&ctx->c);
     FR_GUARD_BEGIN
     FR_HIP(&ctx->c, hipSetDevice(ctx->c.device));
-    int rc = ctx->c.ensure_arena((size_t)256 * 8 * 256 * 4);
+    int rc = ctx->c.ensure_arena(k::blake2s_ceiling_scratch_bytes());
     if (rc) return rc;
     if (k::blake2s_ceiling(ctx->c.stream, reinterpret_cast<uint32_t*>(ctx->c.arena), leaf_per_s, node_per_s))
         return ctx->c.fail(FRIEDA_ERR_HIP, "blake2s_ceiling: event timing failed");
     FR_HIP(&ctx->c, hipGetLastError());
+    return FRIEDA_OK;
+    FR_GUARD_END(ctx)
+}
+
+int frieda_ctx_blake2s_ceiling_ex(frieda_ctx* ctx, double out[6]) {
+    if (!ctx || !out) return FRIEDA_ERR_ARG;
+    FR_NO_JOB(&ctx->c);
+    FR_GUARD_BEGIN
+    FR_HIP(&ctx->c, hipSetDevice(ctx->c.device));
+    int rc = ctx->c.ensure_arena(k::blake2s_ceiling_scratch_bytes());
+    if (rc) return rc;
+    double clk[4] = {0, 0, 0, 0};
+    if (k::blake2s_ceiling(ctx->c.stream, reinterpret_cast<uint32_t*>(ctx->c.arena), &out[0], &out[1], clk))
+        return ctx->c.fail(FRIEDA_ERR_HIP, "blake2s_ceiling: event timing failed");
+    FR_HIP(&ctx->c, hipGetLastError());
+    out[2] = clk[0];
+    out[3] = clk[1];
+    out[4] = clk[2];
+    out[5] = clk[3];
     return FRIEDA_OK;
     FR_GUARD_END(ctx)
 }

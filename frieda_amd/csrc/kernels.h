@@ -56,7 +56,9 @@ void unpack30(const Launch& L, const uint8_t* d_bytes, size_t len, uint32_t* d_o
 
 // ---- diag.hip ----
 // pure-compute Blake2s compression rate of this device (measurement aid; see frieda_ctx_blake2s_ceiling)
-int blake2s_ceiling(hipStream_t s, uint32_t* d_scratch, double* leaf_per_s, double* node_per_s);
+// clock (optional, 4 doubles): {leaf clock GHz, leaf SIMD cycles per wave-compression, node clock GHz, node cycles}
+int blake2s_ceiling(hipStream_t s, uint32_t* d_scratch, double* leaf_per_s, double* node_per_s, double* clock = nullptr);
+size_t blake2s_ceiling_scratch_bytes();
 
 // ---- column.hip ----
 // ColumnOps::bit_reverse_column in place on `ncols` columns of 2^log_size words, `stride` words apart (1 = BaseField column,

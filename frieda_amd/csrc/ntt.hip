@@ -68,6 +68,7 @@ struct NttArgs {
     uint32_t n_stages;    // <= 3
     uint32_t stage_r[3];  // layers per stage, top stage first
     size_t bstride_w;     // batch: words between consecutive blobs' buffers (both in and out); blob = blockIdx.z
+    uint32_t rep_log;     // ntt_tile12_rep_kernel: a workgroup produces the tiles of 2^rep_log consecutive high blocks from one read of its source tile
 };
 
 // One stage of R layers on tile bits [lo, lo + R): every thread processes groups of 2^R elements.
@@ -322,6 +323,117 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_tile12_kernel(NttArgs a) {
                 *reinterpret_cast<uint4*>(dst + global_of(e)) = make_uint4(lds[p], lds[p + 1], lds[p + 2], lds[p + 3]);
             }
             __syncthreads();  // the next column overwrites the tile
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// The strided 8-layer pass when it reads the coefficient vector itself (the first pass): the zero-padded layers above it only
+// replicate the coefficients, so the workgroups of all 2^(n - 1 - i_hi) high blocks read the SAME source tile and differ in their
+// twiddles only.  With one workgroup per high block every coefficient was fetched once per block (208 MB from the memory side for
+// 16.8 MB of coefficients at n = 24, profiles/r02_prove24_traffic.json).  Here a workgroup reads its source tile of COLS columns
+// once into registers (16 words per thread and column) and loops over 2^rep_log high blocks: twiddles of the block, then per
+// column registers -> LDS -> two radix-16 stages -> store.  Twiddles are still shared by the workgroup's columns.
+// ------------------------------------------------------------------------------------------------
+template <int COLS>
+__global__ __launch_bounds__(NTT_THREADS) void ntt_tile12_rep_kernel(NttArgs a) {
+    constexpr int NS = 2;
+    constexpr uint32_t LOG_W = MID_LOG_W;
+    __shared__ uint32_t lds[TILE_WORDS];
+    const uint32_t g = threadIdx.x;
+    const uint32_t nwb_log = a.i_lo - LOG_W;
+    const uint32_t wblk = blockIdx.x & ((1u << nwb_log) - 1);
+    const uint32_t hblk0 = (blockIdx.x >> nwb_log) << a.rep_log;
+    constexpr uint32_t wmask = (1u << LOG_W) - 1;
+    const size_t col0 = (size_t)blockIdx.y * COLS;
+    const uint32_t* in = a.in + col0 * a.in_stride + blockIdx.z * a.bstride_w;
+    uint32_t* out = a.out + col0 * a.out_stride + blockIdx.z * a.bstride_w;
+
+    auto piece_e = [&](int kk) { return 4u * g + 1024u * (uint32_t)kk; };
+    // tile element e -> index below the high block (the source index is this, masked: independent of the high block)
+    auto low_of = [&](uint32_t e) { return (wblk << LOG_W) | ((e >> LOG_W) << a.i_lo) | (e & wmask); };
+
+    uint4 src[COLS][4];
+#pragma unroll
+    for (int c = 0; c < COLS; c++) {
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++) {
+            const uint32_t idx = low_of(piece_e(kk)) & a.in_mask;
+            src[c][kk] = idx < a.in_limit ? *reinterpret_cast<const uint4*>(in + (size_t)c * a.in_stride + idx) : make_uint4(0u, 0u, 0u, 0u);
+        }
+    }
+    uint32_t pbase[NS];
+#pragma unroll
+    for (int s = 0; s < NS; s++) {
+        const uint32_t lo = 8 - 4 * s;
+        pbase[s] = pad(((g >> lo) << (lo + 4)) | (g & ((1u << lo) - 1)));
+    }
+
+#pragma unroll 1
+    for (uint32_t h = 0; h < (1u << a.rep_log); h++) {
+        const uint32_t hblk = hblk0 + h;
+        const uint32_t gbase = hblk << (a.i_hi + 1);
+        uint32_t twd[NS][15];
+#pragma unroll
+        for (int s = 0; s < NS; s++) {
+            const uint32_t lo = 8 - 4 * s;
+            const uint32_t base = ((g >> lo) << (lo + 4)) | (g & ((1u << lo) - 1));
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const uint32_t b = lo + 3 - q;
+                const uint32_t i = a.i_lo + b - LOG_W;  // >= i_lo >= 12: always a line layer
+                const uint32_t hbase = (hblk << (a.i_hi - i)) | (base >> (b + 1));
+                const uint32_t* lvl = a.tw + tw_level_offset_dev(a.n, i - 1) + hbase;
+#pragma unroll
+                for (int u = 0; u < (1 << q); u++) {
+                    uint32_t v = lvl[u];
+                    if (s == 0) v = (uint32_t)__builtin_amdgcn_readfirstlane((int)v);  // workgroup-uniform (ntt_tile12_kernel)
+                    twd[s][(1 << q) - 1 + u] = v;
+                }
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < COLS; c++) {
+#pragma unroll
+            for (int kk = 0; kk < 4; kk++) {
+                const uint32_t p = pad(piece_e(kk));
+                lds[p] = src[c][kk].x;
+                lds[p + 1] = src[c][kk].y;
+                lds[p + 2] = src[c][kk].z;
+                lds[p + 3] = src[c][kk].w;
+            }
+            __syncthreads();
+            uint32_t x[16];
+#pragma unroll
+            for (int s = 0; s < NS; s++) {
+                const uint32_t lo = 8 - 4 * s;
+                uint32_t* col = lds + pbase[s];
+#pragma unroll
+                for (int r = 0; r < 16; r++) x[r] = col[pad((uint32_t)r << lo)];
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const int bit = 3 - q;
+#pragma unroll
+                    for (int r = 0; r < 16; r++) {
+                        if (r & (1 << bit)) continue;
+                        const int u = r >> (bit + 1);
+                        const uint32_t t = m31_mul(x[r | (1 << bit)], twd[s][(1 << q) - 1 + u]);
+                        const uint32_t v = x[r];
+                        x[r] = m31_add(v, t);
+                        x[r | (1 << bit)] = m31_sub(v, t);
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 16; r++) col[pad((uint32_t)r << lo)] = x[r];
+                __syncthreads();
+            }
+            uint32_t* dst = out + (size_t)c * a.out_stride + gbase;
+#pragma unroll
+            for (int kk = 0; kk < 4; kk++) {
+                const uint32_t e = piece_e(kk), p = pad(e);
+                *reinterpret_cast<uint4*>(dst + low_of(e)) = make_uint4(lds[p], lds[p + 1], lds[p + 2], lds[p + 3]);
+            }
+            __syncthreads();  // the next tile overwrites the LDS buffer
         }
     }
 }
@@ -639,7 +751,23 @@ uint32_t circle_evaluate_into_tree(const Launch& L_, const uint32_t* d_coef, siz
             return;
         }
         Scope scope(L_, name, enc_bytes / (n_mid + 1));
-        if (aligned && t + a.log_w == TILE_LOG && (t == 12 || t == 8)) {
+        // FRIEDA_NTT_REP=1: one workgroup per source tile looping over the high blocks (ntt_tile12_rep_kernel).  Off by default: it
+        // cuts the pass's fetches from the memory side to the unique coefficients but is no faster (142 vs 140 us at 2^24, 41 vs 35 us at
+        // 2^22, profiles/r03_ntt_mid_rep_ab.txt) — the pass is bound by its butterflies and LDS round trips, not by the re-reads,
+        // which the L2 / Infinity Cache absorb.
+        static const bool use_rep = [] {
+            const char* e = getenv("FRIEDA_NTT_REP");
+            return e && *e == '1';
+        }();
+        const uint32_t hb_log = n - 1 - a.i_hi;  // high blocks = 2^hb_log
+        if (use_rep && aligned && t == 8 && a.log_w == MID_LOG_W && hb_log >= 1 && ((uint64_t)a.in_mask >> (a.i_hi + 1)) == 0 && ncols % 2 == 0) {
+            // this pass reads the (replicated) coefficient vector: every high block has the same source tile
+            a.rep_log = hb_log < 3 ? hb_log : 3;
+            a.ncols = 2;
+            dim3 grid((unsigned)((N >> TILE_LOG) >> a.rep_log), ncols / 2, L_.batch);
+            ntt_tile12_rep_kernel<2><<<grid, NTT_THREADS, 0, s>>>(a);
+            a.rep_log = 0;
+        } else if (aligned && t + a.log_w == TILE_LOG && (t == 12 || t == 8)) {
             a.ncols = cpw4;
             dim3 grid((unsigned)(N >> TILE_LOG), ncols / cpw4, L_.batch);
             if (a.log_w == 0)

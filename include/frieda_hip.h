@@ -95,6 +95,12 @@ size_t frieda_ctx_kernel_timing_report(frieda_ctx* ctx, char* buf, size_t cap, i
  * node-shaped (16 words).  The path is bound by this rate, which depends on the clock the chip holds under the load and on the
  * device; bench.py quotes it beside the measured kernels (roofline_valu) instead of a constant.  ~5 ms; synchronises the stream. */
 int frieda_ctx_blake2s_ceiling(frieda_ctx* ctx, double* leaf_per_s, double* node_per_s);
+/* the same after ~0.25 s of that load per shape (~0.5 s in all), with the clock the chip holds under it read inside the kernel (shader-clock counter against
+ * the 100 MHz wall-clock counter, median over the workgroups): out = {leaf compressions/s, node compressions/s, leaf clock GHz,
+ * leaf SIMD cycles per wave-compression, node clock GHz, node SIMD cycles per wave-compression}.  On MI355X the clock stays at
+ * ~2.4 GHz under this load and a compression costs ~3950 cycles per wave (profiles/r03_clock_probe_mi355x.txt): the ceiling is
+ * the instruction mix, not a lowered clock. */
+int frieda_ctx_blake2s_ceiling_ex(frieda_ctx* ctx, double out[6]);
 /* diagnostic: the Fiat-Shamir transcript of the last finished generate_proof on this ctx (blob 0 of a batch) — what
  * FriProver::commit derives between src/proof.rs:52 and :58 and the Proof does not carry: per FRI layer (first, then inner)
  * the folding alpha drawn after its root (4 u32 each; the roots themselves are the layer commitments of the Proof), and the

@@ -26,18 +26,22 @@ struct Stamp {
     unsigned long long c0, r0, c1, r1;
 };
 
-__device__ __forceinline__ void stamp_begin(Stamp* st) {
-    if (threadIdx.x == 0) {
-        st[blockIdx.x].c0 = __builtin_amdgcn_s_memtime();
-        st[blockIdx.x].r0 = __builtin_amdgcn_s_memrealtime();
-    }
+// Both counters in one volatile asm (s_memtime: shader clock; s_memrealtime: 100 MHz wall clock), waited for at once.  Volatile asm
+// statements keep their order among themselves; the empty ones around them tie the stamp to the data flow of the loop it brackets
+// (the loop's input depends on the first stamp, the second stamp follows an asm that consumes the loop's output), so the compiler
+// can move neither across the loop.
+__device__ __forceinline__ void stamp_pair(unsigned long long& c, unsigned long long& r) {
+    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(c), "=s"(r)::"memory");
 }
-__device__ __forceinline__ void stamp_end(Stamp* st) {
-    if (threadIdx.x == 0) {
-        st[blockIdx.x].c1 = __builtin_amdgcn_s_memtime();
-        st[blockIdx.x].r1 = __builtin_amdgcn_s_memrealtime();
-    }
-}
+
+#define STAMP_BEGIN(dep)                                  \
+    unsigned long long c0_, r0_, c1_, r1_;                \
+    stamp_pair(c0_, r0_);                                 \
+    asm volatile("" : "+v"(dep) : "s"(c0_));
+#define STAMP_END(st, dep)                                \
+    asm volatile("" ::"v"(dep));                          \
+    stamp_pair(c1_, r1_);                                 \
+    if (threadIdx.x == 0) st[blockIdx.x] = Stamp{c0_, r0_, c1_, r1_};
 
 constexpr int UNROLL = 64;  // instructions per loop iteration (8 chains x 8)
 
@@ -46,13 +50,13 @@ constexpr int UNROLL = 64;  // instructions per loop iteration (8 chains x 8)
         uint32_t r[8], k = threadIdx.x * 2654435761u + blockIdx.x * 40503u + 12345u;             \
         for (int i = 0; i < 8; i++) r[i] = k * (2 * i + 1) + 0x9E3779B9u * i;                    \
         uint32_t s1 = k ^ 0x5bd1e995u, s2 = (k >> 3) | 1u;                                       \
-        stamp_begin(st);                                                                         \
+        STAMP_BEGIN(r[0])                                                                        \
         for (int it = 0; it < iters; it++) {                                                     \
             _Pragma("unroll") for (int u = 0; u < UNROLL / 8; u++) {                              \
                 _Pragma("unroll") for (int i = 0; i < 8; i++) asm volatile(ASM : "+v"(r[i]) : "v"(s1), "v"(s2)); \
             }                                                                                    \
         }                                                                                        \
-        stamp_end(st);                                                                           \
+        STAMP_END(st, r[0])                                                                      \
         uint32_t s = 0;                                                                          \
         for (int i = 0; i < 8; i++) s ^= r[i];                                                   \
         out[blockIdx.x * 256 + threadIdx.x] = s;                                                 \
@@ -72,7 +76,7 @@ template <int LEAF>
 __global__ __launch_bounds__(256) void k_blake(uint32_t* out, Stamp* st, int iters) {
     uint32_t m[16], h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int i = 0; i < 16; i++) m[i] = threadIdx.x * 2654435761u + i * 40503u + blockIdx.x;
-    stamp_begin(st);
+    STAMP_BEGIN(m[0])
     for (int it = 0; it < iters; it++) {
         if (LEAF) {
             const uint32_t mm[16] = {m[0], m[1], m[2], m[3], 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -86,7 +90,7 @@ __global__ __launch_bounds__(256) void k_blake(uint32_t* out, Stamp* st, int ite
             }
         }
     }
-    stamp_end(st);
+    STAMP_END(st, h[0])
     uint32_t s = 0;
     for (int i = 0; i < 8; i++) s += h[i];
     out[blockIdx.x * 256 + threadIdx.x] = s;

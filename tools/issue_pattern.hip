@@ -14,6 +14,14 @@ struct Stamp {
     unsigned long long c0, r0, c1, r1;
 };
 
+// Both counters in one volatile asm (s_memtime: shader clock; s_memrealtime: 100 MHz wall clock), waited for at once.  Volatile asm
+// statements keep their order among themselves; the empty ones around them tie the stamp to the data flow of the loop it brackets
+// (the loop's input depends on the first stamp, the second stamp follows an asm that consumes the loop's output), so the compiler
+// can move neither across the loop.
+__device__ __forceinline__ void stamp_pair(unsigned long long& c, unsigned long long& r) {
+    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(c), "=s"(r)::"memory");
+}
+
 #define S_OP(i) asm volatile("v_xor_b32 %0, %0, %1" : "+v"(r[i]) : "v"(s1))
 #define A_OP(i) asm volatile("v_add_u32 %0, %0, %1" : "+v"(r[i]) : "v"(s1))
 #define C_OP(i) asm volatile("v_alignbit_b32 %0, %0, %0, 7" : "+v"(r[i]))
@@ -24,17 +32,15 @@ struct Stamp {
         uint32_t r[8], k = threadIdx.x * 2654435761u + blockIdx.x * 40503u + 12345u;              \
         for (int i = 0; i < 8; i++) r[i] = k * (2 * i + 1) + 0x9E3779B9u * i;                     \
         uint32_t s1 = k ^ 0x5bd1e995u, s2 = (k >> 3) | 1u;                                        \
-        if (threadIdx.x == 0) {                                                                   \
-            st[blockIdx.x].c0 = __builtin_amdgcn_s_memtime();                                     \
-            st[blockIdx.x].r0 = __builtin_amdgcn_s_memrealtime();                                 \
-        }                                                                                         \
+        unsigned long long c0_, r0_, c1_, r1_;                                                    \
+        stamp_pair(c0_, r0_);                                                                     \
+        asm volatile("" : "+v"(r[0]) : "s"(c0_));                                                 \
         for (int it = 0; it < iters; it++) {                                                      \
             _Pragma("unroll") for (int u = 0; u < 4; u++) { BODY }                                 \
         }                                                                                         \
-        if (threadIdx.x == 0) {                                                                   \
-            st[blockIdx.x].c1 = __builtin_amdgcn_s_memtime();                                     \
-            st[blockIdx.x].r1 = __builtin_amdgcn_s_memrealtime();                                 \
-        }                                                                                         \
+        asm volatile("" ::"v"(r[0]));                                                             \
+        stamp_pair(c1_, r1_);                                                                     \
+        if (threadIdx.x == 0) st[blockIdx.x] = Stamp{c0_, r0_, c1_, r1_};                         \
         uint32_t s = 0;                                                                           \
         for (int i = 0; i < 8; i++) s ^= r[i];                                                    \
         out[blockIdx.x * 256 + threadIdx.x] = s;                                                  \
