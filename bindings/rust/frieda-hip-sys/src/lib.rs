@@ -126,6 +126,9 @@ extern "C" {
     /// over-determined form: picks an independent subset of the offered cells (at most 256 needed)
     pub fn frieda_circle_interpolate_cells_any(ctx: *mut frieda_ctx, d_cells: *const u32, cell_index: *const u32, n_avail: u32, ncols: u32, log_cell: u32, log_coef: u32, log_domain: u32, d_coef: *mut u32, out_used: *mut u32) -> c_int;
     pub fn frieda_reconstruct_cells_device(ctx: *mut frieda_ctx, d_cells: *const u32, cell_index: *const u32, n_cells: u32, log_cell: u32, log_coef: u32, log_domain: u32, len: usize, d_out_bytes: *mut c_void) -> c_int;
+    /// any >= 2^log_coef + 2 sampled points, no bound on their number (erasure-locator route, no linear system)
+    pub fn frieda_circle_interpolate_points(ctx: *mut frieda_ctx, d_cells: *const u32, cell_index: *const u32, n_cells: u32, ncols: u32, log_cell: u32, log_coef: u32, log_domain: u32, d_coef: *mut u32) -> c_int;
+    pub fn frieda_reconstruct_points_device(ctx: *mut frieda_ctx, d_cells: *const u32, cell_index: *const u32, n_cells: u32, log_cell: u32, log_coef: u32, log_domain: u32, len: usize, d_out_bytes: *mut c_void) -> c_int;
     pub fn frieda_merkle_commit_layer(ctx: *mut frieda_ctx, log_size: u32, d_prev: *const c_void, d_cols: *const *const u32, ncols: u32, d_out: *mut c_void) -> c_int;
     pub fn frieda_merkle_commit(ctx: *mut frieda_ctx, d_cols: *const u32, log_size: u32, d_layers: *mut c_void) -> c_int;
     pub fn frieda_merkle_layer_offset(log_size: u32, layer_log: u32) -> usize;

@@ -132,6 +132,8 @@ def lib():
         "frieda_circle_interpolate_cells": (C.c_int, [vp, vp, vp, u32, u32, u32, u32, u32, vp]),
         "frieda_circle_interpolate_cells_any": (C.c_int, [vp, vp, vp, u32, u32, u32, u32, u32, vp, vp]),
         "frieda_reconstruct_cells_device": (C.c_int, [vp, vp, vp, u32, u32, u32, u32, sz, vp]),
+        "frieda_circle_interpolate_points": (C.c_int, [vp, vp, vp, u32, u32, u32, u32, u32, vp]),
+        "frieda_reconstruct_points_device": (C.c_int, [vp, vp, vp, u32, u32, u32, u32, sz, vp]),
         "frieda_merkle_commit_layer": (C.c_int, [vp, u32, vp, pp, u32, vp]),
         "frieda_merkle_commit": (C.c_int, [vp, vp, u32, vp]),
         "frieda_merkle_layer_offset": (sz, [u32, u32]),

@@ -197,6 +197,21 @@ class Context:
             ),
         )
 
+    def reconstruct_from_points(self, cells, cell_index, log_coef, log_domain, n_bytes):
+        """cells: uint32[R, 4, 2^m] as in reconstruct_from_cells, but ANY number of distinct cells holding at least 2^log_coef + 2
+        points in all (single sampled points: m = 0) — no linear system, no bound on R (frieda_reconstruct_points_device)."""
+        import numpy as np
+
+        R, m = int(cells.shape[0]), int(cells.shape[2]).bit_length() - 1
+        idx = np.ascontiguousarray(cell_index, dtype=np.uint32)
+        return self._dev_call_with_upload(
+            cells,
+            n_bytes,
+            lambda d_in, d_out: _check(
+                self._L.frieda_reconstruct_points_device(self._h, d_in, idx.ctypes.data, R, m, log_coef, log_domain, n_bytes, d_out), self._h
+            ),
+        )
+
     def commit_and_generate_proof(self, data, seed, pcs_config):
         a = _as_bytes(data)
         root = (C.c_uint8 * 32)()

@@ -834,6 +834,139 @@ int frieda_reconstruct_cells_device(frieda_ctx* ctx, const uint32_t* d_cells, co
     FR_GUARD_END(ctx)
 }
 
+// ---- reconstruction from any >= 2^log_coef + 2 points (erasure.hip) ----
+namespace {
+// coefficients of `ncols` columns into d_coef[ncols][2^log_coef], or — d_coef == nullptr — into the start of the arena (arena_off bytes
+// reserved there by the caller).  Cells as in interpolate_cells (runs of 2^log_cell entries; repeated cells are dropped).
+int interpolate_points(frieda_ctx* ctx, const uint32_t* d_cells, const uint32_t* cell_index, uint32_t n_cells, uint32_t ncols, uint32_t log_cell,
+                       uint32_t log_coef, uint32_t log_domain, uint32_t* d_coef, size_t arena_off) {
+    Ctx& c = ctx->c;
+    FR_NO_JOB(&c);
+    if (log_cell > log_domain || log_coef > log_domain || log_coef < 1 || log_domain < 1 || log_domain + 1 > FRIEDA_MAX_LOG_DOMAIN || log_domain > 26)
+        return c.fail(FRIEDA_ERR_ARG, "points: need 1 <= log_coef <= log_domain <= min(26, FRIEDA_MAX_LOG_DOMAIN - 1) and log_cell <= log_domain");
+    const size_t N = (size_t)1 << log_domain, K = (size_t)1 << log_coef, M = (size_t)1 << log_cell;
+    const uint32_t n = log_domain;
+    // known positions (first occurrence of every cell wins), and where their values sit in the caller's buffer
+    std::vector<uint8_t> known(N, 0);
+    std::vector<uint32_t> pos, src;
+    pos.reserve((size_t)n_cells * M);
+    src.reserve((size_t)n_cells * M);
+    for (uint32_t r = 0; r < n_cells; r++) {
+        if ((uint64_t)cell_index[r] >= ((uint64_t)1 << (log_domain - log_cell))) return c.fail(FRIEDA_ERR_ARG, "points: cell index out of range");
+        const size_t p0 = (size_t)cell_index[r] << log_cell;
+        if (known[p0]) continue;
+        if ((((uint64_t)r * ncols) << log_cell) + (((uint64_t)ncols) << log_cell) > 0xFFFFFFFFull) return c.fail(FRIEDA_ERR_ARG, "points: sample buffer beyond 2^32 words");
+        for (size_t t = 0; t < M; t++) {
+            known[p0 + t] = 1;
+            pos.push_back((uint32_t)(p0 + t));
+            src.push_back((uint32_t)((((size_t)r * ncols) << log_cell) + t));
+        }
+    }
+    if (pos.size() < K + 2)
+        return c.fail(FRIEDA_ERR_ARG, "points: need at least 2^log_coef + 2 distinct points (the locator polynomial needs two spare samples)");
+    // erased positions, an even number of them: with an odd count one known point is given up
+    if ((N - pos.size()) & 1) {
+        known[pos.back()] = 0;
+        pos.pop_back();
+        src.pop_back();
+    }
+    std::vector<uint32_t> erased;
+    erased.reserve(N - pos.size());
+    for (size_t i = 0; i < N; i++)
+        if (!known[i]) erased.push_back((uint32_t)i);
+    const uint32_t s_cnt = (uint32_t)pos.size(), n_lines = (uint32_t)(erased.size() / 2);
+
+    // domains: D (log n) and the next canonic domain D' (log n + 1)
+    auto make_domain = [](uint32_t lg) {
+        k::ErasureDomain g;
+        memset(&g, 0, sizeof g);
+        const Coset h = Coset::half_odds(lg - 1);
+        g.init = point_from_index(h.initial);
+        CPoint sp = point_from_index(h.step);
+        for (uint32_t b = 0; b + 1 < lg && b < 32; b++) {
+            g.step_pow[b] = sp;
+            sp = cp_double(sp);
+        }
+        g.n = lg;
+        return g;
+    };
+    const k::ErasureDomain g0 = make_domain(n), g1 = make_domain(n + 1);
+
+    // workspace
+    auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t chunks_s = k::erasure_zpart_chunks(s_cnt, n_lines), chunks_k = k::erasure_zpart_chunks((uint32_t)K, n_lines);
+    ArenaPlan plan;
+    plan.off = arena_off;
+    const size_t o_pos = plan.take(4 * (size_t)s_cnt), o_src = plan.take(4 * (size_t)s_cnt), o_er = plan.take(4 * erased.size() + 4);
+    const size_t o_la = plan.take(4 * (size_t)n_lines + 4), o_lb = plan.take(4 * (size_t)n_lines + 4), o_lc = plan.take(4 * (size_t)n_lines + 4);
+    const size_t o_px = plan.take(4 * std::max<size_t>(s_cnt, K)), o_py = plan.take(4 * std::max<size_t>(s_cnt, K));
+    const size_t o_zp = plan.take(4 * std::max(chunks_s * s_cnt, chunks_k * K)), o_z = plan.take(4 * std::max<size_t>(s_cnt, K));
+    const size_t o_w = plan.take(al(4 * N) * ncols);   // Z * p on D, then (reused) its evaluation on D' needs 2N per column: see o_ev
+    const size_t o_q = plan.take(al(4 * N) * ncols);   // coefficients of Z * p
+    const size_t o_ev = plan.take(al(8 * N) * ncols);  // Z * p on D'
+    const size_t o_blk = plan.take(al(4 * K) * ncols);
+    int rc = c.ensure_arena(plan.off);
+    if (rc) return rc;
+    TwiddleSet ts0, ts1;
+    rc = c.get_twiddles(n, ts0);
+    if (rc) return rc;
+    rc = c.get_twiddles(n + 1, ts1);
+    if (rc) return rc;
+    uint8_t* A = c.arena;
+    auto W32 = [&](size_t off) { return reinterpret_cast<uint32_t*>(A + off); };
+    hipStream_t s = c.stream;
+    const k::Launch LN = c.launch();
+    FR_HIP(&c, hipMemcpyAsync(A + o_pos, pos.data(), 4 * (size_t)s_cnt, hipMemcpyHostToDevice, s));
+    FR_HIP(&c, hipMemcpyAsync(A + o_src, src.data(), 4 * (size_t)s_cnt, hipMemcpyHostToDevice, s));
+    if (!erased.empty()) FR_HIP(&c, hipMemcpyAsync(A + o_er, erased.data(), 4 * erased.size(), hipMemcpyHostToDevice, s));
+    const size_t w_stride = al(4 * N) / 4, ev_stride = al(8 * N) / 4, blk_stride = al(4 * K) / 4;
+    // 1. locator values at the known points
+    k::erasure_lines(LN, g0, W32(o_er), n_lines, W32(o_la), W32(o_lb), W32(o_lc));
+    k::erasure_points(LN, g0, W32(o_pos), s_cnt, W32(o_px), W32(o_py));
+    k::erasure_zeval(LN, W32(o_px), W32(o_py), s_cnt, W32(o_la), W32(o_lb), W32(o_lc), n_lines, W32(o_zp), W32(o_z));
+    // 2. Z * p on D -> its coefficients
+    FR_HIP(&c, hipMemsetAsync(A + o_w, 0, al(4 * N) * ncols, s));
+    k::erasure_scatter(LN, d_cells, W32(o_src), W32(o_pos), W32(o_z), s_cnt, ncols, log_cell, W32(o_w), w_stride);
+    k::circle_interpolate_block(LN, W32(o_w), w_stride, ncols, n, n, 0, ts0.d_itw, ts0.ds, W32(o_q), w_stride);
+    // 3. onto D', first block of 2^log_coef entries, divided by the locator there
+    k::circle_evaluate(LN, W32(o_q), w_stride, ncols, n, n + 1, ts1.d_tw, ts1.ds, W32(o_ev), ev_stride);
+    k::erasure_points(LN, g1, nullptr, (uint32_t)K, W32(o_px), W32(o_py));
+    k::erasure_zeval(LN, W32(o_px), W32(o_py), (uint32_t)K, W32(o_la), W32(o_lb), W32(o_lc), n_lines, W32(o_zp), W32(o_z));
+    k::erasure_divide(LN, W32(o_ev), ev_stride, W32(o_z), (uint32_t)K, ncols, W32(o_blk), blk_stride);
+    // 4. that block back to coefficients
+    k::circle_interpolate_block(LN, W32(o_blk), blk_stride, ncols, log_coef, n + 1, 0, ts1.d_itw, ts1.ds, d_coef ? d_coef : reinterpret_cast<uint32_t*>(A), K);
+    FR_HIP(&c, hipStreamSynchronize(s));  // pos / src / erased are host memory of this call
+    FR_HIP(&c, hipGetLastError());
+    return FRIEDA_OK;
+}
+}  // namespace
+
+int frieda_circle_interpolate_points(frieda_ctx* ctx, const uint32_t* d_cells, const uint32_t* cell_index, uint32_t n_cells, uint32_t ncols,
+                                     uint32_t log_cell, uint32_t log_coef, uint32_t log_domain, uint32_t* d_coef) {
+    if (!ctx || !d_cells || !cell_index || !d_coef || ncols == 0 || ncols > 1024 || n_cells == 0) return FRIEDA_ERR_ARG;
+    FR_GUARD_BEGIN
+    FR_HIP(&ctx->c, hipSetDevice(ctx->c.device));
+    return interpolate_points(ctx, d_cells, cell_index, n_cells, ncols, log_cell, log_coef, log_domain, d_coef, 0);
+    FR_GUARD_END(ctx)
+}
+
+int frieda_reconstruct_points_device(frieda_ctx* ctx, const uint32_t* d_cells, const uint32_t* cell_index, uint32_t n_cells, uint32_t log_cell,
+                                     uint32_t log_coef, uint32_t log_domain, size_t len, void* d_out_bytes) {
+    if (!ctx || !d_cells || !cell_index || (len && !d_out_bytes) || n_cells == 0) return FRIEDA_ERR_ARG;
+    if (log_coef > FRIEDA_MAX_LOG_DOMAIN) return FRIEDA_ERR_ARG;
+    const size_t n_felts = (size_t)4 << log_coef;
+    if ((8 * len + 29) / 30 > n_felts) return ctx->c.fail(FRIEDA_ERR_ARG, "len does not fit the polynomial");
+    FR_GUARD_BEGIN
+    FR_HIP(&ctx->c, hipSetDevice(ctx->c.device));
+    const size_t coef_bytes = (sizeof(uint32_t) * n_felts + 255) & ~(size_t)255;
+    int rc = interpolate_points(ctx, d_cells, cell_index, n_cells, 4, log_cell, log_coef, log_domain, nullptr, coef_bytes);
+    if (rc) return rc;
+    k::pack30(ctx->c.launch(), reinterpret_cast<const uint32_t*>(ctx->c.arena), n_felts, static_cast<uint8_t*>(d_out_bytes), len);
+    FR_HIP(&ctx->c, hipGetLastError());
+    return FRIEDA_OK;
+    FR_GUARD_END(ctx)
+}
+
 int frieda_merkle_commit_layer(frieda_ctx* ctx, uint32_t log_size, const void* d_prev, const uint32_t* const* d_cols, uint32_t ncols,
                                void* d_out) {
     if (!ctx || !d_out || log_size > FRIEDA_MAX_LOG_DOMAIN || (ncols && !d_cols) || ncols > 1024) return FRIEDA_ERR_ARG;

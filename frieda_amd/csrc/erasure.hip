@@ -1,0 +1,177 @@
+// erasure.hip — reconstruction from ANY sufficiently large set of sampled points of the codeword (the README's
+// sample() flow, /root/reference/README.md:56-69 — not in /root/reference/src, so parity is against the oracle's restatement and
+// encode -> erase -> reconstruct round trips).
+//
+// intt.hip rebuilds a polynomial from exactly 2^L values by inverting a dense system: cubic in the number of cells, capped at 4096.
+// Past that this file uses the erasure-locator route of Reed-Solomon decoding, carried over to the circle domain:
+//
+//   p         the polynomial: 2^L coefficients per column in the circle-FFT basis, degree <= 2^(L-1)
+//   D         the circle domain of the codeword, N = 2^n points; S the known positions, E = D \ S the erased ones, |E| = m even
+//   Z         a circle polynomial vanishing exactly on E: the product over pairs (P, Q) of erased points of the line through P and Q
+//             (a line meets the circle in two points), degree m / 2
+//   Z * p     has degree <= m / 2 + 2^(L-1); while that is <= N / 2 - 1 — i.e. |S| >= 2^L + 2 — it lies in the space of the size-N
+//             circle FFT, and its values on ALL of D are known: Z(P) p(P) on S, zero on E
+//
+//   1. z_i = Z(P_i) for the known points (direct product over the m / 2 lines: O(|S| m), no subproduct tree)
+//   2. w = Z * p on D (zeros at the erased positions); inverse circle FFT of size N -> the N coefficients of Z * p
+//   3. evaluate Z * p on the next larger canonic domain D' (2N points, disjoint from D: no zero of Z lies on it) and take its first
+//      block of 2^L entries; divide by Z there (direct product again): 2^L values of p on a sub-coset of D'
+//   4. inverse transform of that block (intt.hip) -> the coefficients of p
+//
+// Cost: O(|S| (N - |S|)) field multiplications for the two direct products (8e9 for the reference's 128 KiB blob sampled at 2^15 + 2
+// single points of its 2^19 codeword: milliseconds) plus four transforms.  Exact arithmetic: consistent samples give the polynomial.
+#include <hip/hip_runtime.h>
+
+#include "kernels.h"
+
+namespace frieda {
+namespace k {
+
+namespace {
+
+// point of the circle domain of log size g.n at bit-reversed position `pos` (stwo CircleDomain::at over Coset::half_odds(n - 1):
+// natural index j < N / 2 is half_coset[j] = initial + j * step, j >= N / 2 its conjugate)
+__device__ __forceinline__ CPoint domain_point(const ErasureDomain& g, uint32_t pos) {
+    const uint32_t j = g.n ? (__brev(pos) >> (32 - g.n)) : 0u;
+    const bool conj = g.n && ((j >> (g.n - 1)) & 1u);
+    const uint32_t jj = g.n ? (j & ((1u << (g.n - 1)) - 1u)) : 0u;
+    CPoint p = g.init;
+    for (uint32_t b = 0; b + 1 < g.n; b++)
+        if ((jj >> b) & 1u) p = cp_add(p, g.step_pow[b]);
+    if (conj) p.y = m31_neg(p.y);
+    return p;
+}
+
+__global__ void erasure_points_kernel(ErasureDomain g, const uint32_t* __restrict__ pos, uint32_t count, uint32_t* __restrict__ px,
+                                      uint32_t* __restrict__ py) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= count) return;
+    const CPoint p = domain_point(g, pos ? pos[t] : t);
+    px[t] = p.x;
+    py[t] = p.y;
+}
+
+// line a through the erased points 2a and 2a + 1: A x + B y + C with (A, B, C) = (y1 - y2, x2 - x1, x1 y2 - x2 y1)
+__global__ void erasure_lines_kernel(ErasureDomain g, const uint32_t* __restrict__ erased, uint32_t n_lines, uint32_t* __restrict__ la,
+                                     uint32_t* __restrict__ lb, uint32_t* __restrict__ lc) {
+    const uint32_t a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= n_lines) return;
+    const CPoint p = domain_point(g, erased[2 * a]), q = domain_point(g, erased[2 * a + 1]);
+    la[a] = m31_sub(p.y, q.y);
+    lb[a] = m31_sub(q.x, p.x);
+    lc[a] = m31_sub(m31_mul(p.x, q.y), m31_mul(q.x, p.y));
+}
+
+constexpr uint32_t Z_TILE = 512;  // lines staged through LDS per step
+
+// zpart[chunk][t] = product over the lines of chunk `blockIdx.y` of line(P_t); a chunk = lines [chunk * per, (chunk + 1) * per)
+__global__ __launch_bounds__(256) void erasure_zeval_kernel(const uint32_t* __restrict__ px, const uint32_t* __restrict__ py, uint32_t count,
+                                                            const uint32_t* __restrict__ la, const uint32_t* __restrict__ lb,
+                                                            const uint32_t* __restrict__ lc, uint32_t n_lines, uint32_t per,
+                                                            uint32_t* __restrict__ zpart) {
+    __shared__ uint32_t sa[Z_TILE], sb[Z_TILE], sc[Z_TILE];
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t x = t < count ? px[t] : 0u, y = t < count ? py[t] : 0u;
+    const uint32_t first = blockIdx.y * per;
+    const uint32_t last = first + per < n_lines ? first + per : n_lines;
+    uint32_t z = 1;
+    for (uint32_t base = first; base < last; base += Z_TILE) {
+        const uint32_t nt = last - base < Z_TILE ? last - base : Z_TILE;
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < nt; i += blockDim.x) {
+            sa[i] = la[base + i];
+            sb[i] = lb[base + i];
+            sc[i] = lc[base + i];
+        }
+        __syncthreads();
+        for (uint32_t i = 0; i < nt; i++) {
+            // A x + B y + C < 2 (P - 1)^2 + P < 2^63: one reduction
+            const uint32_t v = m31_reduce64((uint64_t)sa[i] * x + (uint64_t)sb[i] * y + sc[i]);
+            z = m31_mul(z, v);
+        }
+    }
+    if (t < count) zpart[(size_t)blockIdx.y * count + t] = z;
+}
+
+__global__ void erasure_zreduce_kernel(const uint32_t* __restrict__ zpart, uint32_t n_chunks, uint32_t count, uint32_t* __restrict__ z) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= count) return;
+    uint32_t v = 1;
+    for (uint32_t c = 0; c < n_chunks; c++) v = m31_mul(v, zpart[(size_t)c * count + t]);
+    z[t] = v;
+}
+
+// w[c][pos[t]] = z[t] * value of column c at known point t (value = cells[src[t] + c * 2^log_cell]); w was zeroed
+__global__ void erasure_scatter_kernel(const uint32_t* __restrict__ cells, const uint32_t* __restrict__ src, const uint32_t* __restrict__ pos,
+                                       const uint32_t* __restrict__ z, uint32_t count, uint32_t ncols, uint32_t log_cell, uint32_t* __restrict__ w,
+                                       size_t w_stride) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= count) return;
+    const uint32_t zt = z[t];
+    const size_t s0 = src[t];
+    const size_t p = pos[t];
+    for (uint32_t c = 0; c < ncols; c++) w[(size_t)c * w_stride + p] = m31_mul(cells[s0 + ((size_t)c << log_cell)], zt);
+}
+
+// block[c][t] = ev[c][t] / z[t], t < count
+__global__ void erasure_divide_kernel(const uint32_t* __restrict__ ev, size_t ev_stride, const uint32_t* __restrict__ z, uint32_t count, uint32_t ncols,
+                                      uint32_t* __restrict__ block, size_t block_stride) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= count) return;
+    const uint32_t zi = m31_inv(z[t]);
+    for (uint32_t c = 0; c < ncols; c++) block[(size_t)c * block_stride + t] = m31_mul(ev[(size_t)c * ev_stride + t], zi);
+}
+
+}  // namespace
+
+size_t erasure_zpart_chunks(uint32_t count, uint32_t n_lines) {
+    if (n_lines == 0) return 1;
+    // enough (point, chunk) pairs to fill the chip (~2^20 threads), at least one LDS tile of lines per chunk, at most 64 chunks
+    size_t want = ((size_t)1 << 20) / (count ? count : 1);
+    if (want < 1) want = 1;
+    if (want > 64) want = 64;
+    const size_t max_by_lines = (n_lines + Z_TILE - 1) / Z_TILE;
+    return want < max_by_lines ? want : max_by_lines;
+}
+
+void erasure_points(const Launch& L_, const ErasureDomain& g, const uint32_t* d_pos, uint32_t count, uint32_t* d_px, uint32_t* d_py) {
+    if (!count) return;
+    Scope scope(L_, "erasure_points", 12.0 * count);
+    erasure_points_kernel<<<(count + 255) / 256, 256, 0, L_.stream>>>(g, d_pos, count, d_px, d_py);
+}
+
+void erasure_lines(const Launch& L_, const ErasureDomain& g, const uint32_t* d_erased, uint32_t n_lines, uint32_t* d_la, uint32_t* d_lb,
+                   uint32_t* d_lc) {
+    if (!n_lines) return;
+    Scope scope(L_, "erasure_lines", 20.0 * n_lines);
+    erasure_lines_kernel<<<(n_lines + 255) / 256, 256, 0, L_.stream>>>(g, d_erased, n_lines, d_la, d_lb, d_lc);
+}
+
+void erasure_zeval(const Launch& L_, const uint32_t* d_px, const uint32_t* d_py, uint32_t count, const uint32_t* d_la, const uint32_t* d_lb,
+                   const uint32_t* d_lc, uint32_t n_lines, uint32_t* d_zpart, uint32_t* d_z) {
+    if (!count) return;
+    const uint32_t chunks = (uint32_t)erasure_zpart_chunks(count, n_lines);
+    const uint32_t per = n_lines ? (n_lines + chunks - 1) / chunks : 0;
+    {
+        Scope scope(L_, "erasure_zeval", 8.0 * count + 12.0 * n_lines);
+        erasure_zeval_kernel<<<dim3((count + 255) / 256, chunks), 256, 0, L_.stream>>>(d_px, d_py, count, d_la, d_lb, d_lc, n_lines, per, d_zpart);
+    }
+    erasure_zreduce_kernel<<<(count + 255) / 256, 256, 0, L_.stream>>>(d_zpart, chunks, count, d_z);
+}
+
+void erasure_scatter(const Launch& L_, const uint32_t* d_cells, const uint32_t* d_src, const uint32_t* d_pos, const uint32_t* d_z, uint32_t count,
+                     uint32_t ncols, uint32_t log_cell, uint32_t* d_w, size_t w_stride) {
+    if (!count) return;
+    Scope scope(L_, "erasure_scatter", (12.0 + 8.0 * ncols) * count);
+    erasure_scatter_kernel<<<(count + 255) / 256, 256, 0, L_.stream>>>(d_cells, d_src, d_pos, d_z, count, ncols, log_cell, d_w, w_stride);
+}
+
+void erasure_divide(const Launch& L_, const uint32_t* d_ev, size_t ev_stride, const uint32_t* d_z, uint32_t count, uint32_t ncols, uint32_t* d_block,
+                    size_t block_stride) {
+    if (!count) return;
+    Scope scope(L_, "erasure_divide", (4.0 + 8.0 * ncols) * count);
+    erasure_divide_kernel<<<(count + 255) / 256, 256, 0, L_.stream>>>(d_ev, ev_stride, d_z, count, ncols, d_block, block_stride);
+}
+
+}  // namespace k
+}  // namespace frieda

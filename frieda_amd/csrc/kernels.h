@@ -112,6 +112,30 @@ void cells_matrix_inverse_device(const Launch& L_, const uint32_t* d_cell_index,
 // inverse of unpack30: felts (30 significant bits each) -> the first `len` bytes of the LSB-first bit stream
 void pack30(const Launch& L_, const uint32_t* d_felts, size_t n_felts, uint8_t* d_out, size_t len);
 
+// ---- erasure.hip (reconstruction from any >= 2^L + 2 sampled points: erasure-locator route) ----
+// the circle domain of log size n as a generator the kernels evaluate per position: initial point of half_odds(n - 1) and the
+// multiples 2^b * step of its step
+struct ErasureDomain {
+    CPoint init;
+    CPoint step_pow[32];
+    uint32_t n;
+};
+// points of the domain at bit-reversed positions d_pos[0 .. count) (d_pos == nullptr: positions 0 .. count - 1)
+void erasure_points(const Launch& L_, const ErasureDomain& g, const uint32_t* d_pos, uint32_t count, uint32_t* d_px, uint32_t* d_py);
+// lines through the erased points (2a, 2a + 1), a < n_lines
+void erasure_lines(const Launch& L_, const ErasureDomain& g, const uint32_t* d_erased, uint32_t n_lines, uint32_t* d_la, uint32_t* d_lb,
+                   uint32_t* d_lc);
+// d_z[t] = product over all lines of line(P_t); d_zpart: erasure_zpart_chunks(count, n_lines) * count words of scratch
+size_t erasure_zpart_chunks(uint32_t count, uint32_t n_lines);
+void erasure_zeval(const Launch& L_, const uint32_t* d_px, const uint32_t* d_py, uint32_t count, const uint32_t* d_la, const uint32_t* d_lb,
+                   const uint32_t* d_lc, uint32_t n_lines, uint32_t* d_zpart, uint32_t* d_z);
+// d_w[c][d_pos[t]] = d_z[t] * d_cells[d_src[t] + c * 2^log_cell] (d_w zeroed by the caller)
+void erasure_scatter(const Launch& L_, const uint32_t* d_cells, const uint32_t* d_src, const uint32_t* d_pos, const uint32_t* d_z, uint32_t count,
+                     uint32_t ncols, uint32_t log_cell, uint32_t* d_w, size_t w_stride);
+// d_block[c][t] = d_ev[c][t] / d_z[t], t < count
+void erasure_divide(const Launch& L_, const uint32_t* d_ev, size_t ev_stride, const uint32_t* d_z, uint32_t count, uint32_t ncols, uint32_t* d_block,
+                    size_t block_stride);
+
 // ---- merkle.hip ----
 // leaves of 4 SoA columns: out[i] = H(c0[i], c1[i], c2[i], c3[i], 0 x 12)
 void merkle_leaf4(const Launch& L, const uint32_t* c0, const uint32_t* c1, const uint32_t* c2, const uint32_t* c3, size_t n,

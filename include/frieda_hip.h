@@ -287,6 +287,21 @@ int frieda_circle_interpolate_cells_any(frieda_ctx* ctx, const uint32_t* d_cells
 int frieda_reconstruct_cells_device(frieda_ctx* ctx, const uint32_t* d_cells, const uint32_t* cell_index, uint32_t n_cells, uint32_t log_cell,
                                     uint32_t log_coef, uint32_t log_domain, size_t len, void* d_out_bytes);
 
+/* Reconstruction from ANY sufficiently large set of samples, with no bound on their number (the README's sample() flow at blob
+ * scale: the reference's 128 KiB `blob` fixture has 2^15 coefficients per column — 2^15 + 2 single sampled points of its 2^19
+ * codeword rebuild it).  Same cell layout as above (d_cells[n_cells][ncols][2^log_cell], cell_index[n_cells] on the host; repeated
+ * cells are ignored); the distinct points offered must number at least 2^log_coef + 2, ALL of them are used, and no system is
+ * solved: the product Z of the lines through pairs of missing points vanishes on everything that was not sampled, Z * p is known
+ * on the whole domain, and p follows by transforms and one pointwise division on a disjoint domain (erasure.hip).  Cost:
+ * O(samples x missing) multiplications + four transforms of the domain size; 1 <= log_coef <= log_domain <= 26.  The samples
+ * must be consistent (values of one polynomial of 2^log_coef coefficients): nothing here detects a corrupted sample — open the
+ * samples against the commitment first (frieda_verify). */
+int frieda_circle_interpolate_points(frieda_ctx* ctx, const uint32_t* d_cells, const uint32_t* cell_index, uint32_t n_cells, uint32_t ncols,
+                                     uint32_t log_cell, uint32_t log_coef, uint32_t log_domain, uint32_t* d_coef);
+/* the same for frieda's 4-column layout, followed by the packer: sampled points -> the original len bytes */
+int frieda_reconstruct_points_device(frieda_ctx* ctx, const uint32_t* d_cells, const uint32_t* cell_index, uint32_t n_cells, uint32_t log_cell,
+                                     uint32_t log_coef, uint32_t log_domain, size_t len, void* d_out_bytes);
+
 /* MerkleOps::commit_on_layer(log_size, prev_layer, columns): d_prev is NULL or 2^(log_size+1) hashes;
  * d_cols is a host array of ncols device column pointers (2^log_size words each); d_out gets 2^log_size
  * 32-byte hashes */

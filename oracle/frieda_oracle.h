@@ -74,6 +74,8 @@ void fo_circle_interpolate_block(const uint32_t* block, uint32_t L, uint32_t n, 
 int fo_reconstruct_cells(const uint32_t* cells, const uint32_t* cell_index, uint32_t R, uint32_t m, uint32_t L, uint32_t n,
                          const uint32_t* tw, const uint32_t* itw, uint32_t* coef_out);
 /* inverse of fo_bytes_to_felt_le: felts (each < 2^30) -> the first `len` bytes of the LSB-first bit stream */
+/* one column from any >= 2^L + 2 distinct sampled points (vals[i] at bit-reversed position pos[i]); erasure-locator route */
+int fo_reconstruct_points(const uint32_t* vals, const uint32_t* pos, uint32_t n_pts, uint32_t L, uint32_t n, uint32_t* coef_out);
 void fo_felts_to_bytes(const uint32_t* felts, size_t n_felts, uint8_t* out, size_t len);
 
 /* ---- Merkle (stwo core/vcs/blake2_merkle.rs::hash_node, backend/cpu/blake2s.rs::commit_on_layer) ---- */

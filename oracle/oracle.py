@@ -94,6 +94,8 @@ def lib():
         L.fo_felts_to_bytes.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
         L.fo_reconstruct_cells.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
         L.fo_reconstruct_cells.restype = C.c_int
+        L.fo_reconstruct_points.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
+        L.fo_reconstruct_points.restype = C.c_int
         L.fo_merkle_commit_layer.argtypes = [C.c_uint32, C.c_void_p, C.POINTER(C.c_void_p), C.c_uint32, C.c_void_p]
         L.fo_merkle_commit.argtypes = [C.POINTER(C.c_void_p), C.c_uint32, C.c_uint32, C.c_void_p]
         L.fo_merkle_layer_offset.restype = C.c_size_t
@@ -223,6 +225,21 @@ def reconstruct_cells(cells, cell_index, n, L, tw=None, itw=None):
         rc = lib().fo_reconstruct_cells(col.ctypes.data, idx.ctypes.data, R, m, L, n, tw.ctypes.data, itw.ctypes.data, out[c].ctypes.data)
         if rc != 0:
             raise ValueError("fo_reconstruct_cells: bad arguments")
+    return out
+
+
+def reconstruct_points(vals, positions, n, L):
+    """vals [n_pts, ncols] = the columns' values at the bit-reversed positions `positions` (any >= 2^L + 2 distinct ones) ->
+    coefficients [ncols, 2^L] (erasure-locator route; quadratic in the domain size: test sizes)."""
+    vals = np.ascontiguousarray(vals, dtype=np.uint32)
+    n_pts, ncols = vals.shape
+    pos = np.ascontiguousarray(positions, dtype=np.uint32)
+    out = np.zeros((ncols, 1 << L), dtype=np.uint32)
+    for c in range(ncols):
+        col = np.ascontiguousarray(vals[:, c])
+        rc = lib().fo_reconstruct_points(col.ctypes.data, pos.ctypes.data, n_pts, L, n, out[c].ctypes.data)
+        if rc != 0:
+            raise ValueError("fo_reconstruct_points: bad arguments or too few distinct points")
     return out
 
 

@@ -1,0 +1,122 @@
+"""GPU: reconstruction from any >= 2^L + 2 sampled points of the codeword, with no bound on their number (erasure.hip,
+frieda_circle_interpolate_points / frieda_reconstruct_points_device) — the README's sample() flow (/root/reference/README.md:56-69; not in
+/root/reference/src) at the size of the reference's own `blob` fixture.  Parity: the oracle's restatement (fo_reconstruct_points, its own
+transforms) and the oracle's dense solve (fo_reconstruct_cells) on small sizes; encode -> sample -> reconstruct == identity at full sizes."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import splitmix64_bytes
+from util import DevBuf
+
+pytestmark = pytest.mark.gpu
+
+P = 2**31 - 1
+
+
+def _check(ctx, rc):
+    from frieda_amd.api import _check as chk
+
+    chk(rc, ctx._h)
+
+
+def _cells(ev, idx, m):
+    return np.ascontiguousarray(np.stack([ev[:, int(c) << m : (int(c) + 1) << m] for c in idx]))  # [R, ncols, 2^m]
+
+
+@pytest.mark.parametrize(
+    "L,n,m,extra,ncols",
+    [(1, 2, 0, 2, 1), (1, 3, 0, 2, 4), (2, 4, 0, 2, 4), (3, 6, 0, 3, 2), (4, 8, 0, 5, 4), (5, 7, 0, 2, 4), (6, 10, 0, 40, 3), (8, 12, 0, 2, 4),
+     (8, 12, 2, 1, 4), (6, 7, 1, 1, 4), (9, 13, 3, 7, 4), (10, 14, 0, 2, 4), (10, 11, 0, 1022, 4)],
+)
+def test_interpolate_points_vs_oracle(gpu_ctx, oracle, L, n, m, extra, ncols):
+    """extra: cells offered beyond the 2^(L - m) that carry 2^L points (m == 0: two spare points are the minimum; negative: all of the
+    domain minus something).  Against the oracle's erasure-locator restatement, its dense solve where that applies, and the truth."""
+    rng = np.random.default_rng(7000 + 100 * L + 10 * n + m)
+    coef = rng.integers(0, P, (ncols, 1 << L), dtype=np.uint32)
+    ev = oracle.circle_evaluate(coef, n)
+    n_cells = (1 << (L - m)) + extra
+    if m > 0:
+        n_cells = max(n_cells, (1 << (L - m)) + 1)  # one more cell of >= 2 points carries the two spare samples
+    n_cells = min(n_cells, 1 << (n - m))
+    idx = rng.permutation(1 << (n - m))[:n_cells].astype(np.uint32)
+    cells = _cells(ev, idx, m)
+    pos = (idx[:, None].astype(np.uint64) * (1 << m) + np.arange(1 << m, dtype=np.uint64)[None, :]).ravel().astype(np.uint32)
+    vals = np.ascontiguousarray(cells.transpose(0, 2, 1).reshape(-1, ncols))  # [n_pts, ncols] in the order of pos
+    if n <= 12:
+        assert np.array_equal(oracle.reconstruct_points(vals, pos, n, L), coef)
+    d_cells, d_c = DevBuf.from_array(gpu_ctx, cells), DevBuf(gpu_ctx, 4 * ncols << L)
+    _check(gpu_ctx, gpu_ctx._L.frieda_circle_interpolate_points(gpu_ctx._h, d_cells.ptr, idx.ctypes.data, n_cells, ncols, m, L, n, d_c.ptr))
+    assert np.array_equal(d_c.to_array(np.uint32, (ncols, 1 << L)), coef)
+    # repeated cells are ignored (first occurrence wins)
+    idx2 = np.concatenate([idx, idx[:3]])
+    cells2 = np.concatenate([cells, np.zeros_like(cells[:3])])
+    d_cells2 = DevBuf.from_array(gpu_ctx, cells2)
+    _check(gpu_ctx, gpu_ctx._L.frieda_circle_interpolate_points(gpu_ctx._h, d_cells2.ptr, idx2.ctypes.data, n_cells + 3, ncols, m, L, n, d_c.ptr))
+    assert np.array_equal(d_c.to_array(np.uint32, (ncols, 1 << L)), coef)
+
+
+def test_interpolate_points_argument_errors(gpu_ctx, oracle):
+    rng = np.random.default_rng(3)
+    L, n = 4, 8
+    coef = rng.integers(0, P, (4, 1 << L), dtype=np.uint32)
+    ev = oracle.circle_evaluate(coef, n)
+    idx = rng.permutation(1 << n)[:18].astype(np.uint32)
+    d_cells, d_c = DevBuf.from_array(gpu_ctx, _cells(ev, idx, 0)), DevBuf(gpu_ctx, 16 << L)
+    f = gpu_ctx._L.frieda_circle_interpolate_points
+    h = gpu_ctx._h
+    assert f(h, d_cells.ptr, idx.ctypes.data, 17, 4, 0, L, n, d_c.ptr) == 1  # 2^L + 1 points: one short
+    assert "2^log_coef + 2" in gpu_ctx._L.frieda_last_error(h).decode()
+    dup = idx.copy()
+    dup[17] = dup[0]
+    assert f(h, d_cells.ptr, dup.ctypes.data, 18, 4, 0, L, n, d_c.ptr) == 1  # 18 offered, 17 distinct
+    bad = idx.copy()
+    bad[5] = 1 << n
+    assert f(h, d_cells.ptr, bad.ctypes.data, 18, 4, 0, L, n, d_c.ptr) == 1  # position outside the domain
+    assert f(h, d_cells.ptr, idx.ctypes.data, 18, 4, 0, 0, n, d_c.ptr) == 1  # a constant polynomial: use the cells entry
+    assert f(h, d_cells.ptr, idx.ctypes.data, 18, 4, 0, L, 27, d_c.ptr) == 1  # beyond the supported domain
+    assert f(h, d_cells.ptr, idx.ctypes.data, 0, 4, 0, L, n, d_c.ptr) == 1
+    assert f(h, None, idx.ctypes.data, 18, 4, 0, L, n, d_c.ptr) == 1
+    _check(gpu_ctx, f(h, d_cells.ptr, idx.ctypes.data, 18, 4, 0, L, n, d_c.ptr))
+    assert np.array_equal(d_c.to_array(np.uint32, (4, 1 << L)), coef)
+
+
+def _encode_on_device(gpu_ctx, data, B):
+    L_ = gpu_ctx._L
+    nf, npad, lg = C.c_size_t(), C.c_size_t(), C.c_uint32()
+    L_.frieda_codec_shape(len(data), C.byref(nf), C.byref(npad), C.byref(lg))
+    L, n = lg.value, lg.value + B
+    d_in = DevBuf.from_array(gpu_ctx, np.frombuffer(data, dtype=np.uint8))
+    d_coef, d_ev = DevBuf(gpu_ctx, 4 * npad.value), DevBuf(gpu_ctx, 16 << n)
+    _check(gpu_ctx, L_.frieda_unpack30(gpu_ctx._h, d_in.ptr, len(data), d_coef.ptr, npad.value))
+    _check(gpu_ctx, L_.frieda_circle_evaluate(gpu_ctx._h, d_coef.ptr, 4, L, n, d_ev.ptr))
+    return d_ev.to_array(np.uint32, (4, 1 << n)), L, n
+
+
+def test_reference_blob_from_single_sampled_points(gpu_ctx, blob):
+    """The reference's own fixture (/root/reference/blob, 262 146 bytes -> 2^15 coefficients per column, 2^19-point codeword at the
+    benches' blow-up): 2^15 + 2 single points sampled anywhere in the codeword give the blob back, byte for byte.  (Round 2 stopped at
+    4096 cells, i.e. blobs of 61 KB for single points.)"""
+    ev, L, n = _encode_on_device(gpu_ctx, blob, 4)
+    assert (L, n) == (15, 19)
+    rng = np.random.default_rng(2026)
+    for n_pts in ((1 << L) + 2, (1 << L) + 3, (1 << L) + 5000, 1 << (n - 1)):
+        idx = rng.permutation(1 << n)[:n_pts].astype(np.uint32)
+        cells = _cells(ev, idx, 0)
+        assert gpu_ctx.reconstruct_from_points(cells, idx, L, n, len(blob)) == blob, n_pts
+
+
+@pytest.mark.parametrize("n_bytes,B,m,extra_cells", [(3000, 2, 0, 2), (70001, 2, 1, 1), (983040, 4, 2, 9), (983040, 1, 0, 2), (3932160, 4, 0, 2),
+                                                     (3932160, 4, 6, 33), (61440, 7, 0, 2)])
+def test_encode_sample_points_reconstruct_round_trip(gpu_ctx, n_bytes, B, m, extra_cells):
+    """encode -> a sampling client's view (cells of 2^m entries scattered over the whole codeword, a handful more than the minimum) ->
+    the original bytes; cell counts far beyond the 4096 of the dense solver (up to 2^18 + 2 single points on a 2^22 domain)."""
+    data = splitmix64_bytes(31 + m, n_bytes).tobytes()
+    ev, L, n = _encode_on_device(gpu_ctx, data, B)
+    m = min(m, L)
+    rng = np.random.default_rng(n_bytes + B)
+    n_cells = (1 << (L - m)) + extra_cells
+    idx = rng.permutation(1 << (n - m))[:n_cells].astype(np.uint32)
+    cells = _cells(ev, idx, m) if n_cells < 70000 else np.ascontiguousarray(ev.reshape(4, -1, 1 << m)[:, idx, :].transpose(1, 0, 2))
+    assert gpu_ctx.reconstruct_from_points(cells, idx, L, n, n_bytes) == data

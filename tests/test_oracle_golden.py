@@ -301,3 +301,26 @@ def test_known_singular_point_set_is_reported(oracle):
         oracle.reconstruct_cells(np.ascontiguousarray(ev[:, sing].T.reshape(-1, 1, 1)), sing, 5, 3)
     ok = np.array([1, 3, 4, 8, 11, 14, 16, 30], dtype=np.uint32)  # one point exchanged
     assert np.array_equal(oracle.reconstruct_cells(np.ascontiguousarray(ev[:, ok].T.reshape(-1, 1, 1)), ok, 5, 3), coef)
+
+
+@pytest.mark.parametrize("L,n,extra", [(1, 3, 2), (2, 4, 2), (3, 6, 3), (4, 8, 5), (5, 7, 2), (6, 10, 40), (7, 8, 120)])
+def test_reconstruct_points_matches_dense_solve_and_round_trip(oracle, L, n, extra):
+    """fo_reconstruct_points (any >= 2^L + 2 sampled points; erasure-locator route, the restatement frieda_circle_interpolate_points is
+    compared with on the GPU) against the truth and against the independent dense solve of fo_reconstruct_cells on the same samples."""
+    rng = np.random.default_rng(9000 + 10 * L + n)
+    P = 2**31 - 1
+    coef = rng.integers(0, P, (2, 1 << L), dtype=np.uint32)
+    ev = oracle.circle_evaluate(coef, n)
+    pos = rng.permutation(1 << n)[: (1 << L) + extra].astype(np.uint32)
+    vals = np.ascontiguousarray(ev[:, pos].T)
+    assert np.array_equal(oracle.reconstruct_points(vals, pos, n, L), coef)
+    # repeated positions are ignored; one point short is refused
+    assert np.array_equal(oracle.reconstruct_points(np.concatenate([vals, vals[:2]]), np.concatenate([pos, pos[:2]]), n, L), coef)
+    with pytest.raises(ValueError):
+        oracle.reconstruct_points(vals[: (1 << L) + 1], pos[: (1 << L) + 1], n, L)
+    if L >= 2:
+        try:
+            dense = oracle.reconstruct_cells(np.ascontiguousarray(ev[:, pos[: 1 << L]].T.reshape(1 << L, 2, 1)), pos[: 1 << L], n, L)
+        except ValueError:
+            return  # (a singular set of exactly 2^L single points: the dense route's own limitation)
+        assert np.array_equal(dense, coef)

@@ -34,3 +34,22 @@ for j in (0, 2, 4, 6, 8):
         dt = time.perf_counter() - t0
     assert rc == 0 and d_o.to_array(np.uint8, (data.size,)).tobytes() == data.tobytes()
     print(f"| {1 << j} | 2^{m} | {1e3 * dt:.2f} |")
+
+# any >= 2^L + 2 points (frieda_reconstruct_points_device: erasure-locator route, no bound on the number of cells)
+print("\n| points path: cells | cell words | spare cells | ms |")
+print("|---|---|---|---|")
+for m, extra in ((0, 2), (0, 1 << (L - 2)), (4, 8), (8, 2), (L - 4, 1)):
+    if m > L:
+        continue
+    n_cells = (1 << (L - m)) + extra
+    idx = rng.permutation(1 << (n - m))[:n_cells].astype(np.uint32)
+    cells = np.ascontiguousarray(ev.reshape(4, -1, 1 << m)[:, idx, :].transpose(1, 0, 2))
+    d_cells, d_o = DevBuf.from_array(ctx, cells), DevBuf(ctx, data.size + 8)
+    for rep in range(3):
+        ctx.synchronize()
+        t0 = time.perf_counter()
+        rc = L_.frieda_reconstruct_points_device(ctx._h, d_cells.ptr, idx.ctypes.data, n_cells, m, L, n, data.size, d_o.ptr)
+        ctx.synchronize()
+        dt = time.perf_counter() - t0
+    assert rc == 0 and d_o.to_array(np.uint8, (data.size,)).tobytes() == data.tobytes()
+    print(f"| {n_cells} | 2^{m} | {extra} | {1e3 * dt:.2f} |")
