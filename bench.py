@@ -77,11 +77,13 @@ def algorithmic_bytes(n, workload, log_blowup=4, log_last=0):
 def traffic_from_profiles(kernel, n, workload):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE collected
     in separate runs and corrected as MI355X_MICROARCH.md §HBM prescribes; tools/traffic_from_pmc.py).  Only valid for the
-    configuration the counters were taken on (2^24 domain).  Returns (bytes or None, source description): the number is a
-    committed measurement of an earlier run of this same command, NOT something this run measured."""
+    configuration the counters were taken on (2^24 domain).  Returns (bytes or None, source description, per-blob bytes of the same
+    kernel in the measured loop's batched mode or None): committed measurements of an earlier run of this same command, NOT something
+    this run measured.  `traffic` is the lone-proof figure: the mode of the instrumented replay that `achieved` and `avg_launch_us`
+    come from."""
     if n != 24:
-        return None, f"none: the committed PMC passes were taken on the 2^24 domain, this run is 2^{n}"
-    for name in ("r02_prove24_traffic.json", "r01_prove24_traffic.json"):
+        return None, f"none: the committed PMC passes were taken on the 2^24 domain, this run is 2^{n}", None
+    for name in ("r03_prove24_traffic.json", "r02_prove24_traffic.json", "r01_prove24_traffic.json"):
         path = os.path.join(ROOT, "profiles", name)
         if not os.path.exists(path):
             continue
@@ -90,11 +92,17 @@ def traffic_from_profiles(kernel, n, workload):
             val = doc["kernels"][kernel]["traffic_bytes_per_launch"]
         except (KeyError, ValueError):
             continue
-        src = f"profiles/{name} (committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command"
+        src = f"profiles/{name} (committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command in lone-proof mode, --batch 1 --in-flight 1"
         if doc.get("collected_at_commit"):
             src += f", collected at commit {doc['collected_at_commit']}"
-        return val, src + "; not re-measured in this run)"
-    return None, "none: no committed PMC pass names this kernel"
+        bat = None
+        try:
+            b = doc["batched"]
+            bat = b["kernels"][kernel]["traffic_bytes_per_launch"] / b["blobs_per_launch"]
+        except (KeyError, TypeError):
+            pass
+        return val, src + "; not re-measured in this run)", bat
+    return None, "none: no committed PMC pass names this kernel", None
 
 
 def _host_threads():
@@ -698,6 +706,8 @@ def main():
             "frac": ach / HBM_PEAK_GBS,
             "traffic": traffic_from_profiles(dom["name"], n, args.workload)[0],
             "traffic_source": traffic_from_profiles(dom["name"], n, args.workload)[1],
+            "traffic_mode": "lone proof (one blob per launch), the mode of the instrumented replay behind achieved / avg_launch_us",
+            "traffic_per_blob_in_measured_loop": traffic_from_profiles(dom["name"], n, args.workload)[2],
             "avg_launch_us": 1e3 * dom["total_ms"] / max(dom["launches"], 1),
             "launches_per_step": dom["launches"] / args.steps,
             "alg_bytes_per_launch": dom["alg_bytes"] / max(dom["launches"], 1),

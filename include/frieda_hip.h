@@ -92,8 +92,8 @@ int frieda_ctx_last_prove_phases(const frieda_ctx* ctx, double out_ms[8]);
 size_t frieda_ctx_kernel_timing_report(frieda_ctx* ctx, char* buf, size_t cap, int reset);
 /* measurement aid: the pure-compute rate of the Merkle compression on THIS device, now — compressions per second with every
  * lane chaining Blake2s compressions on register-resident data (8 workgroups per CU), leaf-shaped (4 message words, 12 zero) and
- * node-shaped (16 words).  The path is bound by this rate, which depends on the clock the chip holds under the load and on the
- * device; bench.py quotes it beside the measured kernels (roofline_valu) instead of a constant.  ~5 ms; synchronises the stream. */
+ * node-shaped (16 words).  The path is bound by this rate, which differs by a few per cent between devices; bench.py quotes it
+ * beside the measured kernels (roofline_valu) instead of a constant.  ~5 ms; synchronises the stream. */
 int frieda_ctx_blake2s_ceiling(frieda_ctx* ctx, double* leaf_per_s, double* node_per_s);
 /* the same after ~0.25 s of that load per shape (~0.5 s in all), with the clock the chip holds under it read inside the kernel (shader-clock counter against
  * the 100 MHz wall-clock counter, median over the workgroups): out = {leaf compressions/s, node compressions/s, leaf clock GHz,

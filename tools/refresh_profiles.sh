@@ -11,13 +11,19 @@ COMMIT=${2:-}
 OUT=gpurun_out/refresh
 mkdir -p $OUT
 export TMPDIR=/tmp
-ONE="--no-cpu-baseline --batch 1 --in-flight 1 --batch-extra 0 --sequential-extra 0"
+ONE="--no-cpu-baseline --no-by-config --no-end-to-end --batch 1 --in-flight 1 --batch-extra 0 --sequential-extra 0"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 bench.py --steps 2 --warmup 1 $ONE > /dev/null 2> $OUT/pmc_fetch_err.txt
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 bench.py --steps 2 --warmup 1 $ONE > /dev/null 2> $OUT/pmc_write_err.txt
-python tools/traffic_from_pmc.py $OUT/pmc_fetch $OUT/pmc_write $OUT/${TAG}_prove24_traffic.json $COMMIT
+# the same two passes in the measured loop's own mode (4 blobs per call, 2 calls in flight): launches cover 4 blobs each
+BAT="--no-cpu-baseline --no-by-config --no-end-to-end --batch-extra 0 --sequential-extra 0"
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_b -- python3 bench.py --steps 8 --warmup 0 $BAT > /dev/null 2> $OUT/pmc_fetch_b_err.txt
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_b -- python3 bench.py --steps 8 --warmup 0 $BAT > /dev/null 2> $OUT/pmc_write_b_err.txt
+python tools/traffic_from_pmc.py $OUT/pmc_fetch $OUT/pmc_write $OUT/${TAG}_prove24_traffic.json "$COMMIT" $OUT/pmc_fetch_b $OUT/pmc_write_b
 cp $OUT/${TAG}_prove24_traffic.json profiles/${TAG}_prove24_traffic.json
 cp $(ls $OUT/pmc_fetch/*/*counter_collection.csv | head -1) $OUT/${TAG}_prove24_pmc_FETCH_SIZE.csv
 cp $(ls $OUT/pmc_write/*/*counter_collection.csv | head -1) $OUT/${TAG}_prove24_pmc_WRITE_SIZE.csv
+cp $(ls $OUT/pmc_fetch_b/*/*counter_collection.csv | head -1) $OUT/${TAG}_prove24_batched_pmc_FETCH_SIZE.csv
+cp $(ls $OUT/pmc_write_b/*/*counter_collection.csv | head -1) $OUT/${TAG}_prove24_batched_pmc_WRITE_SIZE.csv
 if [ -z "${ONLY_PROF:-}" ]; then
 python bench.py > $OUT/${TAG}_prove24_bench.json 2> $OUT/prove_err.txt
 python bench.py --workload commit > $OUT/${TAG}_commit24_bench.json 2> $OUT/commit_err.txt
@@ -29,5 +35,5 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 be
 cp $(ls $OUT/stats/*/*kernel_stats.csv | head -1) $OUT/${TAG}_prove24_kernel_stats.csv
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats22 -- python3 bench.py --log-domain 22 --steps 10 --warmup 3 $ONE > $OUT/stats22_run.json 2> $OUT/stats22_err.txt
 cp $(ls $OUT/stats22/*/*kernel_stats.csv | head -1) $OUT/${TAG}_prove22_kernel_stats.csv
-rm -rf $OUT/stats $OUT/stats22 $OUT/pmc_fetch $OUT/pmc_write
+rm -rf $OUT/stats $OUT/stats22 $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_fetch_b $OUT/pmc_write_b
 ls -la $OUT

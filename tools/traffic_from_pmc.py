@@ -5,7 +5,7 @@ Per kernel family (the names bench.py's HIP-event timer uses), averaged per laun
     traffic_bytes = 1024 * (fetch_correction * FETCH_SIZE + WRITE_SIZE)
 with the correction calibrated per kernel symbol on known byte counts (RULES below), as the guide prescribes.
 
-usage: python tools/traffic_from_pmc.py <fetch_dir | counter_collection.csv> <write_dir | counter_collection.csv> <out.json>
+usage: python tools/traffic_from_pmc.py <fetch_dir | counter_collection.csv> <write_dir | counter_collection.csv> <out.json> [commit [<fetch_dir batched> <write_dir batched>]]
 """
 import collections
 import csv
@@ -82,20 +82,35 @@ def main():
         commit = ""
     res = {"collected_at_commit": (sys.argv[4] if len(sys.argv) > 4 else commit) or None,
            "_units": "averages per launch of the kernel family over the profiled run; traffic_bytes_per_launch in bytes; "
-                     "FETCH_SIZE corrected per kernel symbol (RULES in tools/traffic_from_pmc.py)", "kernels": {}}
-    for fam in sorted(set(fa) | set(wa)):
-        nf, nw = max(fc.get(fam, 0), 1), max(wc.get(fam, 0), 1)
-        f, w = fa.get(fam, 0.0) / nf, wa.get(fam, 0.0) / nw
-        res["kernels"][fam] = {
-            "launches_profiled": fc.get(fam, 0),
-            "FETCH_SIZE_KiB_per_launch": fraw.get(fam, 0.0) / nf,
-            "FETCH_corrected_KiB_per_launch": f,
-            "WRITE_SIZE_KiB_per_launch": w,
-            "traffic_bytes_per_launch": 1024.0 * (f + w),
-        }
+                     "FETCH_SIZE corrected per kernel symbol (RULES in tools/traffic_from_pmc.py)",
+           "mode": "lone proofs (bench.py --batch 1 --in-flight 1): one blob per launch, nothing else on the chip — the launches bench.py's "
+                   "instrumented replay times", "kernels": {}}
+
+    def table(fa, fraw, fc, wa, wc):
+        t = {}
+        for fam in sorted(set(fa) | set(wa)):
+            nf, nw = max(fc.get(fam, 0), 1), max(wc.get(fam, 0), 1)
+            f, w = fa.get(fam, 0.0) / nf, wa.get(fam, 0.0) / nw
+            t[fam] = {
+                "launches_profiled": fc.get(fam, 0),
+                "FETCH_SIZE_KiB_per_launch": fraw.get(fam, 0.0) / nf,
+                "FETCH_corrected_KiB_per_launch": f,
+                "WRITE_SIZE_KiB_per_launch": w,
+                "traffic_bytes_per_launch": 1024.0 * (f + w),
+            }
+        return t
+
+    res["kernels"] = table(fa, fraw, fc, wa, wc)
+    if len(sys.argv) > 6:  # second pair of passes: the measured loop's own mode (4 blobs per launch, 2 calls in flight)
+        fb, fbraw, fbc = collect(sys.argv[5], True)
+        wb, _, wbc = collect(sys.argv[6], False)
+        res["batched"] = {"mode": "the measured loop (bench.py default: 4 blobs per call, 2 calls in flight): a launch covers 4 blobs",
+                          "blobs_per_launch": 4, "kernels": table(fb, fbraw, fbc, wb, wbc)}
     json.dump(res, open(out, "w"), indent=1)
     for k, v in res["kernels"].items():
-        print(f"{k:20s} launches {v['launches_profiled']:4d}  traffic/launch {v['traffic_bytes_per_launch'] / 1e6:9.1f} MB")
+        b = res.get("batched", {}).get("kernels", {}).get(k)
+        extra = f"   batched: {b['traffic_bytes_per_launch'] / 4e6:9.1f} MB per blob ({b['launches_profiled']} launches)" if b else ""
+        print(f"{k:20s} launches {v['launches_profiled']:4d}  traffic/launch {v['traffic_bytes_per_launch'] / 1e6:9.1f} MB{extra}")
 
 
 if __name__ == "__main__":
