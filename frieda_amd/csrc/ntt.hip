@@ -706,7 +706,8 @@ uint32_t circle_evaluate_into_tree(const Launch& L_, const uint32_t* d_coef, siz
     const uint32_t last_t = L < TILE_LOG ? L : TILE_LOG;
     uint32_t rest = L - last_t;
     const uint32_t mid_max = TILE_LOG - MID_LOG_W;
-    const uint32_t n_mid = (rest + mid_max - 1) / mid_max;
+    const uint32_t n_mid_generic = (rest + mid_max - 1) / mid_max;
+    uint32_t n_mid_fast = 0;  // strided passes of the fast plan (0: the generic plan's n_mid_generic)
     NttArgs a{};
     a.in = d_coef;
     a.in_stride = coef_stride;
@@ -735,7 +736,7 @@ uint32_t circle_evaluate_into_tree(const Launch& L_, const uint32_t* d_coef, siz
             // algorithmic bytes: this pass's share of the encode + leaves (16 B in, 32 B out) + 6 node levels (96 B per node)
             static const bool reg_only = getenv("FRIEDA_NTT_TREE_REG_ONLY") != nullptr;  // A/B knob
             const uint32_t levels = reg_only ? 5u : ENCODE_TREE_LEVELS;
-            double bytes = enc_bytes / (n_mid + 1) + 48.0 * (double)N;
+            double bytes = enc_bytes / ((n_mid_fast ? n_mid_fast : n_mid_generic) + 1) + 48.0 * (double)N;
             for (uint32_t l = 1; l < levels; l++) bytes += 96.0 * (double)(N >> l);
             Scope scope(L_, reg_only ? "ntt_last_tree5" : "ntt_last_tree7", bytes);
             const dim3 grid((unsigned)(N >> TILE_LOG), 1, L_.batch);
@@ -750,7 +751,7 @@ uint32_t circle_evaluate_into_tree(const Launch& L_, const uint32_t* d_coef, siz
             fused_levels = levels;
             return;
         }
-        Scope scope(L_, name, enc_bytes / (n_mid + 1));
+        Scope scope(L_, name, enc_bytes / ((n_mid_fast ? n_mid_fast : n_mid_generic) + 1));
         // FRIEDA_NTT_REP=1: one workgroup per source tile looping over the high blocks (ntt_tile12_rep_kernel).  Off by default: it
         // cuts the pass's fetches from the memory side to the unique coefficients but is no faster (142 vs 140 us at 2^24, 41 vs 35 us at
         // 2^22, profiles/r03_ntt_mid_rep_ab.txt) — the pass is bound by its butterflies and LDS round trips, not by the re-reads,
@@ -767,13 +768,15 @@ uint32_t circle_evaluate_into_tree(const Launch& L_, const uint32_t* d_coef, siz
             dim3 grid((unsigned)((N >> TILE_LOG) >> a.rep_log), ncols / 2, L_.batch);
             ntt_tile12_rep_kernel<2><<<grid, NTT_THREADS, 0, s>>>(a);
             a.rep_log = 0;
-        } else if (aligned && t + a.log_w == TILE_LOG && (t == 12 || t == 8)) {
+        } else if (aligned && t + a.log_w == TILE_LOG && (t == 12 || t == 8 || t == 4)) {
             a.ncols = cpw4;
             dim3 grid((unsigned)(N >> TILE_LOG), ncols / cpw4, L_.batch);
-            if (a.log_w == 0)
+            if (t == 12)
                 ntt_tile12_kernel<3, 0><<<grid, NTT_THREADS, 0, s>>>(a);
-            else
+            else if (t == 8)
                 ntt_tile12_kernel<2, MID_LOG_W><<<grid, NTT_THREADS, 0, s>>>(a);
+            else
+                ntt_tile12_kernel<1, 8><<<grid, NTT_THREADS, 0, s>>>(a);  // one radix-16 stage, 1 KiB runs
         } else {
             a.ncols = cpw;
             set_stages(a, t);
@@ -783,27 +786,42 @@ uint32_t circle_evaluate_into_tree(const Launch& L_, const uint32_t* d_coef, siz
     };
     a.in_limit = a.in_mask + 1;
     uint32_t i_hi = L - 1;
-    // A single strided pass of fewer than 8 real layers (2^20 and 2^22 domains at blow-up 16: 4 and 6) runs as the fast 8-layer
-    // kernel with its top `pad` layers taken from the zero-padded ones: those are executed as real butterflies against zero
-    // coefficients (source words beyond 2^L read as zero instead of wrapping), which costs less than the generic kernel saves
-    // (44.8 -> 28 us at 2^22, 19.9 -> 8 us at 2^20).
-    static const bool no_pad8 = getenv("FRIEDA_NTT_NO_PAD8") != nullptr;  // A/B knob
-    if (!no_pad8 && n_mid == 1 && rest < mid_max && (mid_max - rest) <= (n - L) && L >= 4 && ((a.in_stride | a.out_stride) & 3) == 0 &&
-        ((reinterpret_cast<uintptr_t>(a.in) | reinterpret_cast<uintptr_t>(a.out) | L_.bstride) & 15) == 0) {
-        const uint32_t pad = mid_max - rest;
-        a.i_hi = L - 1 + pad;
-        a.i_lo = last_t;  // == 12
-        a.log_w = MID_LOG_W;
-        a.in_mask = (uint32_t)(((size_t)1 << (L + pad)) - 1);
-        a.in_limit = (uint32_t)1 << L;
-        launch_pass(mid_max, "ntt_pass_mid");
-        a.in = d_out;
-        a.in_stride = out_stride;
-        a.in_mask = (uint32_t)(N - 1);
-        a.in_limit = (uint32_t)N;
+    // The strided layers run as passes of the fast kernel: 8 layers (two radix-16 stages, 64-byte runs) or 4 layers (one stage, 1 KiB
+    // runs), a 4-layer pass first when the number of 4-layer units is odd.  `rest` is rounded up to a multiple of 4 with up to three of the
+    // zero-padded layers above the coefficient vector: the first pass executes them as real butterflies against zero coefficients (source
+    // words beyond 2^L read as zero instead of wrapping), which costs less than the generic kernel saves (44.8 -> 28 us at 2^22, 623 ->
+    // 3xx us for the 9 strided layers of a 2^25 domain).  Needs padz <= log_blowup_factor and 16-byte aligned buffers; otherwise the
+    // generic passes below take over.
+    static const bool no_pad8 = getenv("FRIEDA_NTT_NO_PAD8") != nullptr;  // A/B knob: generic kernel unless a pass has exactly 8 real layers
+    const uint32_t units = (rest + 3) / 4, padz = 4 * units - rest;
+    const bool base_aligned = ((a.in_stride | a.out_stride) & 3) == 0 &&
+                              ((reinterpret_cast<uintptr_t>(a.in) | reinterpret_cast<uintptr_t>(a.out) | L_.bstride) & 15) == 0;
+    if (rest > 0 && base_aligned && padz <= n - L && L >= 4 && (!no_pad8 || (padz == 0 && (units & 1) == 0))) {
+        n_mid_fast = (units + 1) / 2;
+        uint32_t top = L - 1 + padz, left = units;
+        bool first = true;
+        while (left) {
+            const uint32_t t = (left & 1) ? 4u : 8u;
+            a.i_hi = top;
+            a.i_lo = top + 1 - t;
+            a.log_w = TILE_LOG - t;
+            if (first) {
+                a.in_mask = (uint32_t)(((size_t)1 << (L + padz)) - 1);
+                a.in_limit = (uint32_t)1 << L;
+            }
+            launch_pass(t, "ntt_pass_mid");
+            a.in = d_out;
+            a.in_stride = out_stride;
+            a.in_mask = (uint32_t)(N - 1);
+            a.in_limit = (uint32_t)N;
+            top -= t;
+            left -= t / 4;
+            first = false;
+        }
         rest = 0;
         i_hi = last_t - 1;
     }
+    const uint32_t n_mid = n_mid_generic;
     for (uint32_t p = 0; p < n_mid && rest; p++) {
         uint32_t t = (rest + (n_mid - p) - 1) / (n_mid - p);
         a.i_hi = i_hi;

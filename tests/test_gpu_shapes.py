@@ -5,12 +5,13 @@ oracle, bit-exact.
 coefficients per column, n = L + log_blowup_factor (/root/reference/src/commit.rs:14-16).  The planner splits the L real layers into a
 contiguous last pass of min(L, 12) layers and strided passes over the `rest = L - 12` layers above it, and picks a kernel per pass:
 
-  * `last12`            rest == 0 (L <= 12): only the contiguous pass (reads the coefficients themselves, replicated)
-  * `pad8(pad=k)`       one strided pass of 1..7 real layers run as the fast 8-layer kernel, its top k = 8 - rest layers being zero-padded
-                        layers executed against zero coefficients (needs k <= log_blowup_factor)
-  * `generic(t,w)`      one strided pass of t < 8 layers through the generic kernel with runs of 2^w words (k > log_blowup_factor)
-  * `fast8`             rest == 8: the 8-layer kernel on real layers only
-  * `two(t1+t2)`        rest > 8: two strided passes (generic unless a pass has exactly 8 layers)
+  * `last12`              rest == 0 (L <= 12): only the contiguous pass (reads the coefficients themselves, replicated)
+  * `fast(4)`, `fast(8)`, `fast(4+8)`, `fast(8+8)` ...
+                          the strided layers as passes of the fast kernel — 8 layers (two radix-16 stages) or 4 layers (one stage), a
+                          4-layer pass first when the number of 4-layer units is odd — with `pad=k`: rest rounded up to a multiple of 4 by
+                          k = 1..3 zero-padded layers, which the first pass executes against zero coefficients (needs k <= log_blowup_factor)
+  * `generic(t,w)`        k > log_blowup_factor, rest < 8: one strided pass of t layers through the generic kernel with runs of 2^w words
+  * `two(t1+t2)`          k > log_blowup_factor, rest > 8: two generic strided passes
 
 `encode_plan` below mirrors that decision so that every test id names the branch it reaches; the product is not told which branch to
 take (the mirror is only used for the ids and to assert that the matrix covers all of them).
@@ -34,11 +35,13 @@ def encode_plan(L, B):
     if L <= 12:
         return "last12"
     rest = L - 12
-    if rest == 8:
-        return "fast8"
+    units = (rest + 3) // 4
+    pad = 4 * units - rest
+    if pad <= B:
+        passes = (["4"] if units & 1 else []) + ["8"] * (units // 2)
+        return f"fast({'+'.join(passes)}{',pad=%d' % pad if pad else ''})"
     if rest < 8:
-        pad = 8 - rest
-        return f"pad8(pad={pad})" if pad <= B and L >= 4 else f"generic(t={rest},w={12 - rest})"
+        return f"generic(t={rest},w={12 - rest})"
     t1 = (rest + 1) // 2
     return f"two({t1}+{rest - t1})"
 
@@ -61,16 +64,16 @@ for _L in (16, 17, 18, 19, 20, 21):
             if _L == 21 and _B == 4 and _kind == "halfplus1":
                 continue  # 2^25 domain: two lengths are enough (the oracle needs ~25 s each)
             COMMIT_CASES.append(pytest.param(_L, _B, _len, id=f"L{_L}-B{_B}-{encode_plan(_L, _B)}-{_kind}"))
-# the padded 8-layer pass with 5..7 zero layers needs a blow-up of at least 2^5; and rest 1..3 below it
-for _L, _B in ((13, 7), (14, 6), (15, 5), (13, 5), (14, 5), (15, 8)):
+# rest 1..3 (a single padded 4-layer pass, or the generic kernel when the blow-up is smaller than the padding), large blow-ups, L = 22
+for _L, _B in ((13, 7), (14, 6), (15, 5), (13, 2), (14, 1), (15, 1), (22, 2), (22, 1)):
     COMMIT_CASES.append(pytest.param(_L, _B, exact_len(_L) - 777, id=f"L{_L}-B{_B}-{encode_plan(_L, _B)}-ragged"))
 
 
 def test_matrix_reaches_every_planner_branch():
-    seen = {c.id.split("-")[2].split("(")[0] for c in COMMIT_CASES}
-    assert {"pad8", "generic", "fast8", "two"} <= seen
-    pads = {c.id.split("-")[2] for c in COMMIT_CASES if "pad8" in c.id}
-    assert {f"pad8(pad={k})" for k in range(1, 8)} <= pads
+    seen = {c.id.split("-")[2] for c in COMMIT_CASES} | {f"{encode_plan(L, n - L)}" for L, n in EVAL_CASES}
+    for want in ("fast(4)", "fast(8)", "fast(4+8)", "fast(8,pad=1)", "fast(8,pad=2)", "fast(8,pad=3)", "fast(4,pad=1)", "fast(4,pad=2)", "fast(4,pad=3)",
+                 "fast(4+8,pad=3)", "fast(4+8,pad=2)", "generic(t=5,w=7)", "generic(t=6,w=6)", "two(5+4)"):
+        assert want in seen, (want, sorted(seen))
     for L in (16, 17, 18, 19, 20, 21):
         fp = 4
         F = (8 * shape_lengths(L)["halfplus1"] + 29) // 30
@@ -111,9 +114,11 @@ PROVE_CASES = [
     (18, 1, "exact", 8, 0, 20),  # generic single pass (pad 2 > B), 2^19 domain
     (21, 1, "ragged", 6, 2, 20),  # two strided passes, 2^22 domain
     (16, 3, "halfplus1", 8, 0, 20),  # generic (pad 4 > B), 2^19 domain
-    (14, 6, "ragged", 6, 0, 20),  # pad 6
-    (15, 5, "exact", 6, 3, 20),  # pad 5
-    (13, 7, "ragged", 6, 0, 20),  # pad 7
+    (14, 6, "ragged", 6, 0, 20),  # one 4-layer pass, pad 2
+    (15, 5, "exact", 6, 3, 20),  # one 4-layer pass, pad 1
+    (13, 7, "ragged", 6, 0, 20),  # one 4-layer pass, pad 3
+    (13, 2, "ragged", 6, 0, 20),  # generic (pad 3 > B)
+    (21, 3, "exact", 6, 0, 20),  # 4-layer pass (pad 3: one real layer) + 8-layer pass, 2^24 domain
 ]
 
 
@@ -134,7 +139,7 @@ def test_whole_proof_mb_scale_shapes(gpu_ctx, oracle, L, B, kind, pow_bits, last
     assert frieda_amd.verify(g_proof, length)
 
 
-EVAL_CASES = [(17, 21), (19, 23), (17, 18), (19, 20), (21, 25), (21, 22), (18, 19), (16, 17), (22, 23), (20, 24)]
+EVAL_CASES = [(17, 21), (19, 23), (17, 18), (19, 20), (21, 25), (21, 22), (18, 19), (16, 17), (22, 23), (20, 24), (22, 24), (24, 25), (16, 20), (13, 14), (14, 16)]
 
 
 @pytest.mark.parametrize("ncols", [1, 4])
