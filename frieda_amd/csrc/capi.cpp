@@ -842,11 +842,11 @@ int interpolate_points(frieda_ctx* ctx, const uint32_t* d_cells, const uint32_t*
                        uint32_t log_coef, uint32_t log_domain, uint32_t* d_coef, size_t arena_off) {
     Ctx& c = ctx->c;
     FR_NO_JOB(&c);
-    if (log_cell > log_domain || log_coef > log_domain || log_coef < 1 || log_domain < 1 || log_domain + 1 > FRIEDA_MAX_LOG_DOMAIN || log_domain > 26)
-        return c.fail(FRIEDA_ERR_ARG, "points: need 1 <= log_coef <= log_domain <= min(26, FRIEDA_MAX_LOG_DOMAIN - 1) and log_cell <= log_domain");
+    if (log_cell > log_domain || log_coef > log_domain || log_coef < 1 || log_domain < 2 || log_domain + 1 > FRIEDA_MAX_LOG_DOMAIN)
+        return c.fail(FRIEDA_ERR_ARG, "points: need 1 <= log_coef <= log_domain <= FRIEDA_MAX_LOG_DOMAIN - 1 and log_cell <= log_domain");
     const size_t N = (size_t)1 << log_domain, K = (size_t)1 << log_coef, M = (size_t)1 << log_cell;
     const uint32_t n = log_domain;
-    // known positions (first occurrence of every cell wins), and where their values sit in the caller's buffer
+    // distinct sampled positions (first occurrence of every cell wins), and where their values sit in the caller's buffer
     std::vector<uint8_t> known(N, 0);
     std::vector<uint32_t> pos, src;
     pos.reserve((size_t)n_cells * M);
@@ -862,19 +862,10 @@ int interpolate_points(frieda_ctx* ctx, const uint32_t* d_cells, const uint32_t*
             src.push_back((uint32_t)((((size_t)r * ncols) << log_cell) + t));
         }
     }
-    if (pos.size() < K + 2)
+    const uint32_t s_all = (uint32_t)pos.size();
+    if (s_all < K + 2)
         return c.fail(FRIEDA_ERR_ARG, "points: need at least 2^log_coef + 2 distinct points (the locator polynomial needs two spare samples)");
-    // erased positions, an even number of them: with an odd count one known point is given up
-    if ((N - pos.size()) & 1) {
-        known[pos.back()] = 0;
-        pos.pop_back();
-        src.pop_back();
-    }
-    std::vector<uint32_t> erased;
-    erased.reserve(N - pos.size());
-    for (size_t i = 0; i < N; i++)
-        if (!known[i]) erased.push_back((uint32_t)i);
-    const uint32_t s_cnt = (uint32_t)pos.size(), n_lines = (uint32_t)(erased.size() / 2);
+    const uint32_t s_use = (uint32_t)K + 2, n_lines = s_use / 2;  // the first K + 2 carry the reconstruction, all of them the check
 
     // domains: D (log n) and the next canonic domain D' (log n + 1)
     auto make_domain = [](uint32_t lg) {
@@ -894,17 +885,19 @@ int interpolate_points(frieda_ctx* ctx, const uint32_t* d_cells, const uint32_t*
 
     // workspace
     auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
-    const size_t chunks_s = k::erasure_zpart_chunks(s_cnt, n_lines), chunks_k = k::erasure_zpart_chunks((uint32_t)K, n_lines);
+    const size_t chunks = std::max(k::erasure_zpart_chunks(s_use, n_lines), k::erasure_zpart_chunks((uint32_t)K, n_lines));
     ArenaPlan plan;
     plan.off = arena_off;
-    const size_t o_pos = plan.take(4 * (size_t)s_cnt), o_src = plan.take(4 * (size_t)s_cnt), o_er = plan.take(4 * erased.size() + 4);
-    const size_t o_la = plan.take(4 * (size_t)n_lines + 4), o_lb = plan.take(4 * (size_t)n_lines + 4), o_lc = plan.take(4 * (size_t)n_lines + 4);
-    const size_t o_px = plan.take(4 * std::max<size_t>(s_cnt, K)), o_py = plan.take(4 * std::max<size_t>(s_cnt, K));
-    const size_t o_zp = plan.take(4 * std::max(chunks_s * s_cnt, chunks_k * K)), o_z = plan.take(4 * std::max<size_t>(s_cnt, K));
-    const size_t o_w = plan.take(al(4 * N) * ncols);   // Z * p on D, then (reused) its evaluation on D' needs 2N per column: see o_ev
+    const size_t o_pos = plan.take(4 * (size_t)s_all), o_src = plan.take(4 * (size_t)s_all);
+    const size_t o_la = plan.take(4 * (size_t)n_lines), o_lb = plan.take(4 * (size_t)n_lines), o_lc = plan.take(4 * (size_t)n_lines);
+    const size_t o_px = plan.take(4 * (size_t)s_use), o_py = plan.take(4 * (size_t)s_use);
+    const size_t o_zp = plan.take(4 * chunks * s_use), o_z = plan.take(4 * (size_t)s_use), o_bad = plan.take(4);
+    const size_t o_w = plan.take(al(4 * N) * ncols);   // Z * p on D; later the re-encoded polynomial for the check
     const size_t o_q = plan.take(al(4 * N) * ncols);   // coefficients of Z * p
     const size_t o_ev = plan.take(al(8 * N) * ncols);  // Z * p on D'
     const size_t o_blk = plan.take(al(4 * K) * ncols);
+    const size_t o_out = d_coef ? 0 : 0;  // (d_coef == nullptr: the coefficients go to the start of the arena)
+    (void)o_out;
     int rc = c.ensure_arena(plan.off);
     if (rc) return rc;
     TwiddleSet ts0, ts1;
@@ -916,27 +909,37 @@ int interpolate_points(frieda_ctx* ctx, const uint32_t* d_cells, const uint32_t*
     auto W32 = [&](size_t off) { return reinterpret_cast<uint32_t*>(A + off); };
     hipStream_t s = c.stream;
     const k::Launch LN = c.launch();
-    FR_HIP(&c, hipMemcpyAsync(A + o_pos, pos.data(), 4 * (size_t)s_cnt, hipMemcpyHostToDevice, s));
-    FR_HIP(&c, hipMemcpyAsync(A + o_src, src.data(), 4 * (size_t)s_cnt, hipMemcpyHostToDevice, s));
-    if (!erased.empty()) FR_HIP(&c, hipMemcpyAsync(A + o_er, erased.data(), 4 * erased.size(), hipMemcpyHostToDevice, s));
+    FR_HIP(&c, hipMemcpyAsync(A + o_pos, pos.data(), 4 * (size_t)s_all, hipMemcpyHostToDevice, s));
+    FR_HIP(&c, hipMemcpyAsync(A + o_src, src.data(), 4 * (size_t)s_all, hipMemcpyHostToDevice, s));
+    FR_HIP(&c, hipMemsetAsync(A + o_bad, 0, 4, s));
     const size_t w_stride = al(4 * N) / 4, ev_stride = al(8 * N) / 4, blk_stride = al(4 * K) / 4;
-    // 1. locator values at the known points
-    k::erasure_lines(LN, g0, W32(o_er), n_lines, W32(o_la), W32(o_lb), W32(o_lc));
-    k::erasure_points(LN, g0, W32(o_pos), s_cnt, W32(o_px), W32(o_py));
-    k::erasure_zeval(LN, W32(o_px), W32(o_py), s_cnt, W32(o_la), W32(o_lb), W32(o_lc), n_lines, W32(o_zp), W32(o_z));
+    uint32_t* coef_out = d_coef ? d_coef : reinterpret_cast<uint32_t*>(A);
+    // 1. the locator on the K + 2 points it is built from: ratio of tangent derivatives
+    k::erasure_lines(LN, g0, W32(o_pos), n_lines, W32(o_la), W32(o_lb), W32(o_lc));
+    k::erasure_points(LN, g0, W32(o_pos), s_use, W32(o_px), W32(o_py));
+    k::erasure_zeval(LN, W32(o_px), W32(o_py), s_use, W32(o_la), W32(o_lb), W32(o_lc), n_lines, true, W32(o_zp), W32(o_z));
+    k::erasure_known_weights(LN, W32(o_px), W32(o_py), s_use, n, W32(o_z));
     // 2. Z * p on D -> its coefficients
     FR_HIP(&c, hipMemsetAsync(A + o_w, 0, al(4 * N) * ncols, s));
-    k::erasure_scatter(LN, d_cells, W32(o_src), W32(o_pos), W32(o_z), s_cnt, ncols, log_cell, W32(o_w), w_stride);
+    k::erasure_scatter(LN, d_cells, W32(o_src), W32(o_pos), W32(o_z), s_use, ncols, log_cell, W32(o_w), w_stride);
     k::circle_interpolate_block(LN, W32(o_w), w_stride, ncols, n, n, 0, ts0.d_itw, ts0.ds, W32(o_q), w_stride);
-    // 3. onto D', first block of 2^log_coef entries, divided by the locator there
+    // 3. onto D', first block of 2^log_coef entries: p = (Z p) Z_S / V_D there
     k::circle_evaluate(LN, W32(o_q), w_stride, ncols, n, n + 1, ts1.d_tw, ts1.ds, W32(o_ev), ev_stride);
     k::erasure_points(LN, g1, nullptr, (uint32_t)K, W32(o_px), W32(o_py));
-    k::erasure_zeval(LN, W32(o_px), W32(o_py), (uint32_t)K, W32(o_la), W32(o_lb), W32(o_lc), n_lines, W32(o_zp), W32(o_z));
-    k::erasure_divide(LN, W32(o_ev), ev_stride, W32(o_z), (uint32_t)K, ncols, W32(o_blk), blk_stride);
+    k::erasure_zeval(LN, W32(o_px), W32(o_py), (uint32_t)K, W32(o_la), W32(o_lb), W32(o_lc), n_lines, false, W32(o_zp), W32(o_z));
+    k::erasure_divide(LN, W32(o_ev), ev_stride, W32(o_z), W32(o_px), (uint32_t)K, ncols, n, W32(o_blk), blk_stride);
     // 4. that block back to coefficients
-    k::circle_interpolate_block(LN, W32(o_blk), blk_stride, ncols, log_coef, n + 1, 0, ts1.d_itw, ts1.ds, d_coef ? d_coef : reinterpret_cast<uint32_t*>(A), K);
-    FR_HIP(&c, hipStreamSynchronize(s));  // pos / src / erased are host memory of this call
+    k::circle_interpolate_block(LN, W32(o_blk), blk_stride, ncols, log_coef, n + 1, 0, ts1.d_itw, ts1.ds, coef_out, K);
+    // 5. encode again and compare every sample that was offered
+    k::circle_evaluate(LN, coef_out, K, ncols, log_coef, n, ts0.d_tw, ts0.ds, W32(o_w), w_stride);
+    k::erasure_check(LN, d_cells, W32(o_src), W32(o_pos), s_all, ncols, log_cell, W32(o_w), w_stride, W32(o_bad));
+    uint32_t bad = 0;
+    FR_HIP(&c, hipMemcpyAsync(&bad, A + o_bad, 4, hipMemcpyDeviceToHost, s));
+    FR_HIP(&c, hipStreamSynchronize(s));  // pos / src are host memory of this call
     FR_HIP(&c, hipGetLastError());
+    if (bad)
+        return c.fail(FRIEDA_ERR_ARG, "points: the samples are not values of one polynomial of 2^log_coef coefficients (" + std::to_string(bad) +
+                                          " sample words differ from the re-encoded result)");
     return FRIEDA_OK;
 }
 }  // namespace

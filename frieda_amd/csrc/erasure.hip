@@ -5,21 +5,27 @@
 // intt.hip rebuilds a polynomial from exactly 2^L values by inverting a dense system: cubic in the number of cells, capped at 4096.
 // Past that this file uses the erasure-locator route of Reed-Solomon decoding, carried over to the circle domain:
 //
-//   p         the polynomial: 2^L coefficients per column in the circle-FFT basis, degree <= 2^(L-1)
-//   D         the circle domain of the codeword, N = 2^n points; S the known positions, E = D \ S the erased ones, |E| = m even
-//   Z         a circle polynomial vanishing exactly on E: the product over pairs (P, Q) of erased points of the line through P and Q
-//             (a line meets the circle in two points), degree m / 2
-//   Z * p     has degree <= m / 2 + 2^(L-1); while that is <= N / 2 - 1 — i.e. |S| >= 2^L + 2 — it lies in the space of the size-N
-//             circle FFT, and its values on ALL of D are known: Z(P) p(P) on S, zero on E
+//   p         the polynomial: K = 2^L coefficients per column in the circle-FFT basis, degree <= K / 2
+//   D         the circle domain of the codeword (canonic coset, N = 2^n points); V_D(x, y) = pi^(n-1)(x), pi(x) = 2 x^2 - 1, vanishes
+//             exactly on D (n - 1 doublings take a point of D to x = 0)
+//   S         K + 2 of the sampled points (more may be offered: the rest only serve the consistency check at the end)
+//   Z_S       the product of the K / 2 + 1 lines through consecutive pairs of S (a line meets the circle in exactly two points):
+//             vanishes exactly on S, degree K / 2 + 1
+//   Z         = V_D / Z_S: a polynomial function on the circle (the zeros of Z_S are simple zeros of V_D) of degree N / 2 - K / 2 - 1
+//             that vanishes exactly on D \ S — the erasure locator — without ever touching the N - K - 2 missing points
+//   Z * p     has degree <= N / 2 - 1, so it lies in the space of the size-N circle FFT, and its values on ALL of D are known:
+//             Z(s) p(s) on S, zero elsewhere
 //
-//   1. z_i = Z(P_i) for the known points (direct product over the m / 2 lines: O(|S| m), no subproduct tree)
-//   2. w = Z * p on D (zeros at the erased positions); inverse circle FFT of size N -> the N coefficients of Z * p
-//   3. evaluate Z * p on the next larger canonic domain D' (2N points, disjoint from D: no zero of Z lies on it) and take its first
-//      block of 2^L entries; divide by Z there (direct product again): 2^L values of p on a sub-coset of D'
+//   1. Z on S: V_D and Z_S both vanish there, so Z(s) is the ratio of their derivatives along the circle's tangent (-y, x):
+//             V_D' = -y prod_{j < n-1} 4 pi^j(x);  Z_S' = (-y A + x B) of the point's own line times the other lines' values
+//   2. w = Z * p on D (zero off S); inverse circle FFT of size N -> the N coefficients of Z * p
+//   3. evaluate Z * p on the next canonic domain D' (2N points, disjoint from D) and take its first block of K entries; there
+//      p = (Z p) Z_S / V_D pointwise: K values of p on a sub-coset of D'
 //   4. inverse transform of that block (intt.hip) -> the coefficients of p
+//   5. encode p again and compare EVERY offered sample: samples that are not values of one polynomial are reported, not returned
 //
-// Cost: O(|S| (N - |S|)) field multiplications for the two direct products (8e9 for the reference's 128 KiB blob sampled at 2^15 + 2
-// single points of its 2^19 codeword: milliseconds) plus four transforms.  Exact arithmetic: consistent samples give the polynomial.
+// Cost: (K + 2)(K / 2 + 1) + K (K / 2 + 1) line evaluations for the two products — quadratic in the polynomial, not in the domain —
+// plus five transforms.  Exact arithmetic: consistent samples give the polynomial.
 #include <hip/hip_runtime.h>
 
 #include "kernels.h"
@@ -51,7 +57,7 @@ __global__ void erasure_points_kernel(ErasureDomain g, const uint32_t* __restric
     py[t] = p.y;
 }
 
-// line a through the erased points 2a and 2a + 1: A x + B y + C with (A, B, C) = (y1 - y2, x2 - x1, x1 y2 - x2 y1)
+// line a through the points at positions pos[2a] and pos[2a + 1]: A x + B y + C with (A, B, C) = (y1 - y2, x2 - x1, x1 y2 - x2 y1)
 __global__ void erasure_lines_kernel(ErasureDomain g, const uint32_t* __restrict__ erased, uint32_t n_lines, uint32_t* __restrict__ la,
                                      uint32_t* __restrict__ lb, uint32_t* __restrict__ lc) {
     const uint32_t a = blockIdx.x * blockDim.x + threadIdx.x;
@@ -64,7 +70,10 @@ __global__ void erasure_lines_kernel(ErasureDomain g, const uint32_t* __restrict
 
 constexpr uint32_t Z_TILE = 512;  // lines staged through LDS per step
 
-// zpart[chunk][t] = product over the lines of chunk `blockIdx.y` of line(P_t); a chunk = lines [chunk * per, (chunk + 1) * per)
+// zpart[chunk][t] = product over the lines of chunk `blockIdx.y` of line(P_t); a chunk = lines [chunk * per, (chunk + 1) * per).
+// OWN: point t lies on line t >> 1 (the points are the pairs the lines were drawn through): that factor is the line's derivative
+// along the circle's tangent at P_t, -y A + x B, instead of its value (zero).
+template <bool OWN>
 __global__ __launch_bounds__(256) void erasure_zeval_kernel(const uint32_t* __restrict__ px, const uint32_t* __restrict__ py, uint32_t count,
                                                             const uint32_t* __restrict__ la, const uint32_t* __restrict__ lb,
                                                             const uint32_t* __restrict__ lc, uint32_t n_lines, uint32_t per,
@@ -72,6 +81,8 @@ __global__ __launch_bounds__(256) void erasure_zeval_kernel(const uint32_t* __re
     __shared__ uint32_t sa[Z_TILE], sb[Z_TILE], sc[Z_TILE];
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t x = t < count ? px[t] : 0u, y = t < count ? py[t] : 0u;
+    const uint32_t ny = m31_neg(y);
+    const uint32_t own = t >> 1;
     const uint32_t first = blockIdx.y * per;
     const uint32_t last = first + per < n_lines ? first + per : n_lines;
     uint32_t z = 1;
@@ -86,8 +97,9 @@ __global__ __launch_bounds__(256) void erasure_zeval_kernel(const uint32_t* __re
         __syncthreads();
         for (uint32_t i = 0; i < nt; i++) {
             // A x + B y + C < 2 (P - 1)^2 + P < 2^63: one reduction
-            const uint32_t v = m31_reduce64((uint64_t)sa[i] * x + (uint64_t)sb[i] * y + sc[i]);
-            z = m31_mul(z, v);
+            uint64_t acc = (uint64_t)sa[i] * x + (uint64_t)sb[i] * y + sc[i];
+            if (OWN && base + i == own) acc = (uint64_t)sa[i] * ny + (uint64_t)sb[i] * x;
+            z = m31_mul(z, m31_reduce64(acc));
         }
     }
     if (t < count) zpart[(size_t)blockIdx.y * count + t] = z;
@@ -113,13 +125,40 @@ __global__ void erasure_scatter_kernel(const uint32_t* __restrict__ cells, const
     for (uint32_t c = 0; c < ncols; c++) w[(size_t)c * w_stride + p] = m31_mul(cells[s0 + ((size_t)c << log_cell)], zt);
 }
 
-// block[c][t] = ev[c][t] / z[t], t < count
-__global__ void erasure_divide_kernel(const uint32_t* __restrict__ ev, size_t ev_stride, const uint32_t* __restrict__ z, uint32_t count, uint32_t ncols,
-                                      uint32_t* __restrict__ block, size_t block_stride) {
+// weights of the known points: z[t] = V_D'(P_t) / Z_S'(P_t) with z[t] holding Z_S'(P_t) on entry; V_D' = -y prod_{j < n-1} 4 pi^j(x)
+__global__ void erasure_known_weights_kernel(const uint32_t* __restrict__ px, const uint32_t* __restrict__ py, uint32_t count, uint32_t n,
+                                             uint32_t* __restrict__ z) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= count) return;
-    const uint32_t zi = m31_inv(z[t]);
-    for (uint32_t c = 0; c < ncols; c++) block[(size_t)c * block_stride + t] = m31_mul(ev[(size_t)c * ev_stride + t], zi);
+    uint32_t x = px[t], r = m31_neg(py[t]);
+    for (uint32_t j = 0; j + 1 < n; j++) {
+        const uint32_t x4 = m31_add(m31_add(x, x), m31_add(x, x));
+        r = m31_mul(r, x4);
+        x = double_x(x);
+    }
+    z[t] = m31_mul(r, m31_inv(z[t]));
+}
+
+// block[c][t] = ev[c][t] * Z_S(P_t) / V_D(P_t) for the first `count` points P_t of D' (z[t] = Z_S(P_t), px = their x-coordinates)
+__global__ void erasure_divide_kernel(const uint32_t* __restrict__ ev, size_t ev_stride, const uint32_t* __restrict__ z, const uint32_t* __restrict__ px,
+                                      uint32_t count, uint32_t ncols, uint32_t n, uint32_t* __restrict__ block, size_t block_stride) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= count) return;
+    uint32_t x = px[t];
+    for (uint32_t j = 0; j + 1 < n; j++) x = double_x(x);  // V_D(P_t) = pi^(n-1)(x): non-zero off D
+    const uint32_t f = m31_mul(z[t], m31_inv(x));
+    for (uint32_t c = 0; c < ncols; c++) block[(size_t)c * block_stride + t] = m31_mul(ev[(size_t)c * ev_stride + t], f);
+}
+
+// mismatch[0] += number of offered samples that differ from the re-encoded polynomial: ev[c][pos[t]] vs cells[src[t] + c * 2^log_cell]
+__global__ void erasure_check_kernel(const uint32_t* __restrict__ cells, const uint32_t* __restrict__ src, const uint32_t* __restrict__ pos,
+                                     uint32_t count, uint32_t ncols, uint32_t log_cell, const uint32_t* __restrict__ ev, size_t ev_stride,
+                                     uint32_t* __restrict__ mismatch) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= count) return;
+    uint32_t bad = 0;
+    for (uint32_t c = 0; c < ncols; c++) bad += ev[(size_t)c * ev_stride + pos[t]] != cells[(size_t)src[t] + ((size_t)c << log_cell)];
+    if (bad) atomicAdd(mismatch, bad);
 }
 
 }  // namespace
@@ -148,15 +187,24 @@ void erasure_lines(const Launch& L_, const ErasureDomain& g, const uint32_t* d_e
 }
 
 void erasure_zeval(const Launch& L_, const uint32_t* d_px, const uint32_t* d_py, uint32_t count, const uint32_t* d_la, const uint32_t* d_lb,
-                   const uint32_t* d_lc, uint32_t n_lines, uint32_t* d_zpart, uint32_t* d_z) {
+                   const uint32_t* d_lc, uint32_t n_lines, bool own, uint32_t* d_zpart, uint32_t* d_z) {
     if (!count) return;
     const uint32_t chunks = (uint32_t)erasure_zpart_chunks(count, n_lines);
     const uint32_t per = n_lines ? (n_lines + chunks - 1) / chunks : 0;
     {
         Scope scope(L_, "erasure_zeval", 8.0 * count + 12.0 * n_lines);
-        erasure_zeval_kernel<<<dim3((count + 255) / 256, chunks), 256, 0, L_.stream>>>(d_px, d_py, count, d_la, d_lb, d_lc, n_lines, per, d_zpart);
+        const dim3 grid((count + 255) / 256, chunks);
+        if (own)
+            erasure_zeval_kernel<true><<<grid, 256, 0, L_.stream>>>(d_px, d_py, count, d_la, d_lb, d_lc, n_lines, per, d_zpart);
+        else
+            erasure_zeval_kernel<false><<<grid, 256, 0, L_.stream>>>(d_px, d_py, count, d_la, d_lb, d_lc, n_lines, per, d_zpart);
     }
     erasure_zreduce_kernel<<<(count + 255) / 256, 256, 0, L_.stream>>>(d_zpart, chunks, count, d_z);
+}
+
+void erasure_known_weights(const Launch& L_, const uint32_t* d_px, const uint32_t* d_py, uint32_t count, uint32_t n, uint32_t* d_z) {
+    if (!count) return;
+    erasure_known_weights_kernel<<<(count + 255) / 256, 256, 0, L_.stream>>>(d_px, d_py, count, n, d_z);
 }
 
 void erasure_scatter(const Launch& L_, const uint32_t* d_cells, const uint32_t* d_src, const uint32_t* d_pos, const uint32_t* d_z, uint32_t count,
@@ -166,11 +214,18 @@ void erasure_scatter(const Launch& L_, const uint32_t* d_cells, const uint32_t* 
     erasure_scatter_kernel<<<(count + 255) / 256, 256, 0, L_.stream>>>(d_cells, d_src, d_pos, d_z, count, ncols, log_cell, d_w, w_stride);
 }
 
-void erasure_divide(const Launch& L_, const uint32_t* d_ev, size_t ev_stride, const uint32_t* d_z, uint32_t count, uint32_t ncols, uint32_t* d_block,
-                    size_t block_stride) {
+void erasure_divide(const Launch& L_, const uint32_t* d_ev, size_t ev_stride, const uint32_t* d_z, const uint32_t* d_px, uint32_t count, uint32_t ncols,
+                    uint32_t n, uint32_t* d_block, size_t block_stride) {
     if (!count) return;
-    Scope scope(L_, "erasure_divide", (4.0 + 8.0 * ncols) * count);
-    erasure_divide_kernel<<<(count + 255) / 256, 256, 0, L_.stream>>>(d_ev, ev_stride, d_z, count, ncols, d_block, block_stride);
+    Scope scope(L_, "erasure_divide", (8.0 + 8.0 * ncols) * count);
+    erasure_divide_kernel<<<(count + 255) / 256, 256, 0, L_.stream>>>(d_ev, ev_stride, d_z, d_px, count, ncols, n, d_block, block_stride);
+}
+
+void erasure_check(const Launch& L_, const uint32_t* d_cells, const uint32_t* d_src, const uint32_t* d_pos, uint32_t count, uint32_t ncols,
+                   uint32_t log_cell, const uint32_t* d_ev, size_t ev_stride, uint32_t* d_mismatch) {
+    if (!count) return;
+    Scope scope(L_, "erasure_check", (8.0 + 8.0 * ncols) * count);
+    erasure_check_kernel<<<(count + 255) / 256, 256, 0, L_.stream>>>(d_cells, d_src, d_pos, count, ncols, log_cell, d_ev, ev_stride, d_mismatch);
 }
 
 }  // namespace k

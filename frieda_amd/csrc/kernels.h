@@ -122,19 +122,25 @@ struct ErasureDomain {
 };
 // points of the domain at bit-reversed positions d_pos[0 .. count) (d_pos == nullptr: positions 0 .. count - 1)
 void erasure_points(const Launch& L_, const ErasureDomain& g, const uint32_t* d_pos, uint32_t count, uint32_t* d_px, uint32_t* d_py);
-// lines through the erased points (2a, 2a + 1), a < n_lines
-void erasure_lines(const Launch& L_, const ErasureDomain& g, const uint32_t* d_erased, uint32_t n_lines, uint32_t* d_la, uint32_t* d_lb,
+// lines through the points at positions (d_pos[2a], d_pos[2a + 1]), a < n_lines
+void erasure_lines(const Launch& L_, const ErasureDomain& g, const uint32_t* d_pos, uint32_t n_lines, uint32_t* d_la, uint32_t* d_lb,
                    uint32_t* d_lc);
-// d_z[t] = product over all lines of line(P_t); d_zpart: erasure_zpart_chunks(count, n_lines) * count words of scratch
+// d_z[t] = product over all lines of line(P_t) — own: with the point's own line (t >> 1) replaced by its tangent derivative at P_t;
+// d_zpart: erasure_zpart_chunks(count, n_lines) * count words of scratch
 size_t erasure_zpart_chunks(uint32_t count, uint32_t n_lines);
 void erasure_zeval(const Launch& L_, const uint32_t* d_px, const uint32_t* d_py, uint32_t count, const uint32_t* d_la, const uint32_t* d_lb,
-                   const uint32_t* d_lc, uint32_t n_lines, uint32_t* d_zpart, uint32_t* d_z);
+                   const uint32_t* d_lc, uint32_t n_lines, bool own, uint32_t* d_zpart, uint32_t* d_z);
+// d_z[t] = V_D'(P_t) / d_z[t] for the domain of log size n (the locator's values on the known points)
+void erasure_known_weights(const Launch& L_, const uint32_t* d_px, const uint32_t* d_py, uint32_t count, uint32_t n, uint32_t* d_z);
 // d_w[c][d_pos[t]] = d_z[t] * d_cells[d_src[t] + c * 2^log_cell] (d_w zeroed by the caller)
 void erasure_scatter(const Launch& L_, const uint32_t* d_cells, const uint32_t* d_src, const uint32_t* d_pos, const uint32_t* d_z, uint32_t count,
                      uint32_t ncols, uint32_t log_cell, uint32_t* d_w, size_t w_stride);
-// d_block[c][t] = d_ev[c][t] / d_z[t], t < count
-void erasure_divide(const Launch& L_, const uint32_t* d_ev, size_t ev_stride, const uint32_t* d_z, uint32_t count, uint32_t ncols, uint32_t* d_block,
-                    size_t block_stride);
+// d_block[c][t] = d_ev[c][t] * d_z[t] / V_D(x = d_px[t]), t < count (V_D of the domain of log size n)
+void erasure_divide(const Launch& L_, const uint32_t* d_ev, size_t ev_stride, const uint32_t* d_z, const uint32_t* d_px, uint32_t count, uint32_t ncols,
+                    uint32_t n, uint32_t* d_block, size_t block_stride);
+// *d_mismatch += samples (per column) that differ from d_ev[c][d_pos[t]]
+void erasure_check(const Launch& L_, const uint32_t* d_cells, const uint32_t* d_src, const uint32_t* d_pos, uint32_t count, uint32_t ncols,
+                   uint32_t log_cell, const uint32_t* d_ev, size_t ev_stride, uint32_t* d_mismatch);
 
 // ---- merkle.hip ----
 // leaves of 4 SoA columns: out[i] = H(c0[i], c1[i], c2[i], c3[i], 0 x 12)

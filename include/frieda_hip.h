@@ -290,12 +290,13 @@ int frieda_reconstruct_cells_device(frieda_ctx* ctx, const uint32_t* d_cells, co
 /* Reconstruction from ANY sufficiently large set of samples, with no bound on their number (the README's sample() flow at blob
  * scale: the reference's 128 KiB `blob` fixture has 2^15 coefficients per column — 2^15 + 2 single sampled points of its 2^19
  * codeword rebuild it).  Same cell layout as above (d_cells[n_cells][ncols][2^log_cell], cell_index[n_cells] on the host; repeated
- * cells are ignored); the distinct points offered must number at least 2^log_coef + 2, ALL of them are used, and no system is
- * solved: the product Z of the lines through pairs of missing points vanishes on everything that was not sampled, Z * p is known
- * on the whole domain, and p follows by transforms and one pointwise division on a disjoint domain (erasure.hip).  Cost:
- * O(samples x missing) multiplications + four transforms of the domain size; 1 <= log_coef <= log_domain <= 26.  The samples
- * must be consistent (values of one polynomial of 2^log_coef coefficients): nothing here detects a corrupted sample — open the
- * samples against the commitment first (frieda_verify). */
+ * cells are ignored); the distinct points offered must number at least 2^log_coef + 2.  No system is solved: with S the first
+ * 2^log_coef + 2 points, V_D the vanishing polynomial of the domain and Z_S the product of the lines through pairs of S, the
+ * quotient Z = V_D / Z_S vanishes on everything outside S, Z * p is known on the whole domain, and p follows by transforms and one
+ * pointwise division on a disjoint domain (erasure.hip).  Cost: ~2^(2 log_coef) multiplications (quadratic in the polynomial, not in
+ * the domain) + five transforms; 1 <= log_coef <= log_domain <= FRIEDA_MAX_LOG_DOMAIN - 1, log_domain >= 2.  Every sample offered,
+ * used or not, is then compared with the re-encoded result: samples that are not values of one polynomial of 2^log_coef
+ * coefficients give FRIEDA_ERR_ARG (and unspecified d_coef contents) instead of a wrong answer. */
 int frieda_circle_interpolate_points(frieda_ctx* ctx, const uint32_t* d_cells, const uint32_t* cell_index, uint32_t n_cells, uint32_t ncols,
                                      uint32_t log_cell, uint32_t log_coef, uint32_t log_domain, uint32_t* d_coef);
 /* the same for frieda's 4-column layout, followed by the packer: sampled points -> the original len bytes */

@@ -409,11 +409,13 @@ int fo_reconstruct_cells(const uint32_t* cells, const uint32_t* cell_index, uint
 
 /* Reconstruction of one column from ANY >= 2^L + 2 distinct sampled points (positions in the bit-reversed evaluation on the domain of
  * log size n), by the erasure-locator route the product takes (frieda_amd/csrc/erasure.hip) restated with this file's own transforms:
- * Z = product of the lines through pairs of missing points; Z * p is known on the whole domain; its coefficients, evaluated on the
- * next canonic domain (disjoint: Z has no zero there) and divided by Z on a block of 2^L entries, give p on a sub-coset; inverse
- * block transform.  There is no reference code for this (the README's sample() flow is not in /root/reference/src): the check of
- * this function is fo_reconstruct_cells (dense solve) and the encode -> sample -> reconstruct round trip.  Quadratic in the domain
- * size; for test sizes.  Returns 0, or -1 on bad arguments / fewer than 2^L + 2 distinct points. */
+ * S = the first K + 2 = 2^L + 2 distinct points; Z_S = product of the lines through consecutive pairs of S; V_D = pi^(n-1)(x) vanishes
+ * on the whole domain D; Z = V_D / Z_S vanishes on D \ S, so Z * p is known on all of D (zero off S; on S, Z is the ratio of the
+ * tangent derivatives of V_D and Z_S).  Its coefficients, evaluated on the next canonic domain (disjoint from D) and multiplied by
+ * Z_S / V_D on a block of 2^L entries, give p on a sub-coset; inverse block transform.  Then every offered sample is compared with
+ * the re-encoded polynomial.  There is no reference code for this (the README's sample() flow is not in /root/reference/src): the
+ * check of this function is fo_reconstruct_cells (dense solve) and the encode -> sample -> reconstruct round trip.
+ * Returns 0; -1 on bad arguments / fewer than 2^L + 2 distinct points; -2 when the samples are not values of one polynomial. */
 static cpoint domain_point_bitrev(uint32_t n, uint32_t pos) {
     const uint32_t j = fo_bit_reverse_index(pos, n);
     const coset h = coset_half_odds(n - 1);
@@ -423,8 +425,9 @@ static cpoint domain_point_bitrev(uint32_t n, uint32_t pos) {
     p.y = m31_neg(p.y);
     return p;
 }
+static inline uint32_t pi_x(uint32_t x) { return m31_sub(m31_add(m31_mul(x, x), m31_mul(x, x)), 1); }
 int fo_reconstruct_points(const uint32_t* vals, const uint32_t* pos, uint32_t n_pts, uint32_t L, uint32_t n, uint32_t* coef_out) {
-    if (L < 1 || L > n || n < 1 || n + 1 > 28) return -1;
+    if (L < 1 || L > n || n < 2 || n + 1 > 28) return -1;
     const size_t N = (size_t)1 << n, K = (size_t)1 << L;
     uint8_t* known = (uint8_t*)calloc(N, 1);
     uint32_t* kpos = (uint32_t*)malloc(sizeof(uint32_t) * (n_pts + 1));
@@ -441,42 +444,38 @@ int fo_reconstruct_points(const uint32_t* vals, const uint32_t* pos, uint32_t n_
         kval[s] = vals[i];
         s++;
     }
+    free(known);
     if (s < K + 2) {
-        free(known), free(kpos), free(kval);
+        free(kpos), free(kval);
         return -1;
     }
-    if ((N - s) & 1) known[kpos[--s]] = 0; /* an even number of missing points: one sample is given up */
-    const size_t m = N - s, n_lines = m / 2;
-    uint32_t *la = (uint32_t*)malloc(4 * (n_lines + 1)), *lb = (uint32_t*)malloc(4 * (n_lines + 1)), *lc = (uint32_t*)malloc(4 * (n_lines + 1));
-    {
-        size_t a = 0;
-        cpoint prev = {0, 0};
-        int have = 0;
-        for (size_t i = 0; i < N; i++) {
-            if (known[i]) continue;
-            const cpoint q = domain_point_bitrev(n, (uint32_t)i);
-            if (!have) {
-                prev = q;
-                have = 1;
-            } else {
-                la[a] = m31_sub(prev.y, q.y);
-                lb[a] = m31_sub(q.x, prev.x);
-                lc[a] = m31_sub(m31_mul(prev.x, q.y), m31_mul(q.x, prev.y));
-                a++;
-                have = 0;
-            }
-        }
+    const size_t su = K + 2, n_lines = su / 2;
+    cpoint* pt = (cpoint*)malloc(sizeof(cpoint) * su);
+    uint32_t *la = (uint32_t*)malloc(4 * n_lines), *lb = (uint32_t*)malloc(4 * n_lines), *lc = (uint32_t*)malloc(4 * n_lines);
+    for (size_t t = 0; t < su; t++) pt[t] = domain_point_bitrev(n, kpos[t]);
+    for (size_t a = 0; a < n_lines; a++) {
+        const cpoint p = pt[2 * a], q = pt[2 * a + 1];
+        la[a] = m31_sub(p.y, q.y);
+        lb[a] = m31_sub(q.x, p.x);
+        lc[a] = m31_sub(m31_mul(p.x, q.y), m31_mul(q.x, p.y));
     }
     uint32_t *tw0 = (uint32_t*)malloc(4 * (N / 2 + 1)), *itw0 = (uint32_t*)malloc(4 * (N / 2 + 1));
     uint32_t *tw1 = (uint32_t*)malloc(4 * (N + 1)), *itw1 = (uint32_t*)malloc(4 * (N + 1));
     fo_precompute_twiddles(n, tw0, itw0);
     fo_precompute_twiddles(n + 1, tw1, itw1);
     uint32_t* w = (uint32_t*)calloc(N, 4);
-    for (size_t t = 0; t < s; t++) {
-        const cpoint pt = domain_point_bitrev(n, kpos[t]);
-        uint32_t z = 1;
-        for (size_t a = 0; a < n_lines; a++) z = m31_mul(z, m31_add(m31_add(m31_mul(la[a], pt.x), m31_mul(lb[a], pt.y)), lc[a]));
-        w[kpos[t]] = m31_mul(kval[t], z);
+    for (size_t t = 0; t < su; t++) {
+        const uint32_t x = pt[t].x, y = pt[t].y;
+        uint32_t den = 1; /* Z_S'(P_t): tangent derivative (-y A + x B) of the point's own line, values of the others */
+        for (size_t a = 0; a < n_lines; a++)
+            den = m31_mul(den, a == t / 2 ? m31_add(m31_mul(m31_neg(y), la[a]), m31_mul(x, lb[a]))
+                                          : m31_add(m31_add(m31_mul(la[a], x), m31_mul(lb[a], y)), lc[a]));
+        uint32_t num = m31_neg(y), xx = x; /* V_D'(P_t) = -y prod_{j < n-1} 4 pi^j(x) */
+        for (uint32_t j = 0; j + 1 < n; j++) {
+            num = m31_mul(num, m31_mul(4, xx));
+            xx = pi_x(xx);
+        }
+        w[kpos[t]] = m31_mul(kval[t], m31_mul(num, m31_inv(den)));
     }
     uint32_t* q = (uint32_t*)malloc(4 * N);
     fo_circle_interpolate_block(w, n, n, 0, itw0, q);
@@ -484,14 +483,20 @@ int fo_reconstruct_points(const uint32_t* vals, const uint32_t* pos, uint32_t n_
     fo_circle_evaluate(q, n, n + 1, tw1, ev);
     uint32_t* blk = (uint32_t*)malloc(4 * K);
     for (size_t t = 0; t < K; t++) {
-        const cpoint pt = domain_point_bitrev(n + 1, (uint32_t)t);
-        uint32_t z = 1;
-        for (size_t a = 0; a < n_lines; a++) z = m31_mul(z, m31_add(m31_add(m31_mul(la[a], pt.x), m31_mul(lb[a], pt.y)), lc[a]));
-        blk[t] = m31_mul(ev[t], m31_inv(z));
+        const cpoint p = domain_point_bitrev(n + 1, (uint32_t)t);
+        uint32_t zs = 1, vd = p.x;
+        for (size_t a = 0; a < n_lines; a++) zs = m31_mul(zs, m31_add(m31_add(m31_mul(la[a], p.x), m31_mul(lb[a], p.y)), lc[a]));
+        for (uint32_t j = 0; j + 1 < n; j++) vd = pi_x(vd);
+        blk[t] = m31_mul(ev[t], m31_mul(zs, m31_inv(vd)));
     }
     fo_circle_interpolate_block(blk, L, n + 1, 0, itw1, coef_out);
-    free(known), free(kpos), free(kval), free(la), free(lb), free(lc), free(tw0), free(itw0), free(tw1), free(itw1), free(w), free(q), free(ev), free(blk);
-    return 0;
+    /* every offered sample against the re-encoded polynomial */
+    fo_circle_evaluate(coef_out, L, n, tw0, w);
+    int rc = 0;
+    for (size_t t = 0; t < s; t++)
+        if (w[kpos[t]] != kval[t]) rc = -2;
+    free(kpos), free(kval), free(pt), free(la), free(lb), free(lc), free(tw0), free(itw0), free(tw1), free(itw1), free(w), free(q), free(ev), free(blk);
+    return rc;
 }
 
 void fo_felts_to_bytes(const uint32_t* felts, size_t n_felts, uint8_t* out, size_t len) {

@@ -238,6 +238,8 @@ def reconstruct_points(vals, positions, n, L):
     for c in range(ncols):
         col = np.ascontiguousarray(vals[:, c])
         rc = lib().fo_reconstruct_points(col.ctypes.data, pos.ctypes.data, n_pts, L, n, out[c].ctypes.data)
+        if rc == -2:
+            raise ValueError("fo_reconstruct_points: the samples are not values of one polynomial")
         if rc != 0:
             raise ValueError("fo_reconstruct_points: bad arguments or too few distinct points")
     return out

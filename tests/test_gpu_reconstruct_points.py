@@ -75,11 +75,36 @@ def test_interpolate_points_argument_errors(gpu_ctx, oracle):
     bad[5] = 1 << n
     assert f(h, d_cells.ptr, bad.ctypes.data, 18, 4, 0, L, n, d_c.ptr) == 1  # position outside the domain
     assert f(h, d_cells.ptr, idx.ctypes.data, 18, 4, 0, 0, n, d_c.ptr) == 1  # a constant polynomial: use the cells entry
-    assert f(h, d_cells.ptr, idx.ctypes.data, 18, 4, 0, L, 27, d_c.ptr) == 1  # beyond the supported domain
+    assert f(h, d_cells.ptr, idx.ctypes.data, 18, 4, 0, L, 28, d_c.ptr) == 1  # beyond the supported domain (needs a 2^(n+1) transform)
     assert f(h, d_cells.ptr, idx.ctypes.data, 0, 4, 0, L, n, d_c.ptr) == 1
     assert f(h, None, idx.ctypes.data, 18, 4, 0, L, n, d_c.ptr) == 1
     _check(gpu_ctx, f(h, d_cells.ptr, idx.ctypes.data, 18, 4, 0, L, n, d_c.ptr))
     assert np.array_equal(d_c.to_array(np.uint32, (4, 1 << L)), coef)
+
+
+@pytest.mark.parametrize("L,n,extra,where", [(4, 8, 2, "used"), (6, 10, 30, "used"), (6, 10, 30, "spare"), (10, 14, 100, "spare"), (10, 14, 2, "used")])
+def test_inconsistent_samples_are_reported(gpu_ctx, oracle, L, n, extra, where):
+    """One corrupted sample word — among the 2^L + 2 points the locator is built from, or among the spare ones that only serve the check —
+    is reported (FRIEDA_ERR_ARG), never answered with a wrong polynomial; the oracle's restatement reports the same."""
+    rng = np.random.default_rng(8000 + L + n)
+    coef = rng.integers(0, P, (4, 1 << L), dtype=np.uint32)
+    ev = oracle.circle_evaluate(coef, n)
+    n_pts = (1 << L) + extra
+    idx = rng.permutation(1 << n)[:n_pts].astype(np.uint32)
+    cells = _cells(ev, idx, 0)
+    victim = 5 if where == "used" else n_pts - 1
+    cells[victim, 2, 0] = (int(cells[victim, 2, 0]) + 1) % P
+    d_cells, d_c = DevBuf.from_array(gpu_ctx, cells), DevBuf(gpu_ctx, 16 << L)
+    assert gpu_ctx._L.frieda_circle_interpolate_points(gpu_ctx._h, d_cells.ptr, idx.ctypes.data, n_pts, 4, 0, L, n, d_c.ptr) == 1
+    assert "not values of one polynomial" in gpu_ctx._L.frieda_last_error(gpu_ctx._h).decode()
+    if n <= 10:
+        with pytest.raises(ValueError, match="not values of one polynomial"):
+            oracle.reconstruct_points(np.ascontiguousarray(cells[:, :, 0]), idx, n, L)
+    # the untouched columns alone are fine
+    good = np.ascontiguousarray(cells[:, :2, :])
+    d_good = DevBuf.from_array(gpu_ctx, good)
+    _check(gpu_ctx, gpu_ctx._L.frieda_circle_interpolate_points(gpu_ctx._h, d_good.ptr, idx.ctypes.data, n_pts, 2, 0, L, n, d_c.ptr))
+    assert np.array_equal(d_c.to_array(np.uint32, (2, 1 << L)), coef[:2])
 
 
 def _encode_on_device(gpu_ctx, data, B):
@@ -101,17 +126,18 @@ def test_reference_blob_from_single_sampled_points(gpu_ctx, blob):
     ev, L, n = _encode_on_device(gpu_ctx, blob, 4)
     assert (L, n) == (15, 19)
     rng = np.random.default_rng(2026)
-    for n_pts in ((1 << L) + 2, (1 << L) + 3, (1 << L) + 5000, 1 << (n - 1)):
+    for n_pts in ((1 << L) + 2, (1 << L) + 3, (1 << L) + 5000, 1 << (n - 1)):  # the spare ones only serve the consistency check
         idx = rng.permutation(1 << n)[:n_pts].astype(np.uint32)
         cells = _cells(ev, idx, 0)
         assert gpu_ctx.reconstruct_from_points(cells, idx, L, n, len(blob)) == blob, n_pts
 
 
 @pytest.mark.parametrize("n_bytes,B,m,extra_cells", [(3000, 2, 0, 2), (70001, 2, 1, 1), (983040, 4, 2, 9), (983040, 1, 0, 2), (3932160, 4, 0, 2),
-                                                     (3932160, 4, 6, 33), (61440, 7, 0, 2)])
+                                                     (3932160, 4, 6, 33), (61440, 7, 0, 2), (15728640, 4, 0, 2)])
 def test_encode_sample_points_reconstruct_round_trip(gpu_ctx, n_bytes, B, m, extra_cells):
     """encode -> a sampling client's view (cells of 2^m entries scattered over the whole codeword, a handful more than the minimum) ->
-    the original bytes; cell counts far beyond the 4096 of the dense solver (up to 2^18 + 2 single points on a 2^22 domain)."""
+    the original bytes; cell counts far beyond the 4096 of the dense solver (up to 2^20 + 2 single points on the 2^24 domain of the bench
+    workload: 15.7 MB back from a 1/16 sample of its codeword)."""
     data = splitmix64_bytes(31 + m, n_bytes).tobytes()
     ev, L, n = _encode_on_device(gpu_ctx, data, B)
     m = min(m, L)

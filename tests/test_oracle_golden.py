@@ -318,6 +318,10 @@ def test_reconstruct_points_matches_dense_solve_and_round_trip(oracle, L, n, ext
     assert np.array_equal(oracle.reconstruct_points(np.concatenate([vals, vals[:2]]), np.concatenate([pos, pos[:2]]), n, L), coef)
     with pytest.raises(ValueError):
         oracle.reconstruct_points(vals[: (1 << L) + 1], pos[: (1 << L) + 1], n, L)
+    bad = vals.copy()
+    bad[-1, 0] ^= 1  # a corrupted sample (the last one: a spare whenever extra > 2) is reported, not absorbed
+    with pytest.raises(ValueError, match="not values of one polynomial"):
+        oracle.reconstruct_points(bad, pos, n, L)
     if L >= 2:
         try:
             dense = oracle.reconstruct_cells(np.ascontiguousarray(ev[:, pos[: 1 << L]].T.reshape(1 << L, 2, 1)), pos[: 1 << L], n, L)
