@@ -280,7 +280,9 @@ int frieda_circle_interpolate_cells(frieda_ctx* ctx, const uint32_t* d_cells, co
  * given, 2^(log_coef - log_cell) of them whose rows of the cell matrix are linearly independent and reconstructs from those — so a
  * point set that happens to be singular (possible with single points, log_cell == 0) costs a spare sample instead of an error.
  * out_used (optional, 2^(log_coef - log_cell) words): positions in the caller's list of the cells used.  At most 256 needed cells
- * (the selection runs on the host); FRIEDA_ERR_ARG when the offered cells do not span the polynomial space. */
+ * (the selection runs on the host); FRIEDA_ERR_ARG when the offered cells do not span the polynomial space.  A client holding at
+ * least two points more than the polynomial has coefficients needs neither the selection nor the bound: see
+ * frieda_circle_interpolate_points below. */
 int frieda_circle_interpolate_cells_any(frieda_ctx* ctx, const uint32_t* d_cells, const uint32_t* cell_index, uint32_t n_avail, uint32_t ncols,
                                         uint32_t log_cell, uint32_t log_coef, uint32_t log_domain, uint32_t* d_coef, uint32_t* out_used);
 /* the same for frieda's 4-column layout, followed by the packer: scattered cells -> the original len bytes */
