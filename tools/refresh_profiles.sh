@@ -15,7 +15,7 @@ ONE="--no-cpu-baseline --no-by-config --no-end-to-end --batch 1 --in-flight 1 --
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 bench.py --steps 2 --warmup 1 $ONE > /dev/null 2> $OUT/pmc_fetch_err.txt
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 bench.py --steps 2 --warmup 1 $ONE > /dev/null 2> $OUT/pmc_write_err.txt
 # the same two passes in the measured loop's own mode (4 blobs per call, 2 calls in flight): launches cover 4 blobs each
-BAT="--no-cpu-baseline --no-by-config --no-end-to-end --batch-extra 0 --sequential-extra 0"
+BAT="--only-measured-loop"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_b -- python3 bench.py --steps 8 --warmup 0 $BAT > /dev/null 2> $OUT/pmc_fetch_b_err.txt
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_b -- python3 bench.py --steps 8 --warmup 0 $BAT > /dev/null 2> $OUT/pmc_write_b_err.txt
 python tools/traffic_from_pmc.py $OUT/pmc_fetch $OUT/pmc_write $OUT/${TAG}_prove24_traffic.json "$COMMIT" $OUT/pmc_fetch_b $OUT/pmc_write_b
