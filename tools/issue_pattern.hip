@@ -64,6 +64,15 @@ KERNEL(k_gpair, D_OP(0); C_OP(1); D_OP(2); C_OP(3); C_OP(4); C_OP(5); S_OP(6); A
 KERNEL(k_dep_scsc, S_OP(0); C_OP(0); S_OP(0); C_OP(0); S_OP(0); C_OP(0); S_OP(0); C_OP(0); S_OP(0); C_OP(0); S_OP(0); C_OP(0); S_OP(0); C_OP(0); S_OP(0); C_OP(0);, 16)
 KERNEL(k_dep_sscc, S_OP(0); S_OP(0); C_OP(0); C_OP(0); S_OP(0); S_OP(0); C_OP(0); C_OP(0); S_OP(0); S_OP(0); C_OP(0); C_OP(0); S_OP(0); S_OP(0); C_OP(0); C_OP(0);, 16)
 
+// dependent chains of ONE opcode (what the latency of a lone quad-hash wave is made of)
+KERNEL(k_dep_s, S_OP(0); S_OP(0); S_OP(0); S_OP(0); S_OP(0); S_OP(0); S_OP(0); S_OP(0); S_OP(0); S_OP(0); S_OP(0); S_OP(0); S_OP(0); S_OP(0); S_OP(0); S_OP(0);, 16)
+KERNEL(k_dep_a, A_OP(0); A_OP(0); A_OP(0); A_OP(0); A_OP(0); A_OP(0); A_OP(0); A_OP(0); A_OP(0); A_OP(0); A_OP(0); A_OP(0); A_OP(0); A_OP(0); A_OP(0); A_OP(0);, 16)
+KERNEL(k_dep_c, C_OP(0); C_OP(0); C_OP(0); C_OP(0); C_OP(0); C_OP(0); C_OP(0); C_OP(0); C_OP(0); C_OP(0); C_OP(0); C_OP(0); C_OP(0); C_OP(0); C_OP(0); C_OP(0);, 16)
+KERNEL(k_dep_d, D_OP(0); D_OP(0); D_OP(0); D_OP(0); D_OP(0); D_OP(0); D_OP(0); D_OP(0); D_OP(0); D_OP(0); D_OP(0); D_OP(0); D_OP(0); D_OP(0); D_OP(0); D_OP(0);, 16)
+// the G function as ONE dependent chain, and with each v_add3 split into two v_add
+KERNEL(k_dep_g, D_OP(0); S_OP(0); C_OP(0); A_OP(0); S_OP(0); C_OP(0); D_OP(0); S_OP(0); C_OP(0); A_OP(0); S_OP(0); C_OP(0);, 12)
+KERNEL(k_dep_g_split, A_OP(0); A_OP(0); S_OP(0); C_OP(0); A_OP(0); S_OP(0); C_OP(0); A_OP(0); A_OP(0); S_OP(0); C_OP(0); A_OP(0); S_OP(0); C_OP(0);, 14)
+
 typedef void (*kern_t)(uint32_t*, Stamp*, int);
 
 static void run(const char* name, kern_t kfn, int n_inst, int blocks_per_cu, double seconds) {
@@ -107,6 +116,15 @@ static void run(const char* name, kern_t kfn, int n_inst, int blocks_per_cu, dou
 
 int main(int argc, char** argv) {
     const double secs = argc > 1 ? atof(argv[1]) : 1.0;
+    if (argc > 2) {  // latency mode: one wave per SIMD, dependent chains
+        run("dependent v_xor_b32", k_dep_s, k_dep_s_n, 1, secs);
+        run("dependent v_add_u32", k_dep_a, k_dep_a_n, 1, secs);
+        run("dependent v_alignbit_b32", k_dep_c, k_dep_c_n, 1, secs);
+        run("dependent v_add3_u32", k_dep_d, k_dep_d_n, 1, secs);
+        run("dependent G chain (12 instructions)", k_dep_g, k_dep_g_n, 1, secs);
+        run("dependent G chain, v_add3 as 2 x v_add (14)", k_dep_g_split, k_dep_g_split_n, 1, secs);
+        return 0;
+    }
     for (int w : {8, 4, 2, 1}) {
         run("S S S S  (xor only)", k_ssss, k_ssss_n, w, secs);
         run("C C C C  (alignbit only)", k_cccc, k_cccc_n, w, secs);
