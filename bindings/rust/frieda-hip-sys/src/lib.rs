@@ -84,6 +84,8 @@ extern "C" {
     pub fn frieda_commit_many(m: *mut frieda_multi, blobs: *const *const u8, lens: *const usize, count: u32, log_blowup_factor: u32, out_roots: *mut u8) -> c_int;
     pub fn frieda_prove_many(m: *mut frieda_multi, blobs: *const *const u8, lens: *const usize, count: u32, seeds: *const u64, cfg: frieda_pcs_config, out_commitments: *mut u8, out_proofs: *mut *mut frieda_proof) -> c_int;
     pub fn frieda_verify(proof: *const frieda_proof, seed: *const u64, ok: *mut c_int) -> c_int;
+    /// verify + the positions the accepted proof sampled (evaluations[i] sits at out_positions[i] of the bit-reversed codeword)
+    pub fn frieda_verify_samples(proof: *const frieda_proof, seed: *const u64, ok: *mut c_int, out_positions: *mut u32, cap: usize, n_positions: *mut usize) -> c_int;
 
     // struct Proof
     pub fn frieda_proof_free(p: *mut frieda_proof);

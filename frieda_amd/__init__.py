@@ -18,6 +18,7 @@ from .api import (  # noqa: F401
     default_context,
     generate_proof,
     verify,
+    verify_samples,
 )
 
 __all__ = [
@@ -35,4 +36,5 @@ __all__ = [
     "default_context",
     "generate_proof",
     "verify",
+    "verify_samples",
 ]

@@ -98,6 +98,7 @@ def lib():
         "frieda_commit_many": (C.c_int, [vp, pp, C.POINTER(sz), u32, u32, vp]),
         "frieda_prove_many": (C.c_int, [vp, pp, C.POINTER(sz), u32, u64p, PcsConfigC, vp, pp]),
         "frieda_verify": (C.c_int, [vp, u64p, C.POINTER(C.c_int)]),
+        "frieda_verify_samples": (C.c_int, [vp, u64p, C.POINTER(C.c_int), vp, sz, C.POINTER(sz)]),
         "frieda_proof_free": (None, [vp]),
         "frieda_proof_clone": (C.c_int, [vp, pp]),
         "frieda_proof_proof_of_work": (u64, [vp]),

@@ -593,3 +593,18 @@ def verify(proof, seed):
     ok = C.c_int(0)
     _check(_lib.lib().frieda_verify(proof._h, _seed_ptr(seed), C.byref(ok)))
     return bool(ok.value)
+
+
+def verify_samples(proof, seed):
+    """verify + where the accepted proof sampled: (ok, positions) with positions[i] the index in the bit-reversed codeword whose four
+    column values are proof.evaluations[i] (frieda_verify_samples); positions is None when the proof is rejected."""
+    import numpy as np
+
+    ok = C.c_int(0)
+    n = C.c_size_t(0)
+    cap = max(1, int(proof.pcs_config.fri_config.n_queries))
+    buf = np.zeros(cap, dtype=np.uint32)
+    _check(_lib.lib().frieda_verify_samples(proof._h, _seed_ptr(seed), C.byref(ok), buf.ctypes.data, cap, C.byref(n)))
+    if not ok.value:
+        return False, None
+    return True, buf[: n.value].copy()

@@ -392,6 +392,22 @@ int frieda_verify(const frieda_proof* proof, const uint64_t* seed, int* ok) {
     FR_GUARD_END(none)
 }
 
+int frieda_verify_samples(const frieda_proof* proof, const uint64_t* seed, int* ok, uint32_t* out_positions, size_t cap, size_t* n_positions) {
+    if (!proof || !ok || !n_positions || (cap && !out_positions)) return FRIEDA_ERR_ARG;
+    frieda_ctx* none = nullptr;
+    FR_GUARD_BEGIN
+    *n_positions = 0;
+    std::vector<uint32_t> q;
+    const int rc = verify(proof->p, seed, ok, &q);
+    if (rc != FRIEDA_OK || !*ok) return rc;
+    if (q.size() != proof->p.evaluations.size()) return FRIEDA_ERR_INVARIANT;  // (an accepted proof has one evaluation per distinct query)
+    *n_positions = q.size();
+    if (cap < q.size()) return FRIEDA_ERR_ARG;
+    if (!q.empty()) memcpy(out_positions, q.data(), 4 * q.size());
+    return FRIEDA_OK;
+    FR_GUARD_END(none)
+}
+
 // ---- Proof accessors ----
 void frieda_proof_free(frieda_proof* p) {
     if (!p) return;

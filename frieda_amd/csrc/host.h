@@ -166,7 +166,9 @@ int commit_batch_begin(Ctx* ctx, const uint8_t* data, size_t data_stride, size_t
                        const uint8_t* const* host_ptrs = nullptr);
 int commit_batch_finish(Ctx* ctx, uint8_t* out_roots);
 // returns FRIEDA_OK with *ok set, or FRIEDA_ERR_INVARIANT where the reference panics
-int verify(const ProofData& proof, const uint64_t* seed, int* ok);
+// out_queries (optional): on acceptance, the sorted distinct query positions the transcript sampled — evaluations[i] of the proof is
+// the value of the 4 columns at position out_queries[i] of the bit-reversed codeword (src/proof.rs:62-66)
+int verify(const ProofData& proof, const uint64_t* seed, int* ok, std::vector<uint32_t>* out_queries = nullptr);
 
 // transcript pieces shared by prover and verifier (transcript.cpp)
 void channel_mix_felts(Channel& ch, const std::vector<QM31>& felts);

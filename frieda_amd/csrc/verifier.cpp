@@ -151,8 +151,9 @@ QM31 line_poly_eval(const QM31* coeffs, size_t n, const QM31* factors) {
 
 }  // namespace
 
-int verify(const ProofData& proof, const uint64_t* seed, int* ok) {
+int verify(const ProofData& proof, const uint64_t* seed, int* ok, std::vector<uint32_t>* out_queries) {
     *ok = 0;
+    if (out_queries) out_queries->clear();
     const frieda_pcs_config& cfg = proof.pcs_config;
     const uint32_t B = cfg.log_blowup_factor, last = cfg.log_last_layer_degree_bound, L = proof.log_size_bound;
     // CirclePolyDegreeBound::fold_to_line underflows (panics) for L == 0; domain sizes outside the group do too
@@ -252,6 +253,7 @@ int verify(const ProofData& proof, const uint64_t* seed, int* ok) {
         if (!qm_eq(evals[i], line_poly_eval(proof.last_layer_poly.data(), np, fac))) return FRIEDA_OK;  // LastLayerEvaluationsInvalid
     }
     *ok = 1;
+    if (out_queries) *out_queries = queries;
     return FRIEDA_OK;
 }
 

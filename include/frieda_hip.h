@@ -167,6 +167,14 @@ int frieda_generate_proof(frieda_ctx* ctx, const uint8_t* data, size_t len, cons
  * verifier is O(n_queries * log N) hashes).  *ok receives the bool; FRIEDA_ERR_INVARIANT where the
  * reference panics (src/proof.rs:166-173). */
 int frieda_verify(const frieda_proof* proof, const uint64_t* seed, int* ok);
+/* The sampling client's half of the README's flow (/root/reference/README.md:56-69; in src/ a sample IS a proof: the seed of
+ * generate_proof decides, through the transcript, which positions are opened, src/proof.rs:40-42,60-66): verify as above and, when the
+ * proof is accepted, also return WHERE it sampled — out_positions[i] (ascending, distinct) is the position in the bit-reversed
+ * codeword of length 2^(log_size_bound + log_blowup_factor) whose four column values are evaluations[i]
+ * (frieda_proof_evaluations).  Verified (position, value) pairs pooled from proofs with different seeds are exactly the input of
+ * frieda_circle_interpolate_points / frieda_reconstruct_points_device (log_cell 0, cell r = evaluations[r]).  *n_positions receives
+ * the count (0 when the proof is rejected); FRIEDA_ERR_ARG when cap is smaller than that. */
+int frieda_verify_samples(const frieda_proof* proof, const uint64_t* seed, int* ok, uint32_t* out_positions, size_t cap, size_t* n_positions);
 
 /* ---- multi-GPU: a batch of independent blobs across the GPUs of one node ---------------------------------------------
  * What a caller looping api::commit / commit_and_generate_proof over blobs gets on an 8 x MI355X node

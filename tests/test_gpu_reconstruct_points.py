@@ -146,3 +146,38 @@ def test_encode_sample_points_reconstruct_round_trip(gpu_ctx, n_bytes, B, m, ext
     idx = rng.permutation(1 << (n - m))[:n_cells].astype(np.uint32)
     cells = _cells(ev, idx, m) if n_cells < 70000 else np.ascontiguousarray(ev.reshape(4, -1, 1 << m)[:, idx, :].transpose(1, 0, 2))
     assert gpu_ctx.reconstruct_from_points(cells, idx, L, n, n_bytes) == data
+
+
+@pytest.mark.parametrize("spec,B,nq", [("pattern:1024", 4, 20), ("pattern:4096", 4, 20), ("blob", 4, 300), ("pattern:300", 2, 12)])
+def test_das_loop_prove_verify_pool_reconstruct(gpu_ctx, blob, spec, B, nq):
+    """The README's flow with what /root/reference/src actually has (README.md:56-69; src/proof.rs:32-101): a sample IS a proof — the
+    seed of generate_proof decides through the transcript which positions are opened.  Sampling clients with different seeds each get a
+    proof, verify it (frieda_verify_samples also says WHERE it sampled), and the pooled verified (position, value) pairs rebuild the
+    blob once there are 2^L + 2 distinct ones.  Every returned position is checked against the codeword itself."""
+    import frieda_amd
+    from util import resolve_input
+
+    data = resolve_input(spec, blob)
+    ev, L, n = _encode_on_device(gpu_ctx, data, B)
+    cfg = frieda_amd.PcsConfig(frieda_amd.FriConfig(B, 0, nq), 8)
+    root = gpu_ctx.commit(data, B)
+    pool = {}
+    seed = 0
+    while len(pool) < (1 << L) + 2:
+        seed += 1
+        assert seed < 20000, "the pool does not fill"
+        commitment, proof = gpu_ctx.commit_and_generate_proof(data, seed, cfg)  # (the storage node's side)
+        assert commitment == root
+        ok, positions = frieda_amd.verify_samples(proof, seed)  # (the client's side)
+        assert ok and frieda_amd.verify(proof, seed)
+        evals = proof.evaluations
+        assert len(positions) == len(evals) and np.all(np.diff(positions.astype(np.int64)) > 0) and positions.max() < (1 << n)
+        assert np.array_equal(ev[:, positions].T, evals), "a returned position does not hold the proof's evaluation"
+        for p, v in zip(positions.tolist(), evals):
+            pool[p] = v
+        if seed == 1:  # a wrong seed is a rejected proof and yields no positions
+            bad_ok, bad_pos = frieda_amd.verify_samples(proof, seed + 1)
+            assert not bad_ok and bad_pos is None
+    idx = np.array(sorted(pool), dtype=np.uint32)
+    cells = np.ascontiguousarray(np.stack([pool[int(p)] for p in idx]).astype(np.uint32).reshape(-1, 4, 1))
+    assert gpu_ctx.reconstruct_from_points(cells, idx, L, n, len(data)) == bytes(data)

@@ -108,6 +108,23 @@ def test_wire_image_round_trip_and_cross_verify(L, proofs):
         assert not frieda_amd.verify(p, 12345)
 
 
+def test_verify_samples_returns_the_sampled_positions(oracle, proofs, blob):
+    """frieda_verify_samples (host verifier): for an accepted proof, out_positions[i] is where evaluations[i] sits in the bit-reversed
+    codeword — checked against the oracle's own encode of the same blob; a rejected proof yields none."""
+    import frieda_amd
+
+    inputs = {"blob": (blob, None, 4), "p1024": (pattern_bytes(1024).tobytes(), 1024, 4), "small": (pattern_bytes(300).tobytes(), 9, 2)}
+    for name, (root, op) in proofs.items():
+        data, seed, B = inputs[name]
+        p = frieda_amd.Proof.deserialize(op.serialize())
+        ok, pos = frieda_amd.verify_samples(p, seed)
+        assert ok and len(pos) == len(p.evaluations) and np.all(np.diff(pos.astype(np.int64)) > 0)
+        coef, lg = oracle.polynomial_from_bytes(data)
+        ev = oracle.circle_evaluate(coef, lg + B)
+        assert np.array_equal(ev[:, pos].T, p.evaluations), name
+        assert frieda_amd.verify_samples(p, 777) == (False, None)
+
+
 def test_malformed_images_are_rejected(L, proofs):
     import frieda_amd
 
