@@ -221,6 +221,18 @@ inline bool verify(const Proof& proof, std::optional<uint64_t> seed) {
     check(frieda_verify(proof.handle(), seed ? &s : nullptr, &ok));
     return ok != 0;
 }
+// verify + where the accepted proof sampled: evaluations()[i] sits at position [i] of the bit-reversed codeword; nullopt when the proof
+// is rejected (the sampling client's half of the README's flow; pooled pairs feed frieda_reconstruct_points_device)
+inline std::optional<std::vector<uint32_t>> verify_samples(const Proof& proof, std::optional<uint64_t> seed) {
+    int ok = 0;
+    uint64_t s = seed.value_or(0);
+    std::vector<uint32_t> pos(proof.evaluations().size() + 1);
+    size_t n = 0;
+    check(frieda_verify_samples(proof.handle(), seed ? &s : nullptr, &ok, pos.data(), pos.size(), &n));
+    if (!ok) return std::nullopt;
+    pos.resize(n);
+    return pos;
+}
 }  // namespace api
 
 }  // namespace frieda

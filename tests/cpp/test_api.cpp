@@ -106,6 +106,11 @@ int main(int argc, char** argv) {
     CHECK(proof.first_layer_commitment() == commitment);
     // test_verify_proof
     CHECK(api::verify(proof, std::nullopt));
+    {  // the same verification also says where the proof sampled: one ascending position per evaluation, none for a rejected proof
+        auto pos = api::verify_samples(proof, std::nullopt);
+        CHECK(pos.has_value() && pos->size() == proof.evaluations().size() && std::is_sorted(pos->begin(), pos->end()));
+        CHECK(!api::verify_samples(proof, 5).has_value());
+    }
     {  // invalid pow
         Proof p = proof;
         p.set_proof_of_work(p.proof_of_work() + 1);
