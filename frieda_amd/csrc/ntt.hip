@@ -306,7 +306,13 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_tile12_kernel(NttArgs a) {
 #pragma unroll
                 for (int r = 0; r < 16; r++) col[pad((uint32_t)r << lo)] = x[r];
             }
-            __syncthreads();
+            // The stages on tile bits 4..7 and 0..3 only exchange data inside a wave's own 1024 elements (wave w = threads 64 w ..
+            // 64 w + 63 owns elements [1024 w, 1024 w + 1024) in both), and the LDS serves a wave's accesses in order: between those
+            // two stages no workgroup barrier is needed, only that the compiler keeps the order.
+            if (LOG_W == 0 && NS == 3 && s == 1)
+                __builtin_amdgcn_wave_barrier();
+            else
+                __syncthreads();
         }
         uint32_t* dst = out + (size_t)c * a.out_stride;
         if (LOG_W == 0) {
@@ -543,7 +549,10 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_last_tree_kernel(NttTreeArgs 
 #pragma unroll
                 for (int r = 0; r < 16; r++) col[pad((uint32_t)r << lo)] = x[r];
             }
-            __syncthreads();
+            if (s == 1)
+                __builtin_amdgcn_wave_barrier();  // stages 1 and 2 are wave-local (ntt_tile12_kernel)
+            else
+                __syncthreads();
         }
         if (STORE_ALL) {  // generate_proof folds and opens the evaluation; commit() never reads it
             uint4* o = reinterpret_cast<uint4*>(out + (size_t)c * a.out_stride + gbase + 16u * g);
