@@ -912,8 +912,6 @@ int interpolate_points(frieda_ctx* ctx, const uint32_t* d_cells, const uint32_t*
     const size_t o_q = plan.take(al(4 * N) * ncols);   // coefficients of Z * p
     const size_t o_ev = plan.take(al(8 * N) * ncols);  // Z * p on D'
     const size_t o_blk = plan.take(al(4 * K) * ncols);
-    const size_t o_out = d_coef ? 0 : 0;  // (d_coef == nullptr: the coefficients go to the start of the arena)
-    (void)o_out;
     int rc = c.ensure_arena(plan.off);
     if (rc) return rc;
     TwiddleSet ts0, ts1;
