@@ -30,6 +30,7 @@
 #include <atomic>
 #include <cstdlib>
 
+#include "clock_stamps.h"
 #include "kernels.h"
 #include "tree_dev.h"
 
@@ -464,6 +465,7 @@ struct NttTreeArgs {
 };
 
 
+FR_CLOCK_DECL(g_clock_ntt_last_tree)
 // REG_ONLY: stop after the five register levels (256 nodes of level n - 4 per workgroup): see tree5r_kernel in tree.hip
 template <bool STORE_ALL, bool REG_ONLY = false>
 __global__ __launch_bounds__(NTT_THREADS) void ntt_last_tree_kernel(NttTreeArgs A) {
@@ -471,7 +473,9 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_last_tree_kernel(NttTreeArgs 
     __shared__ __attribute__((aligned(16))) uint32_t RC[8 * (256 + 4)];
     __shared__ __attribute__((aligned(16))) uint32_t RD[8 * (128 + 4)];
     const NttArgs& a = A.a;
-    const uint32_t g = threadIdx.x;
+    uint32_t g_tie = threadIdx.x;
+    FR_CLOCK_BEGIN(g_tie)
+    const uint32_t g = g_tie;
     const uint32_t hblk = blockIdx.x;  // i_hi == 11, i_lo == 0, log_w == 0: one contiguous 4096-word tile per workgroup
     const uint32_t gbase = hblk << TILE_LOG;
     const uint32_t* in = a.in + blockIdx.z * a.bstride_w;
@@ -644,6 +648,7 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_last_tree_kernel(NttTreeArgs 
         b2_merkle_block(mm, h);
         uint8_t* dst = STORE_ALL ? layers + layer_off(m, m - 6) : A.last_out + blockIdx.z * A.bstride;
         store_hash(dst, (wg_e >> 2) + g, h);
+        FR_CLOCK_END(g_clock_ntt_last_tree, h[0])
     }
 }
 
@@ -667,6 +672,8 @@ void set_stages(NttArgs& a, uint32_t t) {
 }
 
 }  // namespace
+
+FR_CLOCK_READER(frieda_debug_clock_ntt_last_tree, g_clock_ntt_last_tree)
 
 void circle_evaluate(const Launch& L_, const uint32_t* d_coef, size_t coef_stride, uint32_t ncols, uint32_t L, uint32_t n,
                      const uint32_t* d_tw, DomainScalars ds, uint32_t* d_out, size_t out_stride) {

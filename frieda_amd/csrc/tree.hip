@@ -32,6 +32,7 @@
 
 #include <cstdlib>
 
+#include "clock_stamps.h"
 #include "blake2s.h"
 #include "dev_transcript.h"
 #include "kernels.h"
@@ -186,12 +187,15 @@ __global__ __launch_bounds__(T5_THREADS) void tree5_kernel(TreeArgs a) {
 // REG_ONLY: the three register levels alone (1024, 512, 256 nodes per workgroup; no LDS, no barrier).  The workgroups of a launch
 // start together and stay in step, so the two LDS levels — half, then a quarter of the waves busy — are phases in which the
 // whole chip runs at 50 % / 25 %; leaving them to the next (eight times smaller) launch keeps the big launch at full rate.
+FR_CLOCK_DECL(g_clock_tree5r)
 template <int MODE, bool REG_ONLY = false>
 __global__ __launch_bounds__(T5_THREADS) void tree5r_kernel(TreeArgs a) {
     __shared__ __attribute__((aligned(16))) uint32_t RC[8 * (256 + 4)];
     __shared__ __attribute__((aligned(16))) uint32_t RD[8 * (128 + 4)];
     tree_args_of_blob(a);
-    const uint32_t t = threadIdx.x;
+    uint32_t t_tie = threadIdx.x;
+    FR_CLOCK_BEGIN(t_tie)
+    const uint32_t t = t_tie;
     const size_t wg_base = (size_t)blockIdx.x * 1024;  // the launcher guarantees 2^level_a >= 1024
     const size_t g0 = wg_base + 4 * t;
     uint8_t* out_a = a.store_all && !a.skip_a ? a.layers + layer_off(a.tree_log, a.level_a) : nullptr;
@@ -294,6 +298,7 @@ __global__ __launch_bounds__(T5_THREADS) void tree5r_kernel(TreeArgs a) {
         lds_children(RD, 128 + 4, t, m);
         b2_merkle_block(m, h);
         store_hash(out_e, (wg_base >> 4) + t, h);
+        FR_CLOCK_END(g_clock_tree5r, h[0])
     }
 }
 
@@ -1066,6 +1071,8 @@ double node_levels_bytes(uint32_t la, uint32_t levels) {
 }
 
 }  // namespace
+
+FR_CLOCK_READER(frieda_debug_clock_tree5r, g_clock_tree5r)
 
 // The part of a tree above an already produced level: level `cur` (2^cur hashes per blob) sits at cur_ptr (inside `a.layers` at
 // its leaves-first offset when every level is kept, else in scratch half s0 or s1); node launches until the single-workgroup top
