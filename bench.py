@@ -328,6 +328,46 @@ def measure_config(frieda_amd, torch, device, n, workload, K, BSZ, D, cfg):
     return out
 
 
+def measure_config2(frieda_amd, torch, device, n=20):
+    """BASELINE.json configs[1] as written: a 2^n-element M31 NTT (4 columns, blow-up 16) + fold_circle_into_line
+    + one fold_line through the trait-granular Level B entry points (frieda_circle_evaluate / frieda_fold_circle_into_line /
+    frieda_fold_line: what a Rust HipBackend's PolyOps::evaluate and FriOps would call), device-resident, fixed alphas.  Bit-exactness of
+    exactly this sequence against the oracle is tests/test_gpu_parity.py::test_config2_ntt_plus_fold_round."""
+    import ctypes as C
+
+    L = n - 4
+    ctx = frieda_amd.Context(device)
+    lib, h = ctx._L, ctx._h
+    g = torch.Generator(device="cpu").manual_seed(2)
+    coef = torch.randint(0, 2**31 - 1, (4, 1 << L), dtype=torch.int32, generator=g).cuda()
+    ev = torch.empty((4, 1 << n), dtype=torch.int32, device="cuda")
+    l1 = torch.zeros((4, 1 << (n - 1)), dtype=torch.int32, device="cuda")
+    l2 = torch.empty((4, 1 << (n - 2)), dtype=torch.int32, device="cuda")
+    alphas = (C.c_uint32 * 4)(11, 22, 33, 44), (C.c_uint32 * 4)(55, 66, 77, 88)
+
+    def once():
+        rc = lib.frieda_circle_evaluate(h, coef.data_ptr(), 4, L, n, ev.data_ptr())
+        rc |= lib.frieda_fold_circle_into_line(h, l1.data_ptr(), ev.data_ptr(), n, alphas[0])
+        rc |= lib.frieda_fold_line(h, l1.data_ptr(), n - 1, n, alphas[1], l2.data_ptr())
+        assert rc == 0
+
+    for _ in range(5):
+        once()
+    ctx.synchronize()
+    reps = 200
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        once()
+    ctx.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    N = float(1 << n)
+    alg = 16.0 * N * (1.0 + 1.0 / 16.0) + 24.0 * N + 24.0 * N / 2  # encode + fold_circle_into_line + fold_line at N / 2 (SURVEY.md §8d)
+    ctx.close()
+    return {"log_domain": n, "workload": "configs[1]: circle NTT (4 columns) + fold_circle_into_line + one fold_line, Level B entry points",
+            "ms_per_pass": 1e3 * dt, "value": 4.0 * N / dt, "unit": "M31 field-elems/s", "algorithmic_bytes": alg,
+            "frac_of_hbm_peak_wall": alg / dt / 1e9 / HBM_PEAK_GBS, "launches": "asynchronous on one context, 200 passes"}
+
+
 def end_to_end(frieda_amd, torch, device, n, K, cfg, expect_roots=None):
     """The reference API takes HOST bytes (`data: &[u8]`, /root/reference/src/lib.rs:31,36): the same stream of K distinct blobs
     handed over in host memory — pageable (what a Rust caller has) and page-locked — through the C ABI's throughput entry points
@@ -912,6 +952,8 @@ def main():
             if cn > n:
                 continue  # (small test runs: nothing above the headline size)
             rows.append(measure_config(frieda_amd, torch, local_rank, cn, cw, 64 if cn <= 22 else 20, 4 if cw == "prove" else 1, 2 if cw == "prove" else 1, cfg))
+        if n >= 20:
+            rows.insert(0, measure_config2(frieda_amd, torch, local_rank, 20))
         out["by_config"] = rows
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cb = cpu_baseline(args.cpu_sample_log, args.workload, 2 if args.cpu_sample_log <= 22 else 1, all_cores_log=min(22, args.cpu_sample_log))
