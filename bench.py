@@ -440,6 +440,7 @@ def parse_args(argv=None):
                     help="blobs per call in the measured loop: > 1 uses the batched entry points (every kernel launched once per batch); 1 = one blob per call")
     ap.add_argument("--pipeline-depth", type=int, default=None, help="deprecated alias: 0 means --in-flight 1")
     ap.add_argument("--sequential-extra", type=int, default=20, help="proofs for the extra one-at-a-time figure (0 = skip)")
+    ap.add_argument("--stagger", type=int, default=0, help="experiment: 1 = the second context's first batch has half the blobs")
     ap.add_argument("--only-measured-loop", action="store_true",
                     help="profiling aid: nothing but the measured loop touches the GPU (no lone set-up steps, no instrumented replay, no extra figures), "
                          "so that every proof kernel a profiler sees is a launch of the measured loop")
@@ -653,11 +654,17 @@ def main():
             return []
         out = []
         if BSZ > 1:
-            for i in range(0, n_blobs, BSZ):
+            i = 0
+            nb = 0
+            while i < n_blobs:
                 cnt = min(BSZ, n_blobs - i)
+                if args.stagger and nb == 1 and D == 2 and BSZ >= 2:
+                    cnt = min(cnt, BSZ // 2)  # the second context starts with half a batch: the two contexts then run half a batch apart
                 r = pipe.submit_device(blobs[i].data_ptr(), blob_len, blob_len, cnt, [seed] * cnt, cfg)
                 if r is not None:
                     out.extend(r)
+                i += cnt
+                nb += 1
         else:
             for i in range(n_blobs):
                 r = pipe.submit_device(blobs[i].data_ptr(), blob_len, seed, cfg)
