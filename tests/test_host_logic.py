@@ -123,6 +123,16 @@ def test_verify_samples_returns_the_sampled_positions(oracle, proofs, blob):
         ev = oracle.circle_evaluate(coef, lg + B)
         assert np.array_equal(ev[:, pos].T, p.evaluations), name
         assert frieda_amd.verify_samples(p, 777) == (False, None)
+        # a buffer smaller than the number of positions is refused (and says how many there are); null arguments are refused
+        import ctypes as C
+
+        L_ = frieda_amd._lib.lib()
+        ok, n_pos = C.c_int(0), C.c_size_t(0)
+        small = np.zeros(2, dtype=np.uint32)
+        sp = C.byref(C.c_uint64(seed)) if seed is not None else None
+        assert L_.frieda_verify_samples(p._h, sp, C.byref(ok), small.ctypes.data, 2, C.byref(n_pos)) == 1 and n_pos.value == len(pos) and ok.value == 1
+        assert L_.frieda_verify_samples(p._h, sp, None, small.ctypes.data, 2, C.byref(n_pos)) == 1
+        assert L_.frieda_verify_samples(None, sp, C.byref(ok), small.ctypes.data, 2, C.byref(n_pos)) == 1
 
 
 def test_malformed_images_are_rejected(L, proofs):
