@@ -881,7 +881,18 @@ int interpolate_points(frieda_ctx* ctx, const uint32_t* d_cells, const uint32_t*
     const uint32_t s_all = (uint32_t)pos.size();
     if (s_all < K + 2)
         return c.fail(FRIEDA_ERR_ARG, "points: need at least 2^log_coef + 2 distinct points (the locator polynomial needs two spare samples)");
-    const uint32_t s_use = (uint32_t)K + 2, n_lines = s_use / 2;  // the first K + 2 carry the reconstruction, all of them the check
+    // S, the points the locator is built from (all offered points serve the check): the first K + 2 single points, Z_S a product of
+    // lines through pairs — or, for samples in cells of M >= 2 entries, the first K / M + 1 whole cells, Z_S a product over cells
+    const bool by_cells = log_cell >= 1;
+    const uint32_t n_use_cells = by_cells ? (uint32_t)(K >> log_cell) + 1 : 0;
+    const uint32_t s_use = by_cells ? (uint32_t)((size_t)n_use_cells << log_cell) : (uint32_t)K + 2;
+    const uint32_t n_lines = by_cells ? n_use_cells : s_use / 2;  // factors of Z_S
+    if (s_use > s_all) return c.fail(FRIEDA_ERR_ARG, "points: cells of 2^log_cell entries: need 2^(log_coef - log_cell) + 1 distinct cells");
+    std::vector<uint32_t> cell_pos;
+    if (by_cells) {
+        cell_pos.resize(n_use_cells);
+        for (uint32_t i = 0; i < n_use_cells; i++) cell_pos[i] = pos[(size_t)i << log_cell];
+    }
 
     // domains: D (log n) and the next canonic domain D' (log n + 1)
     auto make_domain = [](uint32_t lg) {
@@ -901,13 +912,14 @@ int interpolate_points(frieda_ctx* ctx, const uint32_t* d_cells, const uint32_t*
 
     // workspace
     auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
-    const size_t chunks = std::max(k::erasure_zpart_chunks(s_use, n_lines), k::erasure_zpart_chunks((uint32_t)K, n_lines));
+    const size_t chunks = 64;  // upper bound of erasure_zpart_chunks
     ArenaPlan plan;
     plan.off = arena_off;
     const size_t o_pos = plan.take(4 * (size_t)s_all), o_src = plan.take(4 * (size_t)s_all);
     const size_t o_la = plan.take(4 * (size_t)n_lines), o_lb = plan.take(4 * (size_t)n_lines), o_lc = plan.take(4 * (size_t)n_lines);
-    const size_t o_px = plan.take(4 * (size_t)s_use), o_py = plan.take(4 * (size_t)s_use);
-    const size_t o_zp = plan.take(4 * chunks * s_use), o_z = plan.take(4 * (size_t)s_use), o_bad = plan.take(4);
+    const size_t s_max = std::max<size_t>(s_use, K);
+    const size_t o_px = plan.take(4 * s_max), o_py = plan.take(4 * s_max);
+    const size_t o_zp = plan.take(4 * chunks * s_max), o_z = plan.take(4 * s_max), o_bad = plan.take(4);
     const size_t o_w = plan.take(al(4 * N) * ncols);   // Z * p on D; later the re-encoded polynomial for the check
     const size_t o_q = plan.take(al(4 * N) * ncols);   // coefficients of Z * p
     const size_t o_ev = plan.take(al(8 * N) * ncols);  // Z * p on D'
@@ -928,11 +940,18 @@ int interpolate_points(frieda_ctx* ctx, const uint32_t* d_cells, const uint32_t*
     FR_HIP(&c, hipMemsetAsync(A + o_bad, 0, 4, s));
     const size_t w_stride = al(4 * N) / 4, ev_stride = al(8 * N) / 4, blk_stride = al(4 * K) / 4;
     uint32_t* coef_out = d_coef ? d_coef : reinterpret_cast<uint32_t*>(A);
-    // 1. the locator on the K + 2 points it is built from: ratio of tangent derivatives
-    k::erasure_lines(LN, g0, W32(o_pos), n_lines, W32(o_la), W32(o_lb), W32(o_lc));
+    // 1. the locator on the points it is built from: ratio of tangent derivatives
     k::erasure_points(LN, g0, W32(o_pos), s_use, W32(o_px), W32(o_py));
-    k::erasure_zeval(LN, W32(o_px), W32(o_py), s_use, W32(o_la), W32(o_lb), W32(o_lc), n_lines, true, W32(o_zp), W32(o_z));
-    k::erasure_known_weights(LN, W32(o_px), W32(o_py), s_use, n, W32(o_z));
+    if (by_cells) {
+        FR_HIP(&c, hipMemcpyAsync(A + o_lb, cell_pos.data(), 4 * (size_t)n_use_cells, hipMemcpyHostToDevice, s));  // (o_lb: free in this form)
+        k::erasure_cellconst(LN, g0, W32(o_lb), n_use_cells, log_cell, W32(o_la));
+        k::erasure_zeval_cells(LN, W32(o_px), s_use, log_cell, W32(o_la), n_use_cells, true, W32(o_zp), W32(o_z));
+        k::erasure_known_weights_cells(LN, W32(o_px), s_use, n, log_cell, W32(o_z));
+    } else {
+        k::erasure_lines(LN, g0, W32(o_pos), n_lines, W32(o_la), W32(o_lb), W32(o_lc));
+        k::erasure_zeval(LN, W32(o_px), W32(o_py), s_use, W32(o_la), W32(o_lb), W32(o_lc), n_lines, true, W32(o_zp), W32(o_z));
+        k::erasure_known_weights(LN, W32(o_px), W32(o_py), s_use, n, W32(o_z));
+    }
     // 2. Z * p on D -> its coefficients
     FR_HIP(&c, hipMemsetAsync(A + o_w, 0, al(4 * N) * ncols, s));
     k::erasure_scatter(LN, d_cells, W32(o_src), W32(o_pos), W32(o_z), s_use, ncols, log_cell, W32(o_w), w_stride);
@@ -940,7 +959,10 @@ int interpolate_points(frieda_ctx* ctx, const uint32_t* d_cells, const uint32_t*
     // 3. onto D', first block of 2^log_coef entries: p = (Z p) Z_S / V_D there
     k::circle_evaluate(LN, W32(o_q), w_stride, ncols, n, n + 1, ts1.d_tw, ts1.ds, W32(o_ev), ev_stride);
     k::erasure_points(LN, g1, nullptr, (uint32_t)K, W32(o_px), W32(o_py));
-    k::erasure_zeval(LN, W32(o_px), W32(o_py), (uint32_t)K, W32(o_la), W32(o_lb), W32(o_lc), n_lines, false, W32(o_zp), W32(o_z));
+    if (by_cells)
+        k::erasure_zeval_cells(LN, W32(o_px), (uint32_t)K, log_cell, W32(o_la), n_use_cells, false, W32(o_zp), W32(o_z));
+    else
+        k::erasure_zeval(LN, W32(o_px), W32(o_py), (uint32_t)K, W32(o_la), W32(o_lb), W32(o_lc), n_lines, false, W32(o_zp), W32(o_z));
     k::erasure_divide(LN, W32(o_ev), ev_stride, W32(o_z), W32(o_px), (uint32_t)K, ncols, n, W32(o_blk), blk_stride);
     // 4. that block back to coefficients
     k::circle_interpolate_block(LN, W32(o_blk), blk_stride, ncols, log_coef, n + 1, 0, ts1.d_itw, ts1.ds, coef_out, K);

@@ -139,6 +139,60 @@ __global__ void erasure_known_weights_kernel(const uint32_t* __restrict__ px, co
     z[t] = m31_mul(r, m31_inv(z[t]));
 }
 
+// ---- samples that come as aligned cells of M = 2^m >= 2 entries: Z_S as a product over CELLS ----
+// Cell c of the bit-reversed codeword (entries c M .. (c + 1) M) is a coset of the subgroup of order M / 2 together with its conjugates:
+// m - 1 doublings take all of its points to ONE x-coordinate, so v_c(x) = pi^(m-1)(x) - k_c vanishes exactly on the cell (degree M / 2,
+// M zeros).  With whole cells as S, Z_S = prod_c v_c costs one subtraction and one multiplication per (point, cell) instead of a line per
+// (point, pair): K / M + 1 factors instead of K / 2 + 1.
+__global__ void erasure_cellconst_kernel(ErasureDomain g, const uint32_t* __restrict__ cell_pos, uint32_t n_cells, uint32_t m, uint32_t* __restrict__ kc) {
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_cells) return;
+    uint32_t x = domain_point(g, cell_pos[c]).x;
+    for (uint32_t j = 0; j + 1 < m; j++) x = double_x(x);
+    kc[c] = x;
+}
+
+// zpart[chunk][t] = product over the cells of the chunk of (pi^(m-1)(x_t) - k_c); OWN: point t belongs to cell t >> m, whose factor
+// (zero) is left out — erasure_known_weights_cells_kernel supplies its tangent derivative
+template <bool OWN>
+__global__ __launch_bounds__(256) void erasure_zeval_cells_kernel(const uint32_t* __restrict__ px, uint32_t count, uint32_t m,
+                                                                  const uint32_t* __restrict__ kc, uint32_t n_cells, uint32_t per,
+                                                                  uint32_t* __restrict__ zpart) {
+    __shared__ uint32_t sk[3 * Z_TILE];
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t u = t < count ? px[t] : 0u;
+    for (uint32_t j = 0; j + 1 < m; j++) u = double_x(u);
+    const uint32_t own = t >> m;
+    const uint32_t first = blockIdx.y * per;
+    const uint32_t last = first + per < n_cells ? first + per : n_cells;
+    uint32_t z = 1;
+    for (uint32_t base = first; base < last; base += 3 * Z_TILE) {
+        const uint32_t nt = last - base < 3 * Z_TILE ? last - base : 3 * Z_TILE;
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < nt; i += blockDim.x) sk[i] = kc[base + i];
+        __syncthreads();
+        for (uint32_t i = 0; i < nt; i++) {
+            uint32_t f = m31_sub(u, sk[i]);
+            if (OWN && base + i == own) f = 1u;
+            z = m31_mul(z, f);
+        }
+    }
+    if (t < count) zpart[(size_t)blockIdx.y * count + t] = z;
+}
+
+// z[t] = V_D'(P_t) / Z_S'(P_t) with z[t] holding the product over the OTHER cells on entry: the -y of the two tangent derivatives
+// cancels and what is left of V_D' = -y prod_{j < n-1} 4 pi^j(x) over (pi^(m-1))' = -y prod_{j < m-1} 4 pi^j(x) is prod_{m-1 <= j < n-1} 4 pi^j(x)
+__global__ void erasure_known_weights_cells_kernel(const uint32_t* __restrict__ px, uint32_t count, uint32_t n, uint32_t m, uint32_t* __restrict__ z) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= count) return;
+    uint32_t x = px[t], r = 1;
+    for (uint32_t j = 0; j + 1 < n; j++) {
+        if (j + 1 >= m) r = m31_mul(r, m31_add(m31_add(x, x), m31_add(x, x)));
+        x = double_x(x);
+    }
+    z[t] = m31_mul(r, m31_inv(z[t]));
+}
+
 // block[c][t] = ev[c][t] * Z_S(P_t) / V_D(P_t) for the first `count` points P_t of D' (z[t] = Z_S(P_t), px = their x-coordinates)
 __global__ void erasure_divide_kernel(const uint32_t* __restrict__ ev, size_t ev_stride, const uint32_t* __restrict__ z, const uint32_t* __restrict__ px,
                                       uint32_t count, uint32_t ncols, uint32_t n, uint32_t* __restrict__ block, size_t block_stride) {
@@ -200,6 +254,32 @@ void erasure_zeval(const Launch& L_, const uint32_t* d_px, const uint32_t* d_py,
             erasure_zeval_kernel<false><<<grid, 256, 0, L_.stream>>>(d_px, d_py, count, d_la, d_lb, d_lc, n_lines, per, d_zpart);
     }
     erasure_zreduce_kernel<<<(count + 255) / 256, 256, 0, L_.stream>>>(d_zpart, chunks, count, d_z);
+}
+
+void erasure_cellconst(const Launch& L_, const ErasureDomain& g, const uint32_t* d_cell_pos, uint32_t n_cells, uint32_t m, uint32_t* d_kc) {
+    if (!n_cells) return;
+    erasure_cellconst_kernel<<<(n_cells + 255) / 256, 256, 0, L_.stream>>>(g, d_cell_pos, n_cells, m, d_kc);
+}
+
+void erasure_zeval_cells(const Launch& L_, const uint32_t* d_px, uint32_t count, uint32_t m, const uint32_t* d_kc, uint32_t n_cells, bool own,
+                         uint32_t* d_zpart, uint32_t* d_z) {
+    if (!count) return;
+    const uint32_t chunks = (uint32_t)erasure_zpart_chunks(count, (n_cells + 2) / 3);
+    const uint32_t per = n_cells ? (n_cells + chunks - 1) / chunks : 0;
+    {
+        Scope scope(L_, "erasure_zeval_cells", 8.0 * count + 4.0 * n_cells);
+        const dim3 grid((count + 255) / 256, chunks);
+        if (own)
+            erasure_zeval_cells_kernel<true><<<grid, 256, 0, L_.stream>>>(d_px, count, m, d_kc, n_cells, per, d_zpart);
+        else
+            erasure_zeval_cells_kernel<false><<<grid, 256, 0, L_.stream>>>(d_px, count, m, d_kc, n_cells, per, d_zpart);
+    }
+    erasure_zreduce_kernel<<<(count + 255) / 256, 256, 0, L_.stream>>>(d_zpart, chunks, count, d_z);
+}
+
+void erasure_known_weights_cells(const Launch& L_, const uint32_t* d_px, uint32_t count, uint32_t n, uint32_t m, uint32_t* d_z) {
+    if (!count) return;
+    erasure_known_weights_cells_kernel<<<(count + 255) / 256, 256, 0, L_.stream>>>(d_px, count, n, m, d_z);
 }
 
 void erasure_known_weights(const Launch& L_, const uint32_t* d_px, const uint32_t* d_py, uint32_t count, uint32_t n, uint32_t* d_z) {

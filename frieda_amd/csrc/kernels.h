@@ -132,6 +132,12 @@ void erasure_zeval(const Launch& L_, const uint32_t* d_px, const uint32_t* d_py,
                    const uint32_t* d_lc, uint32_t n_lines, bool own, uint32_t* d_zpart, uint32_t* d_z);
 // d_z[t] = V_D'(P_t) / d_z[t] for the domain of log size n (the locator's values on the known points)
 void erasure_known_weights(const Launch& L_, const uint32_t* d_px, const uint32_t* d_py, uint32_t count, uint32_t n, uint32_t* d_z);
+// samples in aligned cells of 2^m >= 2 entries: d_kc[c] = pi^(m-1)(x) of cell c's points (its first position d_cell_pos[c]); d_z[t] =
+// product over the cells of (pi^(m-1)(x_t) - d_kc[c]) — own: without the point's own cell t >> m; and the known-point weights for that form
+void erasure_cellconst(const Launch& L_, const ErasureDomain& g, const uint32_t* d_cell_pos, uint32_t n_cells, uint32_t m, uint32_t* d_kc);
+void erasure_zeval_cells(const Launch& L_, const uint32_t* d_px, uint32_t count, uint32_t m, const uint32_t* d_kc, uint32_t n_cells, bool own,
+                         uint32_t* d_zpart, uint32_t* d_z);
+void erasure_known_weights_cells(const Launch& L_, const uint32_t* d_px, uint32_t count, uint32_t n, uint32_t m, uint32_t* d_z);
 // d_w[c][d_pos[t]] = d_z[t] * d_cells[d_src[t] + c * 2^log_cell] (d_w zeroed by the caller)
 void erasure_scatter(const Launch& L_, const uint32_t* d_cells, const uint32_t* d_src, const uint32_t* d_pos, const uint32_t* d_z, uint32_t count,
                      uint32_t ncols, uint32_t log_cell, uint32_t* d_w, size_t w_stride);

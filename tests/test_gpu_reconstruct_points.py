@@ -28,7 +28,8 @@ def _cells(ev, idx, m):
 @pytest.mark.parametrize(
     "L,n,m,extra,ncols",
     [(1, 2, 0, 2, 1), (1, 3, 0, 2, 4), (2, 4, 0, 2, 4), (3, 6, 0, 3, 2), (4, 8, 0, 5, 4), (5, 7, 0, 2, 4), (6, 10, 0, 40, 3), (8, 12, 0, 2, 4),
-     (8, 12, 2, 1, 4), (6, 7, 1, 1, 4), (9, 13, 3, 7, 4), (10, 14, 0, 2, 4), (10, 11, 0, 1022, 4)],
+     (8, 12, 2, 1, 4), (6, 7, 1, 1, 4), (9, 13, 3, 7, 4), (10, 14, 0, 2, 4), (10, 11, 0, 1022, 4),
+     (3, 8, 5, 0, 4), (4, 9, 4, 1, 2), (5, 6, 5, 1, 4), (8, 10, 8, 0, 4), (10, 14, 1, 1, 4), (12, 16, 5, 3, 4)],  # cells: Z_S as a product over cells
 )
 def test_interpolate_points_vs_oracle(gpu_ctx, oracle, L, n, m, extra, ncols):
     """extra: cells offered beyond the 2^(L - m) that carry 2^L points (m == 0: two spare points are the minimum; negative: all of the
@@ -36,9 +37,10 @@ def test_interpolate_points_vs_oracle(gpu_ctx, oracle, L, n, m, extra, ncols):
     rng = np.random.default_rng(7000 + 100 * L + 10 * n + m)
     coef = rng.integers(0, P, (ncols, 1 << L), dtype=np.uint32)
     ev = oracle.circle_evaluate(coef, n)
-    n_cells = (1 << (L - m)) + extra
+    base = (1 << (L - m)) if m <= L else 0  # whole cells that carry 2^L points (none when one cell already holds more than that)
+    n_cells = base + extra
     if m > 0:
-        n_cells = max(n_cells, (1 << (L - m)) + 1)  # one more cell of >= 2 points carries the two spare samples
+        n_cells = max(n_cells, base + 1)  # one more cell of >= 2 points carries the two spare samples
     n_cells = min(n_cells, 1 << (n - m))
     idx = rng.permutation(1 << (n - m))[:n_cells].astype(np.uint32)
     cells = _cells(ev, idx, m)
@@ -50,10 +52,11 @@ def test_interpolate_points_vs_oracle(gpu_ctx, oracle, L, n, m, extra, ncols):
     _check(gpu_ctx, gpu_ctx._L.frieda_circle_interpolate_points(gpu_ctx._h, d_cells.ptr, idx.ctypes.data, n_cells, ncols, m, L, n, d_c.ptr))
     assert np.array_equal(d_c.to_array(np.uint32, (ncols, 1 << L)), coef)
     # repeated cells are ignored (first occurrence wins)
-    idx2 = np.concatenate([idx, idx[:3]])
-    cells2 = np.concatenate([cells, np.zeros_like(cells[:3])])
+    rep = min(3, n_cells)
+    idx2 = np.concatenate([idx, idx[:rep]])
+    cells2 = np.concatenate([cells, np.zeros_like(cells[:rep])])
     d_cells2 = DevBuf.from_array(gpu_ctx, cells2)
-    _check(gpu_ctx, gpu_ctx._L.frieda_circle_interpolate_points(gpu_ctx._h, d_cells2.ptr, idx2.ctypes.data, n_cells + 3, ncols, m, L, n, d_c.ptr))
+    _check(gpu_ctx, gpu_ctx._L.frieda_circle_interpolate_points(gpu_ctx._h, d_cells2.ptr, idx2.ctypes.data, n_cells + rep, ncols, m, L, n, d_c.ptr))
     assert np.array_equal(d_c.to_array(np.uint32, (ncols, 1 << L)), coef)
 
 
