@@ -754,7 +754,8 @@ int interpolate_cells(frieda_ctx* ctx, const uint32_t* d_cells, const uint32_t* 
     if (log_cell > log_coef || log_coef > log_domain || log_domain < 1 || log_domain > FRIEDA_MAX_LOG_DOMAIN)
         return c.fail(FRIEDA_ERR_ARG, "cells: need log_cell <= log_coef <= log_domain");
     if (log_coef - log_cell > FRIEDA_MAX_LOG_CELLS || n_cells != (1u << (log_coef - log_cell)))
-        return c.fail(FRIEDA_ERR_ARG, "cells: n_cells must be 2^(log_coef - log_cell) and at most 2^FRIEDA_MAX_LOG_CELLS");
+        return c.fail(FRIEDA_ERR_ARG, "cells: n_cells must be 2^(log_coef - log_cell) and at most 2^FRIEDA_MAX_LOG_CELLS "
+                                      "(with one spare cell, or two spare points, frieda_circle_interpolate_points has no such bound)");
     for (uint32_t r = 0; r < n_cells; r++)
         if ((uint64_t)cell_index[r] >= ((uint64_t)1 << (log_domain - log_cell))) return c.fail(FRIEDA_ERR_ARG, "cells: cell index out of range");
     {
