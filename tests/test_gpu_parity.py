@@ -481,6 +481,20 @@ def test_cpp_api_harness(gpu_ctx):
     assert r.returncode == 0, r.stdout + r.stderr
 
 
+def test_cpp_bench_harness(gpu_ctx):
+    """The reference's criterion benches restated in C++ over include/frieda.hpp (tests/cpp/bench_api.cpp: groups commit, generate_proof,
+    commit_and_generate_proof, verify_proof on the five bench inputs): runs, every proof verifies, 20 result lines."""
+    import subprocess
+
+    from conftest import GOLDEN, ROOT
+
+    exe = os.path.join(ROOT, "tests", "cpp", "bench_api.bin")
+    assert os.path.exists(exe), "run __graft_entry__.build() first"
+    r = subprocess.run([exe, os.path.join(GOLDEN, "blob"), "0.02"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ok: every proof verified" in r.stdout, r.stdout + r.stderr
+    assert sum("time:" in ln for ln in r.stdout.splitlines()) == 20
+
+
 @pytest.mark.parametrize("n_slots,mode", [(1, "plain"), (1, "rccl"), (2, "stub"), (3, "stub")])
 def test_cpp_multi_gpu_entry_points(gpu_ctx, n_slots, mode):
     """frieda_multi_create / frieda_commit_many / frieda_prove_many from C++ (tests/cpp/test_api.cpp multi_mode): the no-exchange
