@@ -11,14 +11,22 @@ namespace frieda {
 static constexpr uint32_t IDX_MASK = 0x7fffffffu;
 
 CPoint point_from_index(uint32_t index) {
-    // CirclePointIndex::to_point: scalar multiple of the order-2^31 generator
-    CPoint res{1, 0}, cur{CIRCLE_GEN_X, CIRCLE_GEN_Y};
+    // CirclePointIndex::to_point: scalar multiple of the order-2^31 generator.  The 31 doublings of the generator are a table (the host
+    // verifier evaluates a domain point per query and layer: src/proof.rs:98-100, ~400 calls per proof), so a call is one point addition
+    // per set bit of the index.
+    static const std::array<CPoint, 31> pow2 = [] {
+        std::array<CPoint, 31> t{};
+        CPoint cur{CIRCLE_GEN_X, CIRCLE_GEN_Y};
+        for (auto& e : t) {
+            e = cur;
+            cur = cp_double(cur);
+        }
+        return t;
+    }();
+    CPoint res{1, 0};
     index &= IDX_MASK;
-    while (index) {
-        if (index & 1u) res = cp_add(res, cur);
-        cur = cp_double(cur);
-        index >>= 1;
-    }
+    for (uint32_t b = 0; index; b++, index >>= 1)
+        if (index & 1u) res = cp_add(res, pow2[b]);
     return res;
 }
 
