@@ -10,12 +10,14 @@ from conftest import splitmix64_bytes
 
 
 
-def run(budget, seed, ctx=None, big_every=12):
+def run(budget, seed, ctx=None, big_every=12, multi_every=9):
   """-> (single proofs, batches, seconds, MB-scale proofs).  Every `big_every`-th case (the first included) is a 0.4 - 8 MB blob:
-  L = 16 .. 20/21 with ragged lengths, i.e. the strided passes of the encode's planner (padded 8-layer, generic, two-pass)."""
+  L = 16 .. 20/21 with ragged lengths, i.e. the strided passes of the encode's planner (padded 8-layer, generic, two-pass); every
+  `multi_every`-th also sends a mixed list of blobs through frieda_prove_many / frieda_commit_many (counted among the batches)."""
   rng = random.Random(seed)
   n_big = it = 0
   ctx = ctx or frieda_amd.Context(0)
+  mc = None  # the multi-GPU entry on one device (frieda_prove_many / frieda_commit_many: host blobs, upload ring, units of equal lengths)
   t0 = time.time()
   n_single = n_batch = 0
   t_print = t0
@@ -60,6 +62,34 @@ def run(budget, seed, ctx=None, big_every=12):
       assert r == o_root == root and p.serialize() == o_proof.serialize(), ("prove", size, B, last, nq, pow_bits, seed)
       n_single += 1
       n_big += big
+      if multi_every > 0 and it % multi_every == 0:
+          # a mixed list through the C ABI's multi entry: runs of equal lengths (batched units of up to four) between ragged ones
+          if mc is None:
+              mc = frieda_amd.MultiContext([0])
+          lens = []
+          for _ in range(rng.randint(2, 4)):
+              ln = rng.choice([rng.randint(1, 3000), rng.randint(3000, 200000), size])
+              lens += [ln] * rng.choice([1, 1, 2, 5])
+          mblobs = [splitmix64_bytes(rng.randint(1, 1 << 30), max(ln, 1)).tobytes()[:ln] for ln in lens]
+          mseeds = [rng.randint(0, 1 << 40) for _ in lens]
+          want = []
+          try:
+              for b, s_ in zip(mblobs, mseeds):
+                  want.append(O.commit_and_generate_proof(b, s_, ocfg))
+          except Exception:
+              want = None  # a blob the reference panics on for this configuration: the whole call must report it
+          if want is None:
+              try:
+                  mc.prove_many(mblobs, mseeds, cfg)
+                  raise AssertionError(("oracle panicked, prove_many did not", lens, B, last))
+              except frieda_amd.FriedaPanic:
+                  pass
+          else:
+              got = mc.prove_many(mblobs, mseeds, cfg)
+              for (rr, pp), (orr, opp) in zip(got, want):
+                  assert rr == orr and pp.serialize() == opp.serialize(), ("prove_many", lens, B, last, nq, pow_bits)
+              assert mc.commit_many(mblobs, B) == [orr for orr, _ in want], ("commit_many", lens, B)
+              n_batch += 1
       if size <= 20000 and rng.random() < 0.3:
           cnt = rng.randint(2, 9)
           blobs = [splitmix64_bytes(rng.randint(1, 1 << 30), max(size, 1)).tobytes()[:size] for _ in range(cnt)]
@@ -74,6 +104,8 @@ def run(budget, seed, ctx=None, big_every=12):
               orr, opp = O.commit_and_generate_proof(b, s_, ocfg)
               assert rr == orr and pp.serialize() == opp.serialize(), ("batch", size, B, last, nq, pow_bits)
           n_batch += 1
+  if mc is not None:
+      mc.close()
   return n_single, n_batch, time.time() - t0, n_big
 
 
