@@ -378,8 +378,8 @@ def end_to_end(frieda_amd, torch, device, n, K, cfg, expect_roots=None):
     pageable = [splitmix64_bytes(100 + i, blob_len) for i in range(K)]
     mc = frieda_amd.MultiContext([device])
     out = {"blobs": K, "blob_bytes": blob_len, "entry_points": "frieda_prove_many / frieda_commit_many (one device, host blobs), frieda_commit_and_generate_proof"}
-    mc.prove_many(pageable[: min(K, 8)], seeds[: min(K, 8)], cfg)  # sizes workspaces and the upload ring
-    mc.commit_many(pageable[: min(K, 8)], 4)
+    mc.prove_many(pageable[: min(K, 13)], seeds[: min(K, 13)], cfg)  # sizes workspaces (a full unit of four on both contexts) and the upload ring
+    mc.commit_many(pageable[: min(K, 13)], 4)
 
     def timed(blobs):
         dtp = dtc = None
@@ -481,6 +481,7 @@ def launch_ranks(args):
         env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    FRIEDA_BENCH_SELF_LAUNCHED="1")
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env.setdefault("NCCL_SOCKET_IFNAME", "lo")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=None))
     import threading
@@ -573,6 +574,9 @@ def main():
 
     # the host driver of this pool only supports dmabuf IPC: without this RCCL fails with hipIpcGetMemHandle: invalid argument
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    # one node only: RCCL's bootstrap needs no NIC.  Left to itself it picks the container's first interface, whose name may not resolve
+    # (a one-rank communicator has been seen to take minutes to come up on such a box); the loopback always works.  Override to taste.
+    os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
     import torch
 
     world = int(os.environ.get("WORLD_SIZE", "1"))

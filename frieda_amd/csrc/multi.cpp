@@ -384,7 +384,9 @@ int frieda_commit_many(frieda_multi* m, const uint8_t* const* blobs, const size_
                     for (uint32_t slot = 0; slot < mine;) {
                         const uint32_t i0 = (uint32_t)d + slot * (uint32_t)n;
                         uint32_t cnt = 1;
-                        while (cnt < MULTI_UNIT && slot + cnt < mine && lens[i0 + cnt * n] == lens[i0]) cnt++;
+                        // (the very first unit is a single blob when more follow: the chip starts after one upload instead of four)
+                        const uint32_t cap = (slot == 0 && mine > MULTI_UNIT) ? 1u : MULTI_UNIT;
+                        while (cnt < cap && slot + cnt < mine && lens[i0 + cnt * n] == lens[i0]) cnt++;
                         units.push_back(Unit{slot, cnt});
                         ring_need = std::max(ring_need, ring_stride(lens[i0]) * cnt);
                         slot += cnt;
@@ -522,7 +524,9 @@ int frieda_prove_many(frieda_multi* m, const uint8_t* const* blobs, const size_t
                 for (uint32_t slot = 0; slot < mine;) {
                     const uint32_t i0 = (uint32_t)d + slot * (uint32_t)n;
                     uint32_t cnt = 1;
-                    while (batchable && cnt < MULTI_UNIT && slot + cnt < mine && lens[i0 + cnt * n] == lens[i0]) cnt++;
+                    // (the very first unit is a single blob when more follow: the chip starts after one upload instead of four)
+                    const uint32_t cap = (slot == 0 && mine > MULTI_UNIT) ? 1u : MULTI_UNIT;
+                    while (batchable && cnt < cap && slot + cnt < mine && lens[i0 + cnt * n] == lens[i0]) cnt++;
                     units.push_back(Unit{slot, cnt});
                     ring_need = std::max(ring_need, ring_stride(lens[i0]) * cnt);
                     slot += cnt;

@@ -508,6 +508,7 @@ def test_cpp_multi_gpu_entry_points(gpu_ctx, n_slots, mode):
     env = dict(os.environ)
     env.pop("FRIEDA_RCCL_PATH", None)
     env.pop("FRIEDA_MULTI_FORCE_RCCL", None)
+    env.setdefault("NCCL_SOCKET_IFNAME", "lo")  # RCCL's bootstrap over the loopback: the container's own interface may not resolve
     if mode == "rccl":
         env["FRIEDA_MULTI_FORCE_RCCL"] = "1"
     if mode == "stub":
@@ -533,12 +534,14 @@ def test_cpp_multi_gpu_real_rccl():
 
     n = min(_visible_gpus(), 8)
     exe = os.path.join(ROOT, "tests", "cpp", "test_api.bin")
-    r = subprocess.run([exe, os.path.join(GOLDEN, "blob"), "multi_real", str(n)], capture_output=True, text=True, timeout=900)
+    env = dict(os.environ)
+    env.setdefault("NCCL_SOCKET_IFNAME", "lo")  # one node: bootstrap over the loopback
+    r = subprocess.run([exe, os.path.join(GOLDEN, "blob"), "multi_real", str(n)], capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0 and "rccl=1" in r.stdout, r.stdout + r.stderr
 
 
 @pytest.mark.skipif(_visible_gpus() < 2, reason="needs a node with >= 2 visible GPUs (runs unprompted wherever there are)")
-def test_config4_eight_2p22_blobs_across_all_gpus_real_rccl(oracle):
+def test_config4_eight_2p22_blobs_across_all_gpus_real_rccl(oracle, monkeypatch):
     """BASELINE.json configs[3] as written: 8 independent 2^22-domain blobs (generator seeds 100..107, benches/proof.rs:30-44 per
     blob), one per GPU round-robin over every visible device, roots gathered by the real RCCL all-gather: all 8 roots and all 8
     proofs byte-identical to the oracle's."""
@@ -553,6 +556,8 @@ def test_config4_eight_2p22_blobs_across_all_gpus_real_rccl(oracle):
     ocfg = oracle.make_config(20, 4, 0, 20)
     with ThreadPoolExecutor(max_workers=8) as ex:
         expected = list(ex.map(lambda a: oracle.commit_and_generate_proof(a[0], a[1], ocfg), zip(blobs, seeds)))
+    if "NCCL_SOCKET_IFNAME" not in os.environ:
+        monkeypatch.setenv("NCCL_SOCKET_IFNAME", "lo")  # one node: bootstrap over the loopback
     mc = frieda_amd.MultiContext(list(range(n)))
     assert mc.device_count == n and mc.uses_rccl
     assert mc.commit_many(blobs, 4) == [r for r, _ in expected]
