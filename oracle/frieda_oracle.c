@@ -10,6 +10,9 @@
  *
  * Parity: codec + domain + twiddles + FFT + Merkle are PINNED by the golden root of
  * src/commit.rs:31-37.  Channel / folds / grind / queries / decommit / verify: parity unpinned.
+ * The reconstruction side (fo_circle_interpolate_block, fo_reconstruct_cells, fo_reconstruct_points) has no counterpart in
+ * /root/reference/src (README-only sample() flow): it is checked by inverting the pinned encode (round trips) and by two
+ * independent routes agreeing (dense solve vs erasure locator).
  */
 #include "frieda_oracle.h"
 
