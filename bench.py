@@ -95,6 +95,8 @@ def traffic_from_profiles(kernel, n, workload):
         src = f"profiles/{name} (committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command in lone-proof mode, --batch 1 --in-flight 1"
         if doc.get("collected_at_commit"):
             src += f", collected at commit {doc['collected_at_commit']}"
+        if doc.get("csrc_sha16"):
+            src += ("; frieda_amd/csrc unchanged since" if doc["csrc_sha16"] == _csrc_sha16() else "; STALE: frieda_amd/csrc has changed since the counters were taken")
         bat = None
         try:
             b = doc["batched"]
@@ -103,6 +105,19 @@ def traffic_from_profiles(kernel, n, workload):
             pass
         return val, src + "; not re-measured in this run)", bat
     return None, "none: no committed PMC pass names this kernel", None
+
+
+def _csrc_sha16():
+    """the same fingerprint tools/traffic_from_pmc.py stores in the traffic file"""
+    import hashlib
+
+    root = os.path.join(ROOT, "frieda_amd", "csrc")
+    h = hashlib.sha256()
+    for name in sorted(os.listdir(root)):
+        if name.endswith((".hip", ".h", ".cpp")):
+            h.update(name.encode())
+            h.update(open(os.path.join(root, name), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def _host_threads():

@@ -70,6 +70,20 @@ def collect(d, correct):
     return agg, raw, cnt
 
 
+def csrc_sha16():
+    """fingerprint of the kernel and host sources the counters were taken on (bench.py compares it with the tree it runs from)"""
+    import hashlib
+    import os
+
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "frieda_amd", "csrc")
+    h = hashlib.sha256()
+    for name in sorted(os.listdir(root)):
+        if name.endswith((".hip", ".h", ".cpp")):
+            h.update(name.encode())
+            h.update(open(os.path.join(root, name), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def main():
     fetch_dir, write_dir, out = sys.argv[1], sys.argv[2], sys.argv[3]
     fa, fraw, fc = collect(fetch_dir, True)
@@ -81,6 +95,7 @@ def main():
     except OSError:
         commit = ""
     res = {"collected_at_commit": (sys.argv[4] if len(sys.argv) > 4 else commit) or None,
+           "csrc_sha16": csrc_sha16(),
            "_units": "averages per launch of the kernel family over the profiled run; traffic_bytes_per_launch in bytes; "
                      "FETCH_SIZE corrected per kernel symbol (RULES in tools/traffic_from_pmc.py)",
            "mode": "lone proofs (bench.py --batch 1 --in-flight 1): one blob per launch, nothing else on the chip — the launches bench.py's "
