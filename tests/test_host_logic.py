@@ -301,3 +301,25 @@ def test_opening_tables_equal_the_reference_decommit_walk():
             assert witness == E[li + 1], (n, li)
             mine = [(n - s + 1, c) for s in range(li + 2, n + 1) for c in E[s]]
             assert mine == hashes, (n, li)
+
+
+def test_traffic_fingerprint_is_one_function():
+    """bench.py reports `roofline.traffic` from a committed PMC pass and says whether frieda_amd/csrc changed since: the fingerprint in the
+    traffic file (tools/traffic_from_pmc.py) and the one bench.py computes must be the same function of the tree."""
+    import importlib.util
+    import os
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def load(name, path):
+        spec = importlib.util.spec_from_file_location(name, path)
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        return mod
+
+    b = load("bench_mod", os.path.join(root, "bench.py"))
+    t = load("traffic_mod", os.path.join(root, "tools", "traffic_from_pmc.py"))
+    assert b._csrc_sha16() == t.csrc_sha16() and len(b._csrc_sha16()) == 16
+    val, src, per_blob = b.traffic_from_profiles("ntt_last_tree7", 24, "prove")
+    assert val and val > 5e8 and "collected at commit" in src and ("unchanged since" in src or "STALE" in src)
+    assert b.traffic_from_profiles("ntt_last_tree7", 22, "prove")[0] is None
