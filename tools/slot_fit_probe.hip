@@ -51,10 +51,20 @@ static double chain_ms(F launch, hipStream_t s, int n) {
     return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
 }
 
-int main() {
+int main(int argc, char**) {
     hipStream_t sw, sc;
-    (void)hipStreamCreateWithFlags(&sw, hipStreamNonBlocking);
-    (void)hipStreamCreateWithFlags(&sc, hipStreamNonBlocking);
+    // argv[1] = "prio": the chain's stream at the highest priority, the wide stream at the lowest
+    int lo_p = 0, hi_p = 0;
+    (void)hipDeviceGetStreamPriorityRange(&lo_p, &hi_p);
+    const bool prio = argc > 1;
+    if (prio) {
+        printf("stream priorities: wide %d, chain %d\n", lo_p, hi_p);
+        (void)hipStreamCreateWithPriority(&sw, hipStreamNonBlocking, lo_p);
+        (void)hipStreamCreateWithPriority(&sc, hipStreamNonBlocking, hi_p);
+    } else {
+        (void)hipStreamCreateWithFlags(&sw, hipStreamNonBlocking);
+        (void)hipStreamCreateWithFlags(&sc, hipStreamNonBlocking);
+    }
     uint32_t *d_out, *d_chain;
     const int wide_blocks = 256 * 8 * 16;  // 16 rounds of the chip's 2048 slots
     (void)hipMalloc(&d_out, (size_t)wide_blocks * 256 * 4);
