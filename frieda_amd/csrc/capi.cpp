@@ -864,27 +864,36 @@ int interpolate_points(frieda_ctx* ctx, const uint32_t* d_cells, const uint32_t*
     const size_t N = (size_t)1 << log_domain, K = (size_t)1 << log_coef, M = (size_t)1 << log_cell;
     const uint32_t n = log_domain;
     // distinct sampled positions (first occurrence of every cell wins), and where their values sit in the caller's buffer
-    std::vector<uint8_t> known(N, 0);
-    std::vector<uint32_t> pos, src;
-    pos.reserve((size_t)n_cells * M);
-    src.reserve((size_t)n_cells * M);
+    std::vector<uint64_t> known((((size_t)1 << (log_domain - log_cell)) + 63) / 64, 0);  // one bit per cell of the domain
+    std::vector<uint32_t> pos((size_t)n_cells * M), src((size_t)n_cells * M);
+    size_t n_pts = 0;
     for (uint32_t r = 0; r < n_cells; r++) {
-        if ((uint64_t)cell_index[r] >= ((uint64_t)1 << (log_domain - log_cell))) return c.fail(FRIEDA_ERR_ARG, "points: cell index out of range");
-        const size_t p0 = (size_t)cell_index[r] << log_cell;
-        if (known[p0]) continue;
+        const uint32_t ci = cell_index[r];
+        if ((uint64_t)ci >= ((uint64_t)1 << (log_domain - log_cell))) return c.fail(FRIEDA_ERR_ARG, "points: cell index out of range");
+        if (known[ci >> 6] >> (ci & 63) & 1) continue;
+        known[ci >> 6] |= (uint64_t)1 << (ci & 63);
         if ((((uint64_t)r * ncols) << log_cell) + (((uint64_t)ncols) << log_cell) > 0xFFFFFFFFull) return c.fail(FRIEDA_ERR_ARG, "points: sample buffer beyond 2^32 words");
+        const size_t p0 = (size_t)ci << log_cell, s0 = ((size_t)r * ncols) << log_cell;
         for (size_t t = 0; t < M; t++) {
-            known[p0 + t] = 1;
-            pos.push_back((uint32_t)(p0 + t));
-            src.push_back((uint32_t)((((size_t)r * ncols) << log_cell) + t));
+            pos[n_pts] = (uint32_t)(p0 + t);
+            src[n_pts++] = (uint32_t)(s0 + t);
         }
     }
-    const uint32_t s_all = (uint32_t)pos.size();
+    const uint32_t s_all = (uint32_t)n_pts;
     if (s_all < K + 2)
         return c.fail(FRIEDA_ERR_ARG, "points: need at least 2^log_coef + 2 distinct points (the locator polynomial needs two spare samples)");
     // S, the points the locator is built from (all offered points serve the check): the first K + 2 single points, Z_S a product of
     // lines through pairs — or, for samples in cells of M >= 2 entries, the first K / M + 1 whole cells, Z_S a product over cells
-    const bool by_cells = log_cell >= 1;
+    // Single points of a large polynomial take Z_S through a product tree (O(K log^2 K)) instead of K / 2 lines at each of K points
+    // (O(K^2)); many small cells do too, as the single points they consist of (the per-cell form costs K * K / M factor evaluations:
+    // 38 ms against 9 ms for 2^16 cells of 16 on a 2^24 domain).  FRIEDA_ERASURE_TREE_MIN_LOG: smallest log_coef that takes the tree
+    // (default 15: 0.67 against 0.97 ms there; the parity tests lower it; 32 = never; read per call because the tests run both routes in one process).
+    const uint32_t tree_min_log = [] {
+        const char* e = getenv("FRIEDA_ERASURE_TREE_MIN_LOG");
+        const int v = e ? atoi(e) : 15;
+        return (uint32_t)(v < 6 ? 6 : v);
+    }();
+    const bool by_cells = log_cell >= 1 && !(log_coef >= tree_min_log && 2 * log_coef >= 35 + log_cell);
     const uint32_t n_use_cells = by_cells ? (uint32_t)(K >> log_cell) + 1 : 0;
     const uint32_t s_use = by_cells ? (uint32_t)((size_t)n_use_cells << log_cell) : (uint32_t)K + 2;
     const uint32_t n_lines = by_cells ? n_use_cells : s_use / 2;  // factors of Z_S
@@ -925,6 +934,8 @@ int interpolate_points(frieda_ctx* ctx, const uint32_t* d_cells, const uint32_t*
     const size_t o_q = plan.take(al(4 * N) * ncols);   // coefficients of Z * p
     const size_t o_ev = plan.take(al(8 * N) * ncols);  // Z * p on D'
     const size_t o_blk = plan.take(al(4 * K) * ncols);
+    const bool by_tree = !by_cells && log_coef >= tree_min_log;
+    const size_t o_ta = plan.take(by_tree ? 8 * K : 0), o_tb = plan.take(by_tree ? 8 * K : 0), o_tc = plan.take(by_tree ? 16 * K : 0);
     int rc = c.ensure_arena(plan.off);
     if (rc) return rc;
     TwiddleSet ts0, ts1;
@@ -948,10 +959,50 @@ int interpolate_points(frieda_ctx* ctx, const uint32_t* d_cells, const uint32_t*
         k::erasure_cellconst(LN, g0, W32(o_lb), n_use_cells, log_cell, W32(o_la));
         k::erasure_zeval_cells(LN, W32(o_px), s_use, log_cell, W32(o_la), n_use_cells, true, W32(o_zp), W32(o_z));
         k::erasure_known_weights_cells(LN, W32(o_px), s_use, n, log_cell, W32(o_z));
-    } else {
+    } else if (!by_tree) {
         k::erasure_lines(LN, g0, W32(o_pos), n_lines, W32(o_la), W32(o_lb), W32(o_lc));
         k::erasure_zeval(LN, W32(o_px), W32(o_py), s_use, W32(o_la), W32(o_lb), W32(o_lc), n_lines, true, W32(o_zp), W32(o_z));
         k::erasure_known_weights(LN, W32(o_px), W32(o_py), s_use, n, W32(o_z));
+    } else {
+        // Z_S = (product of the first K / 2 lines, by a tree) * (the last line).  A node over 2^j * 32 lines (degree 2^j * 32) is held as its
+        // values on the canonic domain of 2^(j + 7) points; two children go to the parent's domain through their coefficients (the canonic
+        // domains of different sizes share no points) and multiply pointwise there.  The root (degree K / 2, 2 K values) -> coefficients ->
+        // all of D' (o_ev, free until step 3).  Then Z_E = V_D / Z_S: its values on the first N points of D' -> its N coefficients -> its
+        // values on D, of which the S entries are the weights of step 2 (no derivative needed on this route).
+        k::erasure_lines(LN, g0, W32(o_pos), n_lines, W32(o_la), W32(o_lb), W32(o_lc));
+        const k::ErasureDomain g7 = make_domain(7);
+        k::erasure_points(LN, g7, nullptr, 128, W32(o_px), W32(o_py));
+        uint32_t nodes = (uint32_t)(K / 64), d = 7;  // K / 2 lines in leaves of 32
+        k::erasure_lines32(LN, W32(o_px), W32(o_py), W32(o_la), W32(o_lb), W32(o_lc), (uint32_t)(K / 2), W32(o_ta));
+        const uint32_t col_chunk = 32768;
+        while (nodes > 1) {
+            TwiddleSet tsd, tse;
+            rc = c.get_twiddles(d, tsd);
+            if (rc) return rc;
+            rc = c.get_twiddles(d + 1, tse);
+            if (rc) return rc;
+            const size_t sz = (size_t)1 << d;
+            for (uint32_t at = 0; at < nodes; at += col_chunk) {
+                const uint32_t cnt = std::min(col_chunk, nodes - at);
+                k::circle_interpolate_block(LN, W32(o_ta) + at * sz, sz, cnt, d, d, 0, tsd.d_itw, tsd.ds, W32(o_tb) + at * sz, sz);
+                k::circle_evaluate(LN, W32(o_tb) + at * sz, sz, cnt, d, d + 1, tse.d_tw, tse.ds, W32(o_tc) + (size_t)at * 2 * sz, 2 * sz);
+            }
+            k::erasure_pairmul(LN, W32(o_tc), nodes, (uint32_t)(2 * sz), W32(o_ta));
+            nodes /= 2;
+            d++;
+        }
+        // d == log_coef + 1 here: the root's 2 K values -> coefficients -> D' (2 N points)
+        TwiddleSet tsr;
+        rc = c.get_twiddles(d, tsr);
+        if (rc) return rc;
+        k::circle_interpolate_block(LN, W32(o_ta), (size_t)1 << d, 1, d, d, 0, tsr.d_itw, tsr.ds, W32(o_tb), (size_t)1 << d);
+        k::circle_evaluate(LN, W32(o_tb), (size_t)1 << d, 1, d, n + 1, ts1.d_tw, ts1.ds, W32(o_ev), ev_stride);
+        k::erasure_mulline(LN, g1, W32(o_la) + (n_lines - 1), W32(o_lb) + (n_lines - 1), W32(o_lc) + (n_lines - 1), (uint32_t)(2 * N), W32(o_ev));
+        FR_HIP(&c, hipMemcpyAsync(A + o_tc, A + o_ev, 4 * K, hipMemcpyDeviceToDevice, s));  // Z_S on the block step 3 divides on
+        k::erasure_ze(LN, g1, W32(o_ev), (uint32_t)N, n, W32(o_q));
+        k::circle_interpolate_block(LN, W32(o_q), w_stride, 1, n, n + 1, 0, ts1.d_itw, ts1.ds, W32(o_w), w_stride);
+        k::circle_evaluate(LN, W32(o_w), w_stride, 1, n, n, ts0.d_tw, ts0.ds, W32(o_q), w_stride);
+        k::erasure_gather(LN, W32(o_q), W32(o_pos), s_use, W32(o_z));
     }
     // 2. Z * p on D -> its coefficients
     FR_HIP(&c, hipMemsetAsync(A + o_w, 0, al(4 * N) * ncols, s));
@@ -962,6 +1013,8 @@ int interpolate_points(frieda_ctx* ctx, const uint32_t* d_cells, const uint32_t*
     k::erasure_points(LN, g1, nullptr, (uint32_t)K, W32(o_px), W32(o_py));
     if (by_cells)
         k::erasure_zeval_cells(LN, W32(o_px), (uint32_t)K, log_cell, W32(o_la), n_use_cells, false, W32(o_zp), W32(o_z));
+    else if (by_tree)
+        FR_HIP(&c, hipMemcpyAsync(A + o_z, A + o_tc, 4 * K, hipMemcpyDeviceToDevice, s));
     else
         k::erasure_zeval(LN, W32(o_px), W32(o_py), (uint32_t)K, W32(o_la), W32(o_lb), W32(o_lc), n_lines, false, W32(o_zp), W32(o_z));
     k::erasure_divide(LN, W32(o_ev), ev_stride, W32(o_z), W32(o_px), (uint32_t)K, ncols, n, W32(o_blk), blk_stride);

@@ -204,6 +204,62 @@ __global__ void erasure_divide_kernel(const uint32_t* __restrict__ ev, size_t ev
     for (uint32_t c = 0; c < ncols; c++) block[(size_t)c * block_stride + t] = m31_mul(ev[(size_t)c * ev_stride + t], f);
 }
 
+// ---- single points, large K: Z_S by a product tree instead of line by line ----
+// Leaves of the tree: the product of 32 consecutive lines (degree 32) as its values on the canonic domain of 128 points (px, py):
+// out[node][t], 128 threads per node.  Lines beyond n_lines count as the constant 1.
+__global__ __launch_bounds__(128) void erasure_lines32_kernel(const uint32_t* __restrict__ px, const uint32_t* __restrict__ py, const uint32_t* __restrict__ la,
+                                                              const uint32_t* __restrict__ lb, const uint32_t* __restrict__ lc, uint32_t n_lines,
+                                                              uint32_t* __restrict__ out) {
+    __shared__ uint32_t sa[32], sb[32], sc[32];
+    const uint32_t node = blockIdx.x, t = threadIdx.x;
+    const uint32_t first = 32u * node;
+    if (t < 32) {
+        const bool live = first + t < n_lines;
+        sa[t] = live ? la[first + t] : 0u;
+        sb[t] = live ? lb[first + t] : 0u;
+        sc[t] = live ? lc[first + t] : 1u;
+    }
+    __syncthreads();
+    const uint32_t x = px[t], y = py[t];
+    uint32_t z = 1;
+#pragma unroll 8
+    for (int i = 0; i < 32; i++) z = m31_mul(z, m31_reduce64((uint64_t)sa[i] * x + (uint64_t)sb[i] * y + sc[i]));
+    out[(size_t)node * 128 + t] = z;
+}
+
+// parent[i][t] = ext[2 i][t] * ext[2 i + 1][t] (a last child without a sibling is copied), t < size
+__global__ void erasure_pairmul_kernel(const uint32_t* __restrict__ ext, uint32_t n_nodes, uint32_t size, uint32_t* __restrict__ out) {
+    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t total = (size_t)((n_nodes + 1) / 2) * size;
+    if (e >= total) return;
+    const size_t i = e / size, t = e % size;
+    const uint32_t a = ext[(2 * i) * size + t];
+    out[e] = 2 * i + 1 < n_nodes ? m31_mul(a, ext[(2 * i + 1) * size + t]) : a;
+}
+
+// ze[t] = V_D(P_t) / zs[t] for the first `count` points P_t of the next canonic domain g1 (V_D = pi^(n-1)(x) of the domain of log size n)
+__global__ void erasure_ze_kernel(ErasureDomain g1, const uint32_t* __restrict__ zs, uint32_t count, uint32_t n, uint32_t* __restrict__ ze) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= count) return;
+    uint32_t x = domain_point(g1, t).x;
+    for (uint32_t j = 0; j + 1 < n; j++) x = double_x(x);
+    ze[t] = m31_mul(x, m31_inv(zs[t]));
+}
+
+// zs[t] *= (a x + b y + c)(P_t): one more line into a locator already evaluated on the first `count` points of g1
+__global__ void erasure_mulline_kernel(ErasureDomain g1, const uint32_t* __restrict__ la, const uint32_t* __restrict__ lb, const uint32_t* __restrict__ lc,
+                                       uint32_t count, uint32_t* __restrict__ zs) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= count) return;
+    const CPoint p = domain_point(g1, t);
+    zs[t] = m31_mul(zs[t], m31_reduce64((uint64_t)la[0] * p.x + (uint64_t)lb[0] * p.y + lc[0]));
+}
+
+__global__ void erasure_gather_kernel(const uint32_t* __restrict__ src, const uint32_t* __restrict__ pos, uint32_t count, uint32_t* __restrict__ out) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < count) out[t] = src[pos[t]];
+}
+
 // mismatch[0] += number of offered samples that differ from the re-encoded polynomial: ev[c][pos[t]] vs cells[src[t] + c * 2^log_cell]
 __global__ void erasure_check_kernel(const uint32_t* __restrict__ cells, const uint32_t* __restrict__ src, const uint32_t* __restrict__ pos,
                                      uint32_t count, uint32_t ncols, uint32_t log_cell, const uint32_t* __restrict__ ev, size_t ev_stride,
@@ -280,6 +336,37 @@ void erasure_zeval_cells(const Launch& L_, const uint32_t* d_px, uint32_t count,
 void erasure_known_weights_cells(const Launch& L_, const uint32_t* d_px, uint32_t count, uint32_t n, uint32_t m, uint32_t* d_z) {
     if (!count) return;
     erasure_known_weights_cells_kernel<<<(count + 255) / 256, 256, 0, L_.stream>>>(d_px, count, n, m, d_z);
+}
+
+void erasure_lines32(const Launch& L_, const uint32_t* d_px128, const uint32_t* d_py128, const uint32_t* d_la, const uint32_t* d_lb, const uint32_t* d_lc,
+                     uint32_t n_lines, uint32_t* d_out) {
+    const uint32_t nodes = (n_lines + 31) / 32;
+    if (!nodes) return;
+    Scope scope(L_, "erasure_lines32", 12.0 * n_lines + 512.0 * nodes);
+    erasure_lines32_kernel<<<nodes, 128, 0, L_.stream>>>(d_px128, d_py128, d_la, d_lb, d_lc, n_lines, d_out);
+}
+
+void erasure_pairmul(const Launch& L_, const uint32_t* d_ext, uint32_t n_nodes, uint32_t size, uint32_t* d_out) {
+    const size_t total = (size_t)((n_nodes + 1) / 2) * size;
+    if (!total) return;
+    erasure_pairmul_kernel<<<(unsigned)((total + 255) / 256), 256, 0, L_.stream>>>(d_ext, n_nodes, size, d_out);
+}
+
+void erasure_ze(const Launch& L_, const ErasureDomain& g1, const uint32_t* d_zs, uint32_t count, uint32_t n, uint32_t* d_ze) {
+    if (!count) return;
+    Scope scope(L_, "erasure_ze", 8.0 * count);
+    erasure_ze_kernel<<<(count + 255) / 256, 256, 0, L_.stream>>>(g1, d_zs, count, n, d_ze);
+}
+
+void erasure_mulline(const Launch& L_, const ErasureDomain& g1, const uint32_t* d_la, const uint32_t* d_lb, const uint32_t* d_lc, uint32_t count,
+                     uint32_t* d_zs) {
+    if (!count) return;
+    erasure_mulline_kernel<<<(count + 255) / 256, 256, 0, L_.stream>>>(g1, d_la, d_lb, d_lc, count, d_zs);
+}
+
+void erasure_gather(const Launch& L_, const uint32_t* d_src, const uint32_t* d_pos, uint32_t count, uint32_t* d_out) {
+    if (!count) return;
+    erasure_gather_kernel<<<(count + 255) / 256, 256, 0, L_.stream>>>(d_src, d_pos, count, d_out);
 }
 
 void erasure_known_weights(const Launch& L_, const uint32_t* d_px, const uint32_t* d_py, uint32_t count, uint32_t n, uint32_t* d_z) {

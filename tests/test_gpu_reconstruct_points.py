@@ -110,6 +110,37 @@ def test_inconsistent_samples_are_reported(gpu_ctx, oracle, L, n, extra, where):
     assert np.array_equal(d_c.to_array(np.uint32, (2, 1 << L)), coef[:2])
 
 
+@pytest.mark.parametrize("L,n,extra,ncols", [(6, 7, 2, 4), (6, 10, 40, 3), (7, 9, 2, 4), (8, 12, 2, 4), (10, 11, 1022, 4), (10, 14, 2, 4), (12, 13, 2, 4),
+                                             (13, 17, 5, 2), (14, 18, 2, 4), (16, 17, 2, 1)])
+def test_product_tree_route_matches_line_route(gpu_ctx, oracle, monkeypatch, L, n, extra, ncols):
+    """Single points of a polynomial of >= 2^17 coefficients take Z_S through a product tree (O(K log^2 K)) instead of line by line
+    (O(K^2)); FRIEDA_ERASURE_TREE_MIN_LOG lowers the threshold so that both routes run on the same small inputs: identical coefficients,
+    equal to the truth (and to the oracle's restatement where it is quick), and a corrupted sample is still reported."""
+    rng = np.random.default_rng(9100 + 100 * L + n)
+    coef = rng.integers(0, P, (ncols, 1 << L), dtype=np.uint32)
+    ev = oracle.circle_evaluate(coef, n)
+    n_pts = min((1 << L) + extra, 1 << n)
+    idx = rng.permutation(1 << n)[:n_pts].astype(np.uint32)
+    cells = _cells(ev, idx, 0)
+    d_cells, d_c = DevBuf.from_array(gpu_ctx, cells), DevBuf(gpu_ctx, 4 * ncols << L)
+    got = {}
+    for route, min_log in (("lines", "32"), ("tree", "6")):
+        monkeypatch.setenv("FRIEDA_ERASURE_TREE_MIN_LOG", min_log)
+        poison = np.full((ncols, 1 << L), 0xEEEEEEEE, dtype=np.uint32)  # the second route must write its own answer
+        _check(gpu_ctx, gpu_ctx._L.frieda_dev_upload(gpu_ctx._h, d_c.ptr, poison.ctypes.data, poison.nbytes))
+        _check(gpu_ctx, gpu_ctx._L.frieda_circle_interpolate_points(gpu_ctx._h, d_cells.ptr, idx.ctypes.data, n_pts, ncols, 0, L, n, d_c.ptr))
+        got[route] = d_c.to_array(np.uint32, (ncols, 1 << L)).copy()
+    assert np.array_equal(got["tree"], coef) and np.array_equal(got["lines"], coef)
+    if n <= 12:
+        vals = np.ascontiguousarray(cells[:, :, 0])
+        assert np.array_equal(oracle.reconstruct_points(vals, idx, n, L), coef)
+    # a corrupted word among the points the locator is built from, tree route
+    cells[3, ncols - 1, 0] = (int(cells[3, ncols - 1, 0]) + 1) % P
+    d_bad = DevBuf.from_array(gpu_ctx, cells)
+    assert gpu_ctx._L.frieda_circle_interpolate_points(gpu_ctx._h, d_bad.ptr, idx.ctypes.data, n_pts, ncols, 0, L, n, d_c.ptr) == 1
+    assert "not values of one polynomial" in gpu_ctx._L.frieda_last_error(gpu_ctx._h).decode()
+
+
 def _encode_on_device(gpu_ctx, data, B):
     L_ = gpu_ctx._L
     nf, npad, lg = C.c_size_t(), C.c_size_t(), C.c_uint32()
@@ -136,7 +167,8 @@ def test_reference_blob_from_single_sampled_points(gpu_ctx, blob):
 
 
 @pytest.mark.parametrize("n_bytes,B,m,extra_cells", [(3000, 2, 0, 2), (70001, 2, 1, 1), (983040, 4, 2, 9), (983040, 1, 0, 2), (3932160, 4, 0, 2),
-                                                     (3932160, 4, 6, 33), (61440, 7, 0, 2), (15728640, 4, 0, 2)])
+                                                     (3932160, 4, 6, 33), (61440, 7, 0, 2), (15728640, 4, 0, 2),
+                                                     (3932160, 4, 1, 3), (15728640, 4, 4, 5)])  # many small cells: product-tree route
 def test_encode_sample_points_reconstruct_round_trip(gpu_ctx, n_bytes, B, m, extra_cells):
     """encode -> a sampling client's view (cells of 2^m entries scattered over the whole codeword, a handful more than the minimum) ->
     the original bytes; cell counts far beyond the 4096 of the dense solver (up to 2^20 + 2 single points on the 2^24 domain of the bench

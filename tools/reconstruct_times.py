@@ -53,3 +53,10 @@ for m, extra in ((0, 2), (0, 1 << (L - 2)), (4, 8), (8, 2), (L - 4, 1)):
         dt = time.perf_counter() - t0
     assert rc == 0 and d_o.to_array(np.uint8, (data.size,)).tobytes() == data.tobytes()
     print(f"| {n_cells} | 2^{m} | {extra} | {1e3 * dt:.2f} |")
+    if os.environ.get("KERNEL_REPORT") and m == 0 and extra == 2:  # where the time of the single-point case goes (device side)
+        ctx.set_kernel_timing(True)
+        L_.frieda_reconstruct_points_device(ctx._h, d_cells.ptr, idx.ctypes.data, n_cells, m, L, n, data.size, d_o.ptr)
+        rep = ctx.kernel_timing_report()
+        ctx.set_kernel_timing(False)
+        ks = rep if isinstance(rep, list) else rep["kernels"]
+        print("  device spans (ms): " + ", ".join(f"{k['name']} x{k['launches']} {k['total_ms']:.3f}" for k in ks) + f"; sum {sum(k['total_ms'] for k in ks):.3f}")
