@@ -383,6 +383,51 @@ def measure_config2(frieda_amd, torch, device, n=20):
             "frac_of_hbm_peak_wall": alg / dt / 1e9 / HBM_PEAK_GBS, "launches": "asynchronous on one context, 200 passes"}
 
 
+def reconstruct_side(frieda_amd, torch, device, n):
+    """The other side of data-availability sampling (/root/reference/README.md:56-69), device-resident and checked:
+    the blob of the headline size back from (i) one aligned 1/16 block of its codeword and (ii) 2^L + 2 single points sampled anywhere
+    in it (erasure-locator route: no linear system; every sample compared with the re-encoded result).  Not part of `value`."""
+    import numpy as np
+
+    L = n - 4
+    blob_len = blob_len_for(n)
+    ctx = frieda_amd.Context(device)
+    lib, h = ctx._L, ctx._h
+    data = torch.from_numpy(splitmix64_bytes(100, blob_len)).cuda()
+    coef = torch.empty((4, 1 << L), dtype=torch.int32, device="cuda")
+    ev = torch.empty((4, 1 << n), dtype=torch.int32, device="cuda")
+    assert lib.frieda_unpack30(h, data.data_ptr(), blob_len, coef.data_ptr(), 4 << L) == 0
+    assert lib.frieda_circle_evaluate(h, coef.data_ptr(), 4, L, n, ev.data_ptr()) == 0
+    out_bytes = torch.empty(blob_len + 8, dtype=torch.uint8, device="cuda")
+    g = torch.Generator(device="cpu").manual_seed(3)
+    n_pts = (1 << L) + 2
+    pos = torch.randperm(1 << n, generator=g)[:n_pts]
+    idx = np.ascontiguousarray(pos.numpy().astype(np.uint32))
+    cells = ev[:, pos.cuda()].t().contiguous()  # [n_pts][4][1]: the layout of frieda_reconstruct_points_device with cells of one entry
+    block = ev[:, 5 << L : 6 << L].contiguous()
+
+    def best(fn, reps=3):
+        t = None
+        for _ in range(reps + 1):  # first call sizes the workspace
+            out_bytes.zero_()
+            ctx.synchronize()
+            t0 = time.perf_counter()
+            assert fn() == 0
+            ctx.synchronize()
+            d = time.perf_counter() - t0
+            assert torch.equal(out_bytes[:blob_len], data), "a reconstructed blob differs from the original"
+            t = d if t is None else min(t, d)
+        return 1e3 * t
+
+    r = {"log_domain": n, "blob_bytes": blob_len,
+         "from_block_ms": best(lambda: lib.frieda_reconstruct_device(h, block.data_ptr(), L, n, 5, blob_len, out_bytes.data_ptr())),
+         "from_points_ms": best(lambda: lib.frieda_reconstruct_points_device(h, cells.data_ptr(), idx.ctypes.data, n_pts, 0, L, n, blob_len, out_bytes.data_ptr())),
+         "points": n_pts, "entry_points": "frieda_reconstruct_device (block 5 of 16), frieda_reconstruct_points_device (single points)",
+         "checked": "bytes equal to the original blob; every sample equal to the re-encoded codeword (inside the call)"}
+    ctx.close()
+    return r
+
+
 def end_to_end(frieda_amd, torch, device, n, K, cfg, expect_roots=None):
     """The reference API takes HOST bytes (`data: &[u8]`, /root/reference/src/lib.rs:31,36): the same stream of K distinct blobs
     handed over in host memory — pageable (what a Rust caller has) and page-locked — through the C ABI's throughput entry points
@@ -461,12 +506,13 @@ def parse_args(argv=None):
                          "so that every proof kernel a profiler sees is a launch of the measured loop")
     ap.add_argument("--no-by-config", action="store_true", help="skip the by_config block (the other BASELINE configurations)")
     ap.add_argument("--no-end-to-end", action="store_true", help="skip the end_to_end block (host blobs, PCIe-inclusive)")
+    ap.add_argument("--no-reconstruct", action="store_true", help="skip the reconstruct block (blob back from a block / from sampled points)")
     ap.add_argument("--dry-collective", choices=["gloo"], default=None,
                     help="CPU rehearsal of the N > 1 plumbing: launcher, rendezvous, barriers, root all_gather and max-reduce over gloo; GPU work stubbed")
     ap.add_argument("--launch-timeout", type=float, default=1500.0, help="seconds the self-launcher waits for its ranks")
     args = ap.parse_args(argv)
     if args.only_measured_loop:
-        args.no_by_config = args.no_end_to_end = args.no_cpu_baseline = True
+        args.no_by_config = args.no_end_to_end = args.no_cpu_baseline = args.no_reconstruct = True
         args.batch_extra = args.sequential_extra = 0
     if args.pipeline_depth is not None:
         args.in_flight = max(1, args.pipeline_depth)
@@ -973,6 +1019,13 @@ def main():
             raise  # wrong results are never swallowed
         except Exception as e:  # noqa: BLE001
             out["end_to_end"] = {"error": f"{type(e).__name__}: {e}"}
+    if rank == 0 and world == 1 and not args.no_reconstruct and n >= 12:
+        try:
+            out["reconstruct"] = reconstruct_side(frieda_amd, torch, local_rank, n)
+        except AssertionError:
+            raise
+        except Exception as e:  # noqa: BLE001
+            out["reconstruct"] = {"error": f"{type(e).__name__}: {e}"}
     if rank == 0 and world == 1 and not args.no_by_config:
         # the other BASELINE.json configurations through the same measured loop (configs[1]-[3]: 2^20 and 2^22 domains; commit() at
         # the headline size), so that the driver-run line carries them

@@ -45,6 +45,8 @@ def test_bench_line_small_domain(extra):
         e2e = d["end_to_end"]  # host blobs through frieda_prove_many / frieda_commit_many, pageable and page-locked, + a lone call
         for k in ("pageable_ms_per_blob", "pinned_ms_per_blob", "lone_call_ms", "pageable_commit_ms_per_blob", "pinned_commit_ms_per_blob", "device_resident_ms_per_blob"):
             assert e2e[k] > 0, k
+    rec = d["reconstruct"]  # the sampling side: the blob back from one 1/16 block and from 2^L + 2 single points, checked inside bench.py
+    assert rec["from_block_ms"] > 0 and rec["from_points_ms"] > 0 and rec["points"] == (1 << 12) + 2
     assert d["by_config"] == []  # nothing at or below 2^16 in BASELINE.json's configurations
 
 

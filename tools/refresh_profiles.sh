@@ -11,7 +11,7 @@ COMMIT=${2:-}
 OUT=gpurun_out/refresh
 mkdir -p $OUT
 export TMPDIR=/tmp
-ONE="--no-cpu-baseline --no-by-config --no-end-to-end --batch 1 --in-flight 1 --batch-extra 0 --sequential-extra 0"
+ONE="--no-cpu-baseline --no-by-config --no-end-to-end --no-reconstruct --batch 1 --in-flight 1 --batch-extra 0 --sequential-extra 0"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 bench.py --steps 2 --warmup 1 $ONE > /dev/null 2> $OUT/pmc_fetch_err.txt
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 bench.py --steps 2 --warmup 1 $ONE > /dev/null 2> $OUT/pmc_write_err.txt
 # the same two passes in the measured loop's own mode (4 blobs per call, 2 calls in flight): launches cover 4 blobs each
