@@ -141,6 +141,34 @@ def test_product_tree_route_matches_line_route(gpu_ctx, oracle, monkeypatch, L, 
     assert "not values of one polynomial" in gpu_ctx._L.frieda_last_error(gpu_ctx._h).decode()
 
 
+def test_random_shapes_both_routes(gpu_ctx, oracle, monkeypatch):
+    """Seeded sweep over (coefficients, blow-up, cell size, spare cells, columns) with the product tree forced on and off: always the
+    truth.  Shapes the fixed cases do not name: 2^6 coefficients (a tree of one leaf), blow-up 0 .. 5, cells larger than the polynomial."""
+    rng = np.random.default_rng(424242)
+    for case in range(60):
+        L = int(rng.integers(1, 13))
+        B = int(rng.integers(0 if L >= 2 else 1, 6))
+        n = max(L + B, 2)
+        m = int(rng.choice([0, 0, 0, 1, 2, 3, 5])) if n >= 3 else 0
+        m = min(m, n - 1)
+        ncols = int(rng.choice([1, 2, 3, 4, 5]))
+        need = ((1 << max(L - m, 0)) + 1) if m > 0 else (1 << L) + 2
+        total = 1 << (n - m)
+        if need > total:
+            continue  # (blow-up 0 leaves no spare samples)
+        n_cells = int(min(total, need + rng.integers(0, 6)))
+        coef = rng.integers(0, P, (ncols, 1 << L), dtype=np.uint32)
+        ev = oracle.circle_evaluate(coef, n)
+        idx = rng.permutation(total)[:n_cells].astype(np.uint32)
+        cells = _cells(ev, idx, m)
+        d_cells, d_c = DevBuf.from_array(gpu_ctx, cells), DevBuf(gpu_ctx, 4 * ncols << L)
+        for min_log in ("6", "32"):
+            monkeypatch.setenv("FRIEDA_ERASURE_TREE_MIN_LOG", min_log)
+            rc = gpu_ctx._L.frieda_circle_interpolate_points(gpu_ctx._h, d_cells.ptr, idx.ctypes.data, n_cells, ncols, m, L, n, d_c.ptr)
+            assert rc == 0, (case, L, n, m, ncols, n_cells, min_log, gpu_ctx._L.frieda_last_error(gpu_ctx._h))
+            assert np.array_equal(d_c.to_array(np.uint32, (ncols, 1 << L)), coef), (case, L, n, m, ncols, n_cells, min_log)
+
+
 def _encode_on_device(gpu_ctx, data, B):
     L_ = gpu_ctx._L
     nf, npad, lg = C.c_size_t(), C.c_size_t(), C.c_uint32()
@@ -168,7 +196,8 @@ def test_reference_blob_from_single_sampled_points(gpu_ctx, blob):
 
 @pytest.mark.parametrize("n_bytes,B,m,extra_cells", [(3000, 2, 0, 2), (70001, 2, 1, 1), (983040, 4, 2, 9), (983040, 1, 0, 2), (3932160, 4, 0, 2),
                                                      (3932160, 4, 6, 33), (61440, 7, 0, 2), (15728640, 4, 0, 2),
-                                                     (3932160, 4, 1, 3), (15728640, 4, 4, 5)])  # many small cells: product-tree route
+                                                     (3932160, 4, 1, 3), (15728640, 4, 4, 5),  # many small cells: product-tree route
+                                                     (62914560, 1, 0, 2)])  # 2^22 coefficients: 65536 leaves, the tree's transforms in two column chunks
 def test_encode_sample_points_reconstruct_round_trip(gpu_ctx, n_bytes, B, m, extra_cells):
     """encode -> a sampling client's view (cells of 2^m entries scattered over the whole codeword, a handful more than the minimum) ->
     the original bytes; cell counts far beyond the 4096 of the dense solver (up to 2^20 + 2 single points on the 2^24 domain of the bench
