@@ -237,13 +237,33 @@ __global__ void erasure_pairmul_kernel(const uint32_t* __restrict__ ext, uint32_
     out[e] = 2 * i + 1 < n_nodes ? m31_mul(a, ext[(2 * i + 1) * size + t]) : a;
 }
 
-// ze[t] = V_D(P_t) / zs[t] for the first `count` points P_t of the next canonic domain g1 (V_D = pi^(n-1)(x) of the domain of log size n)
+// ze[t] = V_D(P_t) / zs[t] for the first `count` <= 2^n points P_t of the next canonic domain g1 (V_D = pi^(n-1)(x) of the domain of log size n)
+// (a thread takes 8 points, lane-interleaved so that loads and stores stay coalesced, and inverts their product once: Montgomery's trick)
 __global__ void erasure_ze_kernel(ErasureDomain g1, const uint32_t* __restrict__ zs, uint32_t count, uint32_t n, uint32_t* __restrict__ ze) {
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= count) return;
-    uint32_t x = domain_point(g1, t).x;
-    for (uint32_t j = 0; j + 1 < n; j++) x = double_x(x);
-    ze[t] = m31_mul(x, m31_inv(zs[t]));
+    constexpr int PER = 8;
+    const uint32_t t0 = blockIdx.x * blockDim.x * PER + threadIdx.x;
+    uint32_t z[PER], pre[PER];
+    uint32_t acc = 1;
+#pragma unroll
+    for (int j = 0; j < PER; j++) {
+        const uint32_t t = t0 + (uint32_t)j * blockDim.x;
+        z[j] = t < count ? zs[t] : 1u;
+        pre[j] = acc;  // product of z[0 .. j)
+        acc = m31_mul(acc, z[j]);
+    }
+    uint32_t inv = m31_inv(acc);
+    // V_D = pi^(n-1)(x) is constant on the first half of the next canonic domain: n - 1 doublings take its half coset (initial + j * step,
+    // step of order 2^n) to initial' + j * (the point of order 2), i.e. to +-x' by the parity of j — and the first half of the
+    // bit-reversed order is the even j
+    uint32_t vd = domain_point(g1, 0).x;
+    for (uint32_t k = 0; k + 1 < n; k++) vd = double_x(vd);
+#pragma unroll
+    for (int j = PER - 1; j >= 0; j--) {
+        const uint32_t t = t0 + (uint32_t)j * blockDim.x;
+        const uint32_t zi = m31_mul(inv, pre[j]);  // 1 / z[j]
+        inv = m31_mul(inv, z[j]);
+        if (t < count) ze[t] = m31_mul(vd, zi);
+    }
 }
 
 // zs[t] *= (a x + b y + c)(P_t): one more line into a locator already evaluated on the first `count` points of g1
@@ -355,7 +375,7 @@ void erasure_pairmul(const Launch& L_, const uint32_t* d_ext, uint32_t n_nodes, 
 void erasure_ze(const Launch& L_, const ErasureDomain& g1, const uint32_t* d_zs, uint32_t count, uint32_t n, uint32_t* d_ze) {
     if (!count) return;
     Scope scope(L_, "erasure_ze", 8.0 * count);
-    erasure_ze_kernel<<<(count + 255) / 256, 256, 0, L_.stream>>>(g1, d_zs, count, n, d_ze);
+    erasure_ze_kernel<<<(count + 2047) / 2048, 256, 0, L_.stream>>>(g1, d_zs, count, n, d_ze);
 }
 
 void erasure_mulline(const Launch& L_, const ErasureDomain& g1, const uint32_t* d_la, const uint32_t* d_lb, const uint32_t* d_lc, uint32_t count,

@@ -13,6 +13,8 @@
 // thread runs up to four layers on 2^R elements in registers, lowest layer first.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "kernels.h"
 
 namespace frieda {
@@ -45,6 +47,7 @@ struct InttArgs {
     uint32_t n_stages;
     uint32_t stage_r[3];  // layers per stage, LOWEST stage first
     uint32_t scale;       // multiply every output by this (2^-L on the last pass, 1 otherwise)
+    uint32_t ncols;       // intt_tile12_kernel: columns handled by one workgroup (<= 4); grid.y strides over groups of this many
 };
 
 template <int R>
@@ -126,6 +129,128 @@ void set_inv_stages(InttArgs& a, uint32_t t) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The hot shapes, mirror image of ntt_tile12_kernel (ntt.hip): a 4096-word tile whose layers split into NS stages of exactly four —
+// NS = 3, LOG_W = 0: the contiguous first pass of 12 layers; NS = 2, LOG_W = 4: a strided pass of 8 layers (64-byte runs); NS = 1,
+// LOG_W = 8: a strided pass of 4 layers (1 KiB runs).  One group of 16 elements per thread and stage, lowest stage first; the 15 * NS
+// inverse twiddles of the thread are loaded once and serve the workgroup's (up to four) columns, those of the stage on tile bits 8..11
+// are workgroup-uniform and live in scalar registers.  The first stage takes its 16 elements straight from memory (the contiguous pass:
+// four 16-byte loads of the thread's own 16 consecutive words; the strided passes: 16 coalesced 4-byte loads), the last stage stores
+// straight from registers (element g + 256 r: consecutive lanes, consecutive words), so the 17 KiB LDS tile only carries the exchange
+// between stages — none at all for the 4-layer pass — and the next column's elements are prefetched while the current one is computed.
+// ------------------------------------------------------------------------------------------------
+template <int NS, int LOG_W>
+__global__ __launch_bounds__(INTT_THREADS) void intt_tile12_kernel(InttArgs a) {
+    __shared__ uint32_t lds[NS > 1 ? ITILE_WORDS : 1];
+    const uint32_t g = threadIdx.x;
+    const uint32_t nwb_log = a.i_lo - LOG_W;
+    const uint32_t wblk = blockIdx.x & ((1u << nwb_log) - 1);
+    const uint32_t hloc = blockIdx.x >> nwb_log;                   // index bits above i_hi inside the block
+    const uint32_t hblk = (a.block << (a.L - 1 - a.i_hi)) | hloc;  // ... and the block number above those
+    const uint32_t gbase = (hloc << (a.i_hi + 1)) | (wblk << LOG_W);
+    constexpr uint32_t wmask = (1u << LOG_W) - 1;
+    const size_t col0 = (size_t)blockIdx.y * a.ncols;
+    const uint32_t* in = a.in + col0 * a.in_stride;
+    uint32_t* out = a.out + col0 * a.out_stride;
+
+    uint32_t pbase[NS];
+    uint32_t twd[NS][15];
+#pragma unroll
+    for (int s = 0; s < NS; s++) {
+        constexpr uint32_t lo0 = LOG_W;
+        const uint32_t lo = lo0 + 4u * (uint32_t)s;
+        const uint32_t base = ((g >> lo) << (lo + 4)) | (g & ((1u << lo) - 1));
+        pbase[s] = ipad(base);
+#pragma unroll
+        for (int bit = 0; bit < 4; bit++) {
+            const int q = 3 - bit;  // 2^q distinct twiddles in this layer of the group
+            const uint32_t b = lo + (uint32_t)bit;
+            const uint32_t i = a.i_lo + b - LOG_W;
+            const uint32_t hbase = (hblk << (a.i_hi - i)) | (base >> (b + 1));  // its low q bits are zero
+            if (LOG_W == 0 && s == 0 && bit == 0) {  // i == 0: the circle layer
+#pragma unroll
+                for (int u = 0; u < 8; u++) twd[s][7 + u] = inv_circle_tw(a.itw, a.n, hbase + (uint32_t)u, a.inv_init_y);
+            } else {
+                const uint32_t* lvl = a.itw + tw_level_offset_dev(a.n, i - 1) + hbase;
+#pragma unroll
+                for (int u = 0; u < (1 << q); u++) {
+                    uint32_t v = lvl[u];
+                    if (LOG_W + 4 * s == 8) v = (uint32_t)__builtin_amdgcn_readfirstlane((int)v);  // tile bits 8..11: no thread-dependent index bits
+                    twd[s][(1 << q) - 1 + u] = v;
+                }
+            }
+        }
+    }
+
+    // the thread's 16 elements of the first stage (tile bits LOG_W .. LOG_W + 3) and of the last one (tile bits 8 .. 11), as global indices
+    auto global_of = [&](uint32_t e) { return gbase | ((e >> LOG_W) << a.i_lo) | (e & wmask); };
+    const uint32_t base_first = ((g >> LOG_W) << (LOG_W + 4)) | (g & wmask);
+    auto load16 = [&](const uint32_t* src, uint32_t* x) {
+        if (LOG_W == 0) {
+            const uint4* p = reinterpret_cast<const uint4*>(src + gbase + 16u * g);
+#pragma unroll
+            for (int kk = 0; kk < 4; kk++) {
+                const uint4 v = p[kk];
+                x[4 * kk] = v.x;
+                x[4 * kk + 1] = v.y;
+                x[4 * kk + 2] = v.z;
+                x[4 * kk + 3] = v.w;
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; r++) x[r] = src[global_of(base_first | ((uint32_t)r << LOG_W))];
+        }
+    };
+
+    uint32_t pre[16];
+    load16(in, pre);
+    for (uint32_t c = 0; c < a.ncols; c++) {
+        uint32_t x[16];
+#pragma unroll
+        for (int r = 0; r < 16; r++) x[r] = pre[r];
+        if (c + 1 < a.ncols) load16(in + (size_t)(c + 1) * a.in_stride, pre);  // prefetch the next column
+#pragma unroll
+        for (int s = 0; s < NS; s++) {
+            const uint32_t lo = LOG_W + 4u * (uint32_t)s;
+            uint32_t* col = lds + pbase[s];
+            if (s > 0) {
+#pragma unroll
+                for (int r = 0; r < 16; r++) x[r] = col[ipad((uint32_t)r << lo)];
+            }
+#pragma unroll
+            for (int bit = 0; bit < 4; bit++) {
+                const int q = 3 - bit;
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    if (r & (1 << bit)) continue;
+                    const int u = r >> (bit + 1);
+                    const uint32_t v0 = x[r], v1 = x[r | (1 << bit)];
+                    x[r] = m31_add(v0, v1);
+                    x[r | (1 << bit)] = m31_mul(m31_sub(v0, v1), twd[s][(1 << q) - 1 + u]);
+                }
+            }
+            if (s + 1 < NS) {
+#pragma unroll
+                for (int r = 0; r < 16; r++) col[ipad((uint32_t)r << lo)] = x[r];
+                // The stages on tile bits 0..3 and 4..7 only exchange data inside a wave's own 1024 elements (as in ntt_tile12_kernel): no
+                // workgroup barrier between those two, only program order.
+                if (LOG_W == 0 && NS == 3 && s == 0)
+                    __builtin_amdgcn_wave_barrier();
+                else
+                    __syncthreads();
+            }
+        }
+        // last stage: tile bits 8..11, the thread holds elements g + 256 r
+        uint32_t* dst = out + (size_t)c * a.out_stride;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const uint32_t v = a.scale == 1u ? x[r] : m31_mul(x[r], a.scale);
+            dst[global_of(g | ((uint32_t)r << 8))] = v;
+        }
+        if (NS > 1 && c + 1 < a.ncols) __syncthreads();  // the next column's first exchange overwrites the tile other waves may still read
+    }
+}
+
 // felts -> bytes: output dword d holds stream bits [32 d, 32 d + 32), i.e. pieces of the felts floor(32 d / 30) ..
 __global__ __launch_bounds__(256) void pack30_kernel(const uint32_t* __restrict__ felts, size_t n_felts, uint8_t* __restrict__ out,
                                                      size_t len) {
@@ -175,10 +300,38 @@ void circle_interpolate_block(const Launch& L_, const uint32_t* d_block, size_t 
     a.block = block;
     a.inv_init_y = ds.inv_init_y;
     const uint32_t scale = (1u << (31 - L)) % P31;  // 2^-L = 2^(31-L) mod P
+    // 12 or more layers over 16-byte aligned buffers: the first 12 layers, then the strided ones 8 and 4 at a time, as passes of
+    // intt_tile12_kernel; what is left (L mod 4 layers) and every other shape goes through the generic kernel below.
+    static const bool no_fast = getenv("FRIEDA_INTT_GENERIC") != nullptr;  // A/B knob
+    const bool aligned = ((in_stride | out_stride) & 3) == 0 && ((reinterpret_cast<uintptr_t>(d_block) | reinterpret_cast<uintptr_t>(d_coef)) & 15) == 0;
+    uint32_t done = 0;
+    if (L >= ITILE_LOG && aligned && !no_fast) {
+        uint32_t cpw = 4;
+        while (ncols % cpw) cpw--;
+        a.ncols = cpw;
+        const dim3 grid((unsigned)(M >> ITILE_LOG), ncols / cpw);
+        a.i_lo = 0;
+        a.i_hi = ITILE_LOG - 1;
+        a.scale = L == ITILE_LOG ? scale : 1u;
+        intt_tile12_kernel<3, 0><<<grid, INTT_THREADS, 0, s>>>(a);
+        done = ITILE_LOG;
+        a.in = d_coef;
+        a.in_stride = out_stride;
+        while (L - done >= 4) {
+            const uint32_t t = L - done >= 8 ? 8u : 4u;
+            a.i_lo = done;
+            a.i_hi = done + t - 1;
+            done += t;
+            a.scale = done == L ? scale : 1u;
+            if (t == 8)
+                intt_tile12_kernel<2, 4><<<grid, INTT_THREADS, 0, s>>>(a);
+            else
+                intt_tile12_kernel<1, 8><<<grid, INTT_THREADS, 0, s>>>(a);
+        }
+    }
     // first pass: layers 0 .. t0-1 (contiguous); later passes: up to 8 strided layers each
     const uint32_t t0 = L < ITILE_LOG ? L : ITILE_LOG;
-    uint32_t done = 0;
-    {
+    if (done == 0) {
         a.i_lo = 0;
         a.i_hi = t0 - 1;
         a.log_w = 0;
@@ -195,7 +348,7 @@ void circle_interpolate_block(const Launch& L_, const uint32_t* d_block, size_t 
         uint32_t t = L - done < mid_max ? L - done : mid_max;
         a.i_lo = done;
         a.i_hi = done + t - 1;
-        a.log_w = IMID_LOG_W;  // done >= 12 here
+        a.log_w = ITILE_LOG - t;  // done >= 12 >= log_w here: a pass of fewer than 8 layers takes longer runs so that its tile still has 4096 words
         set_inv_stages(a, t);
         done += t;
         a.scale = done == L ? scale : 1u;

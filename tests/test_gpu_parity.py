@@ -829,6 +829,37 @@ def test_circle_interpolate_blocks(gpu_ctx, oracle, L, n):
         assert np.array_equal(d_c.to_array(np.uint32, (ncols, 1 << L)), coef), f"block {k}"
 
 
+@pytest.mark.parametrize("L,n,ncols", [(12, 12, 1), (12, 13, 3), (13, 13, 4), (14, 15, 2), (15, 19, 5), (16, 16, 4), (17, 18, 1), (18, 18, 8), (19, 20, 4),
+                                       (20, 20, 2), (21, 22, 4), (22, 22, 1), (23, 23, 2), (24, 24, 4), (20, 24, 4), (24, 25, 1)])
+def test_circle_interpolate_pass_plans(gpu_ctx, oracle, L, n, ncols):
+    """Every plan of the inverse transform from 12 layers on: the contiguous 12-layer pass, strided passes of 8 and 4 layers
+    (intt_tile12_kernel<3,0> / <2,4> / <1,8>) and the generic kernel for the L mod 4 layers left, 1 .. 8 columns (groups of 4, 3, 2, 1
+    per workgroup), first / last / a middle block.  Truth: the coefficients that were encoded (oracle encode up to 2^20, the device's own
+    parity-tested encode above that); and an unaligned source (word offset 1) takes the generic kernel to the same answer."""
+    rng = np.random.default_rng(5100 + 31 * n + L)
+    coef = rand_m31(rng, (ncols, 1 << L))
+    if n <= 20:
+        ev = oracle.circle_evaluate(coef, n)
+    else:
+        d_c0, d_ev = DevBuf.from_array(gpu_ctx, coef), DevBuf(gpu_ctx, 4 * ncols << n)
+        _check(gpu_ctx, gpu_ctx._L.frieda_circle_evaluate(gpu_ctx._h, d_c0.ptr, ncols, L, n, d_ev.ptr))
+        ev = d_ev.to_array(np.uint32, (ncols, 1 << n))
+        d_c0.free(), d_ev.free()
+    nb = 1 << (n - L)
+    for k in sorted(set([0, nb - 1, nb // 2])):
+        blk = np.ascontiguousarray(ev[:, k << L : (k + 1) << L])
+        d_b, d_c = DevBuf.from_array(gpu_ctx, blk), DevBuf(gpu_ctx, 4 * ncols << L)
+        _check(gpu_ctx, gpu_ctx._L.frieda_circle_interpolate(gpu_ctx._h, d_b.ptr, ncols, L, n, k, d_c.ptr))
+        assert np.array_equal(d_c.to_array(np.uint32, (ncols, 1 << L)), coef), f"block {k}"
+    if ncols == 1 and L <= 22:
+        import ctypes as C
+
+        shifted = np.concatenate([np.zeros(1, np.uint32), blk.ravel()])
+        d_s = DevBuf.from_array(gpu_ctx, shifted)
+        _check(gpu_ctx, gpu_ctx._L.frieda_circle_interpolate(gpu_ctx._h, C.c_void_p(d_s.ptr.value + 4), 1, L, n, k, d_c.ptr))
+        assert np.array_equal(d_c.to_array(np.uint32, (1, 1 << L)), coef)
+
+
 @pytest.mark.parametrize("n_bytes", [1, 3, 4, 15, 16, 58, 119, 120, 1000, 4097, 65536])
 def test_pack30(gpu_ctx, oracle, n_bytes):
     data = splitmix64_bytes(13, n_bytes)
