@@ -1,5 +1,7 @@
+"""Forward (frieda_circle_evaluate, L = n) against inverse (frieda_circle_interpolate, block 0) transform times, 1 and 4 columns.  Measurement aid;
+FRIEDA_INTT_GENERIC=1 gives the one-column inverse kernel for the A/B."""
 import sys, time, os
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, frieda_amd
 ctx = frieda_amd.Context(0); lib, h = ctx._L, ctx._h
 for n in (20, 22, 24):
