@@ -257,38 +257,47 @@ def measure_config(frieda_amd, torch, device, n, workload, K, BSZ, D, cfg):
     path_bytes = algorithmic_bytes(n, workload)
     out = {"log_domain": n, "workload": "commit_and_generate_proof" if workload == "prove" else "commit", "blob_bytes": blob_len, "blobs": K}
     if workload == "prove":
-        pipe = frieda_amd.BatchPipeline(device, D) if BSZ > 1 else frieda_amd.ProofPipeline(device, D)
+        def stream(bsz):
+            pipe = frieda_amd.BatchPipeline(device, D) if bsz > 1 else frieda_amd.ProofPipeline(device, D)
 
-        def run():
-            res = []
-            for i in range(0, K, BSZ):
-                cnt = min(BSZ, K - i)
-                if BSZ > 1:
-                    r = pipe.submit_device(blobs[i].data_ptr(), blob_len, blob_len, cnt, [seed] * cnt, cfg)
-                    if r is not None:
-                        res.extend(r)
-                else:
-                    r = pipe.submit_device(blobs[i].data_ptr(), blob_len, seed, cfg)
-                    if r is not None:
-                        res.append(r)
-            res.extend(pipe.drain())
-            return res
+            def run():
+                res = []
+                for i in range(0, K, bsz):
+                    cnt = min(bsz, K - i)
+                    if bsz > 1:
+                        r = pipe.submit_device(blobs[i].data_ptr(), blob_len, blob_len, cnt, [seed] * cnt, cfg)
+                        if r is not None:
+                            res.extend(r)
+                    else:
+                        r = pipe.submit_device(blobs[i].data_ptr(), blob_len, seed, cfg)
+                        if r is not None:
+                            res.append(r)
+                res.extend(pipe.drain())
+                return res
 
-        run()  # sizes the workspaces, builds the twiddles
-        run()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        res = run()
-        torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / K
-        assert len(res) == K and len({r for r, _ in res}) == K
-        for r, p in res:
-            assert p.commitment == r and frieda_amd.verify(p, seed), "a timed proof does not verify"
+            run()  # sizes the workspaces, builds the twiddles
+            run()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            res = run()
+            torch.cuda.synchronize()
+            dt_ = (time.perf_counter() - t0) / K
+            assert len(res) == K and len({r for r, _ in res}) == K
+            for r, p in res:
+                assert p.commitment == r and frieda_amd.verify(p, seed), "a timed proof does not verify"
+            pipe.close()
+            return dt_, [r for r, _ in res]
+
+        dt, roots = stream(BSZ)
         out["measured_loop"] = f"{BSZ} blobs per call, {D} calls in flight"
         out["verified_proofs"] = K
-        root0 = res[0][0]
-        del res
-        pipe.close()
+        root0 = roots[0]
+        big = min(32, BSZ << max(0, 24 - n), K // D)
+        if big > BSZ:  # smaller blobs want more of them per call: the same bytes in flight as 4 blobs of the 2^24 domain (at most 32)
+            dtb, roots_b = stream(big)
+            assert roots_b == roots
+            out["larger_batch"] = {"measured_loop": f"{big} blobs per call, {D} calls in flight", "ms_per_blob": 1e3 * dtb, "value": elems / dtb,
+                                   "frac_of_hbm_peak_wall": path_bytes / dtb / 1e9 / HBM_PEAK_GBS, "verified_proofs": K}
 
         def lone():
             return ctx.commit_and_generate_proof_device(blobs[0].data_ptr(), blob_len, seed, cfg)
