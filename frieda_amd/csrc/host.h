@@ -199,6 +199,19 @@ struct frieda_ctx {
     frieda::Ctx c;
     std::shared_ptr<ProofPool> pool = std::make_shared<ProofPool>();
 };
+
+// the extern "C" entry points' exception fence: no exception crosses the ABI
+#define FR_GUARD_BEGIN try {
+#define FR_GUARD_END(ctxptr)                                          \
+    }                                                                 \
+    catch (const std::bad_alloc&) {                                   \
+        if (ctxptr) (ctxptr)->c.err = "host allocation failed";       \
+        return FRIEDA_ERR_NOMEM;                                      \
+    }                                                                 \
+    catch (const std::exception& e) {                                 \
+        if (ctxptr) (ctxptr)->c.err = e.what();                       \
+        return FRIEDA_ERR_INVARIANT;                                  \
+    }
 struct frieda_proof {
     frieda::ProofData p;
     std::shared_ptr<ProofPool> home;  // set while the object is out with the caller; null inside the pool and for clones / parsed proofs
