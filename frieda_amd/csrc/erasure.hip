@@ -48,6 +48,118 @@ __device__ __forceinline__ CPoint domain_point(const ErasureDomain& g, uint32_t 
     return p;
 }
 
+// ---- the caller's cell list -> de-duplicated position lists, on the device ----
+// The caller names its samples by cell index (host array, any order, repeats allowed: the first occurrence of a cell counts).  Building
+// the de-duplicated (position, source offset) lists on the host cost more than the locator for 2^20 single points (a random-access
+// bitmap and 8 MB of fresh vectors per call), so: owner[cell] = atomicMin(index in the list); an entry is kept iff it owns its cell;
+// kept entries are ranked in list order (stable: the first K + 2 points of the LIST build the locator, whatever the launch geometry) by
+// a two-level count — 2048 entries per workgroup, ballots inside — and expanded to one (pos, src) pair per point.
+constexpr uint32_t DED_THREADS = 256, DED_PER = 8, DED_CHUNK = DED_THREADS * DED_PER;
+
+__global__ void dedup_claim_kernel(const uint32_t* __restrict__ idx, uint32_t n_cells, uint32_t domain_cells, uint32_t* __restrict__ owner,
+                                   uint32_t* __restrict__ state) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_cells) return;
+    const uint32_t ci = idx[r];
+    if (ci >= domain_cells) {
+        atomicOr(&state[1], 1u);  // an index outside the domain: reported by the host
+        return;
+    }
+    atomicMin(&owner[ci], r);
+}
+
+__device__ __forceinline__ bool dedup_kept(const uint32_t* __restrict__ idx, const uint32_t* __restrict__ owner, uint32_t r, uint32_t n_cells,
+                                           uint32_t domain_cells) {
+    if (r >= n_cells) return false;
+    const uint32_t ci = idx[r];
+    return ci < domain_cells && owner[ci] == r;
+}
+
+__global__ __launch_bounds__(DED_THREADS) void dedup_count_kernel(const uint32_t* __restrict__ idx, const uint32_t* __restrict__ owner, uint32_t n_cells,
+                                                                  uint32_t domain_cells, uint32_t* __restrict__ chunk_sum) {
+    __shared__ uint32_t wave_sum[DED_THREADS / 64];
+    const uint32_t base = blockIdx.x * DED_CHUNK;
+    uint32_t mine = 0;
+#pragma unroll
+    for (uint32_t j = 0; j < DED_PER; j++) mine += dedup_kept(idx, owner, base + j * DED_THREADS + threadIdx.x, n_cells, domain_cells) ? 1u : 0u;
+    for (int off = 32; off > 0; off >>= 1) mine += __shfl_down(mine, off, 64);
+    if ((threadIdx.x & 63) == 0) wave_sum[threadIdx.x >> 6] = mine;
+    __syncthreads();
+    if (threadIdx.x == 0) chunk_sum[blockIdx.x] = wave_sum[0] + wave_sum[1] + wave_sum[2] + wave_sum[3];
+}
+
+// exclusive prefix of the chunk sums (one workgroup, 1024 sums per round with a running carry); state[0] = the total
+__global__ __launch_bounds__(1024) void dedup_offsets_kernel(const uint32_t* __restrict__ chunk_sum, uint32_t n_chunks, uint32_t* __restrict__ chunk_off,
+                                                             uint32_t* __restrict__ state) {
+    __shared__ uint32_t buf[1024];
+    __shared__ uint32_t carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (uint32_t at = 0; at < n_chunks; at += 1024) {
+        const uint32_t i = at + threadIdx.x;
+        const uint32_t v = i < n_chunks ? chunk_sum[i] : 0u;
+        buf[threadIdx.x] = v;
+        __syncthreads();
+        for (uint32_t d = 1; d < 1024; d <<= 1) {  // Hillis-Steele inclusive scan
+            const uint32_t add = threadIdx.x >= d ? buf[threadIdx.x - d] : 0u;
+            __syncthreads();
+            buf[threadIdx.x] += add;
+            __syncthreads();
+        }
+        if (i < n_chunks) chunk_off[i] = carry + buf[threadIdx.x] - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry += buf[1023];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) state[0] = carry;
+}
+
+// kept entry of rank k: first_cell[k] = its cell, first_row[k] = its index in the caller's list
+__global__ __launch_bounds__(DED_THREADS) void dedup_emit_kernel(const uint32_t* __restrict__ idx, const uint32_t* __restrict__ owner, uint32_t n_cells,
+                                                                 uint32_t domain_cells, const uint32_t* __restrict__ chunk_off,
+                                                                 uint32_t* __restrict__ first_cell, uint32_t* __restrict__ first_row) {
+    __shared__ uint32_t wave_cnt[DED_THREADS / 64];
+    const uint32_t base = blockIdx.x * DED_CHUNK;
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t run = chunk_off[blockIdx.x];
+    for (uint32_t j = 0; j < DED_PER; j++) {
+        const uint32_t r = base + j * DED_THREADS + threadIdx.x;
+        const bool keep = dedup_kept(idx, owner, r, n_cells, domain_cells);
+        const unsigned long long bal = __ballot(keep);
+        const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+        if (lane == 0) wave_cnt[wave] = (uint32_t)__popcll(bal);
+        __syncthreads();
+        uint32_t before = 0, all = 0;
+#pragma unroll
+        for (uint32_t w = 0; w < DED_THREADS / 64; w++) {
+            before += w < wave ? wave_cnt[w] : 0u;
+            all += wave_cnt[w];
+        }
+        if (keep) {
+            const uint32_t k = run + before + below;
+            first_cell[k] = idx[r];
+            first_row[k] = r;
+        }
+        run += all;
+        __syncthreads();
+    }
+}
+
+// point e of the kept cells: pos[e] = its position in the codeword, src[e] = its word offset in the caller's sample buffer
+__global__ void dedup_expand_kernel(const uint32_t* __restrict__ first_cell, const uint32_t* __restrict__ first_row, const uint32_t* __restrict__ state,
+                                    uint32_t ncols, uint32_t log_cell, uint32_t* __restrict__ pos, uint32_t* __restrict__ src) {
+    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= ((size_t)state[0] << log_cell)) return;
+    const uint32_t k = (uint32_t)(e >> log_cell), t = (uint32_t)e & ((1u << log_cell) - 1u);
+    pos[e] = (first_cell[k] << log_cell) + t;
+    src[e] = ((first_row[k] * ncols) << log_cell) + t;
+}
+
+__global__ void erasure_cell_firsts_kernel(const uint32_t* __restrict__ pos, uint32_t n_cells, uint32_t log_cell, uint32_t* __restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_cells) out[i] = pos[(size_t)i << log_cell];
+}
+
 __global__ void erasure_points_kernel(ErasureDomain g, const uint32_t* __restrict__ pos, uint32_t count, uint32_t* __restrict__ px,
                                       uint32_t* __restrict__ py) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -206,10 +318,11 @@ __global__ void erasure_divide_kernel(const uint32_t* __restrict__ ev, size_t ev
 
 // ---- single points, large K: Z_S by a product tree instead of line by line ----
 // Leaves of the tree: the product of 32 consecutive lines (degree 32) as its values on the canonic domain of 128 points (px, py):
-// out[node][t], 128 threads per node.  Lines beyond n_lines count as the constant 1.
+// out[node][t], 128 threads per node, `nodes` leaves.  The few lines beyond 32 * nodes (Z_S has K / 2 + 1 lines, the tree K / 2) go into
+// leaf 0: a node's domain has four points per line, so every node above leaf 0 has room for the extra degree.
 __global__ __launch_bounds__(128) void erasure_lines32_kernel(const uint32_t* __restrict__ px, const uint32_t* __restrict__ py, const uint32_t* __restrict__ la,
                                                               const uint32_t* __restrict__ lb, const uint32_t* __restrict__ lc, uint32_t n_lines,
-                                                              uint32_t* __restrict__ out) {
+                                                              uint32_t nodes, uint32_t* __restrict__ out) {
     __shared__ uint32_t sa[32], sb[32], sc[32];
     const uint32_t node = blockIdx.x, t = threadIdx.x;
     const uint32_t first = 32u * node;
@@ -224,6 +337,8 @@ __global__ __launch_bounds__(128) void erasure_lines32_kernel(const uint32_t* __
     uint32_t z = 1;
 #pragma unroll 8
     for (int i = 0; i < 32; i++) z = m31_mul(z, m31_reduce64((uint64_t)sa[i] * x + (uint64_t)sb[i] * y + sc[i]));
+    if (node == 0)
+        for (uint32_t i = 32u * nodes; i < n_lines; i++) z = m31_mul(z, m31_reduce64((uint64_t)la[i] * x + (uint64_t)lb[i] * y + lc[i]));
     out[(size_t)node * 128 + t] = z;
 }
 
@@ -266,15 +381,6 @@ __global__ void erasure_ze_kernel(ErasureDomain g1, const uint32_t* __restrict__
     }
 }
 
-// zs[t] *= (a x + b y + c)(P_t): one more line into a locator already evaluated on the first `count` points of g1
-__global__ void erasure_mulline_kernel(ErasureDomain g1, const uint32_t* __restrict__ la, const uint32_t* __restrict__ lb, const uint32_t* __restrict__ lc,
-                                       uint32_t count, uint32_t* __restrict__ zs) {
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= count) return;
-    const CPoint p = domain_point(g1, t);
-    zs[t] = m31_mul(zs[t], m31_reduce64((uint64_t)la[0] * p.x + (uint64_t)lb[0] * p.y + lc[0]));
-}
-
 __global__ void erasure_gather_kernel(const uint32_t* __restrict__ src, const uint32_t* __restrict__ pos, uint32_t count, uint32_t* __restrict__ out) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t < count) out[t] = src[pos[t]];
@@ -301,6 +407,30 @@ size_t erasure_zpart_chunks(uint32_t count, uint32_t n_lines) {
     if (want > 64) want = 64;
     const size_t max_by_lines = (n_lines + Z_TILE - 1) / Z_TILE;
     return want < max_by_lines ? want : max_by_lines;
+}
+
+size_t erasure_sample_lists_chunks(uint32_t n_cells) { return ((size_t)n_cells + DED_CHUNK - 1) / DED_CHUNK; }
+
+void erasure_sample_lists(const Launch& L_, const uint32_t* d_idx, uint32_t n_cells, uint32_t domain_cells, uint32_t ncols, uint32_t log_cell,
+                          uint32_t* d_owner, uint32_t* d_chunk_sum, uint32_t* d_chunk_off, uint32_t* d_first_cell, uint32_t* d_first_row,
+                          uint32_t* d_state, uint32_t* d_pos, uint32_t* d_src) {
+    if (!n_cells) return;
+    Scope scope(L_, "erasure_sample_lists", 20.0 * n_cells + 8.0 * ((double)n_cells * (double)((size_t)1 << log_cell)));
+    hipStream_t s = L_.stream;
+    const unsigned chunks = (unsigned)erasure_sample_lists_chunks(n_cells);
+    (void)hipMemsetAsync(d_owner, 0xFF, 4 * (size_t)domain_cells, s);
+    (void)hipMemsetAsync(d_state, 0, 8, s);
+    dedup_claim_kernel<<<(n_cells + 255) / 256, 256, 0, s>>>(d_idx, n_cells, domain_cells, d_owner, d_state);
+    dedup_count_kernel<<<chunks, DED_THREADS, 0, s>>>(d_idx, d_owner, n_cells, domain_cells, d_chunk_sum);
+    dedup_offsets_kernel<<<1, 1024, 0, s>>>(d_chunk_sum, chunks, d_chunk_off, d_state);
+    dedup_emit_kernel<<<chunks, DED_THREADS, 0, s>>>(d_idx, d_owner, n_cells, domain_cells, d_chunk_off, d_first_cell, d_first_row);
+    const size_t pts_cap = (size_t)n_cells << log_cell;
+    dedup_expand_kernel<<<(unsigned)((pts_cap + 255) / 256), 256, 0, s>>>(d_first_cell, d_first_row, d_state, ncols, log_cell, d_pos, d_src);
+}
+
+void erasure_cell_firsts(const Launch& L_, const uint32_t* d_pos, uint32_t n_cells, uint32_t log_cell, uint32_t* d_out) {
+    if (!n_cells) return;
+    erasure_cell_firsts_kernel<<<(n_cells + 255) / 256, 256, 0, L_.stream>>>(d_pos, n_cells, log_cell, d_out);
 }
 
 void erasure_points(const Launch& L_, const ErasureDomain& g, const uint32_t* d_pos, uint32_t count, uint32_t* d_px, uint32_t* d_py) {
@@ -359,11 +489,10 @@ void erasure_known_weights_cells(const Launch& L_, const uint32_t* d_px, uint32_
 }
 
 void erasure_lines32(const Launch& L_, const uint32_t* d_px128, const uint32_t* d_py128, const uint32_t* d_la, const uint32_t* d_lb, const uint32_t* d_lc,
-                     uint32_t n_lines, uint32_t* d_out) {
-    const uint32_t nodes = (n_lines + 31) / 32;
+                     uint32_t n_lines, uint32_t nodes, uint32_t* d_out) {
     if (!nodes) return;
     Scope scope(L_, "erasure_lines32", 12.0 * n_lines + 512.0 * nodes);
-    erasure_lines32_kernel<<<nodes, 128, 0, L_.stream>>>(d_px128, d_py128, d_la, d_lb, d_lc, n_lines, d_out);
+    erasure_lines32_kernel<<<nodes, 128, 0, L_.stream>>>(d_px128, d_py128, d_la, d_lb, d_lc, n_lines, nodes, d_out);
 }
 
 void erasure_pairmul(const Launch& L_, const uint32_t* d_ext, uint32_t n_nodes, uint32_t size, uint32_t* d_out) {
@@ -376,12 +505,6 @@ void erasure_ze(const Launch& L_, const ErasureDomain& g1, const uint32_t* d_zs,
     if (!count) return;
     Scope scope(L_, "erasure_ze", 8.0 * count);
     erasure_ze_kernel<<<(count + 2047) / 2048, 256, 0, L_.stream>>>(g1, d_zs, count, n, d_ze);
-}
-
-void erasure_mulline(const Launch& L_, const ErasureDomain& g1, const uint32_t* d_la, const uint32_t* d_lb, const uint32_t* d_lc, uint32_t count,
-                     uint32_t* d_zs) {
-    if (!count) return;
-    erasure_mulline_kernel<<<(count + 255) / 256, 256, 0, L_.stream>>>(g1, d_la, d_lb, d_lc, count, d_zs);
 }
 
 void erasure_gather(const Launch& L_, const uint32_t* d_src, const uint32_t* d_pos, uint32_t count, uint32_t* d_out) {

@@ -138,16 +138,24 @@ void erasure_cellconst(const Launch& L_, const ErasureDomain& g, const uint32_t*
 void erasure_zeval_cells(const Launch& L_, const uint32_t* d_px, uint32_t count, uint32_t m, const uint32_t* d_kc, uint32_t n_cells, bool own,
                          uint32_t* d_zpart, uint32_t* d_z);
 void erasure_known_weights_cells(const Launch& L_, const uint32_t* d_px, uint32_t count, uint32_t n, uint32_t m, uint32_t* d_z);
+// The caller's cell list (d_idx[n_cells], repeats allowed, first occurrence counts; domain_cells = 2^(n - log_cell)) -> the de-duplicated
+// lists in list order: d_pos[e] = position of point e in the codeword, d_src[e] = its word offset in the sample buffer
+// [n_cells][ncols][2^log_cell]; d_state[0] = number of kept cells, d_state[1] != 0 iff an index was out of range.  Scratch: d_owner
+// [domain_cells], d_chunk_sum / d_chunk_off [erasure_sample_lists_chunks(n_cells)], d_first_cell / d_first_row [n_cells]; d_pos / d_src
+// [n_cells << log_cell].  erasure_cell_firsts: d_out[i] = d_pos[i << log_cell].
+size_t erasure_sample_lists_chunks(uint32_t n_cells);
+void erasure_sample_lists(const Launch& L_, const uint32_t* d_idx, uint32_t n_cells, uint32_t domain_cells, uint32_t ncols, uint32_t log_cell,
+                          uint32_t* d_owner, uint32_t* d_chunk_sum, uint32_t* d_chunk_off, uint32_t* d_first_cell, uint32_t* d_first_row,
+                          uint32_t* d_state, uint32_t* d_pos, uint32_t* d_src);
+void erasure_cell_firsts(const Launch& L_, const uint32_t* d_pos, uint32_t n_cells, uint32_t log_cell, uint32_t* d_out);
 // single points, large polynomials: Z_S through a product tree.  Leaves: products of 32 consecutive lines as values on the canonic domain of
-// 128 points (d_out[node][128]); erasure_pairmul multiplies neighbouring nodes' values (d_ext[n_nodes][size] -> d_out[ceil(n_nodes / 2)][size]);
-// erasure_ze: d_ze[t] = V_D(P_t) / d_zs[t] on the first `count` points of the next canonic domain; erasure_gather: d_out[t] = d_src[d_pos[t]]
+// 128 points (d_out[node][128], `nodes` leaves; the lines beyond 32 * nodes — at most a few — go into leaf 0); erasure_pairmul multiplies
+// neighbouring nodes' values (d_ext[n_nodes][size] -> d_out[ceil(n_nodes / 2)][size]); erasure_ze: d_ze[t] = V_D(P_t) / d_zs[t] on the
+// first `count` <= 2^n points of the next canonic domain; erasure_gather: d_out[t] = d_src[d_pos[t]]
 void erasure_lines32(const Launch& L_, const uint32_t* d_px128, const uint32_t* d_py128, const uint32_t* d_la, const uint32_t* d_lb, const uint32_t* d_lc,
-                     uint32_t n_lines, uint32_t* d_out);
+                     uint32_t n_lines, uint32_t nodes, uint32_t* d_out);
 void erasure_pairmul(const Launch& L_, const uint32_t* d_ext, uint32_t n_nodes, uint32_t size, uint32_t* d_out);
 void erasure_ze(const Launch& L_, const ErasureDomain& g1, const uint32_t* d_zs, uint32_t count, uint32_t n, uint32_t* d_ze);
-// d_zs[t] *= line(P_t) for the first `count` points of g1 (d_la / d_lb / d_lc point at that line's coefficients)
-void erasure_mulline(const Launch& L_, const ErasureDomain& g1, const uint32_t* d_la, const uint32_t* d_lb, const uint32_t* d_lc, uint32_t count,
-                     uint32_t* d_zs);
 void erasure_gather(const Launch& L_, const uint32_t* d_src, const uint32_t* d_pos, uint32_t count, uint32_t* d_out);
 // d_w[c][d_pos[t]] = d_z[t] * d_cells[d_src[t] + c * 2^log_cell] (d_w zeroed by the caller)
 void erasure_scatter(const Launch& L_, const uint32_t* d_cells, const uint32_t* d_src, const uint32_t* d_pos, const uint32_t* d_z, uint32_t count,

@@ -226,26 +226,14 @@ int interpolate_points(frieda_ctx* ctx, const uint32_t* d_cells, const uint32_t*
     FR_NO_JOB(&c);
     if (log_cell > log_domain || log_coef > log_domain || log_coef < 1 || log_domain < 2 || log_domain + 1 > FRIEDA_MAX_LOG_DOMAIN)
         return c.fail(FRIEDA_ERR_ARG, "points: need 1 <= log_coef <= log_domain <= FRIEDA_MAX_LOG_DOMAIN - 1 and log_cell <= log_domain");
-    const size_t N = (size_t)1 << log_domain, K = (size_t)1 << log_coef, M = (size_t)1 << log_cell;
+    const size_t N = (size_t)1 << log_domain, K = (size_t)1 << log_coef;
     const uint32_t n = log_domain;
-    // distinct sampled positions (first occurrence of every cell wins), and where their values sit in the caller's buffer
-    std::vector<uint64_t> known((((size_t)1 << (log_domain - log_cell)) + 63) / 64, 0);  // one bit per cell of the domain
-    std::vector<uint32_t> pos((size_t)n_cells * M), src((size_t)n_cells * M);
-    size_t n_pts = 0;
-    for (uint32_t r = 0; r < n_cells; r++) {
-        const uint32_t ci = cell_index[r];
-        if ((uint64_t)ci >= ((uint64_t)1 << (log_domain - log_cell))) return c.fail(FRIEDA_ERR_ARG, "points: cell index out of range");
-        if (known[ci >> 6] >> (ci & 63) & 1) continue;
-        known[ci >> 6] |= (uint64_t)1 << (ci & 63);
-        if ((((uint64_t)r * ncols) << log_cell) + (((uint64_t)ncols) << log_cell) > 0xFFFFFFFFull) return c.fail(FRIEDA_ERR_ARG, "points: sample buffer beyond 2^32 words");
-        const size_t p0 = (size_t)ci << log_cell, s0 = ((size_t)r * ncols) << log_cell;
-        for (size_t t = 0; t < M; t++) {
-            pos[n_pts] = (uint32_t)(p0 + t);
-            src[n_pts++] = (uint32_t)(s0 + t);
-        }
-    }
-    const uint32_t s_all = (uint32_t)n_pts;
-    if (s_all < K + 2)
+    // The distinct sampled positions (first occurrence of every cell wins) and where their values sit in the caller's buffer are worked out
+    // on the device (erasure_sample_lists): only their number comes back, for the argument checks below.
+    const uint32_t domain_cells = (uint32_t)(N >> log_cell);
+    if ((((uint64_t)n_cells * ncols) << log_cell) > 0x100000000ull) return c.fail(FRIEDA_ERR_ARG, "points: sample buffer beyond 2^32 words");
+    const size_t s_cap = (size_t)n_cells << log_cell;  // points offered, repeats included
+    if (s_cap < K + 2)
         return c.fail(FRIEDA_ERR_ARG, "points: need at least 2^log_coef + 2 distinct points (the locator polynomial needs two spare samples)");
     // S, the points the locator is built from (all offered points serve the check): the first K + 2 single points, Z_S a product of
     // lines through pairs — or, for samples in cells of M >= 2 entries, the first K / M + 1 whole cells, Z_S a product over cells
@@ -262,12 +250,7 @@ int interpolate_points(frieda_ctx* ctx, const uint32_t* d_cells, const uint32_t*
     const uint32_t n_use_cells = by_cells ? (uint32_t)(K >> log_cell) + 1 : 0;
     const uint32_t s_use = by_cells ? (uint32_t)((size_t)n_use_cells << log_cell) : (uint32_t)K + 2;
     const uint32_t n_lines = by_cells ? n_use_cells : s_use / 2;  // factors of Z_S
-    if (s_use > s_all) return c.fail(FRIEDA_ERR_ARG, "points: cells of 2^log_cell entries: need 2^(log_coef - log_cell) + 1 distinct cells");
-    std::vector<uint32_t> cell_pos;
-    if (by_cells) {
-        cell_pos.resize(n_use_cells);
-        for (uint32_t i = 0; i < n_use_cells; i++) cell_pos[i] = pos[(size_t)i << log_cell];
-    }
+    if (s_use > s_cap) return c.fail(FRIEDA_ERR_ARG, "points: cells of 2^log_cell entries: need 2^(log_coef - log_cell) + 1 distinct cells");
 
     // domains: D (log n) and the next canonic domain D' (log n + 1)
     auto make_domain = [](uint32_t lg) {
@@ -290,7 +273,10 @@ int interpolate_points(frieda_ctx* ctx, const uint32_t* d_cells, const uint32_t*
     const size_t chunks = 64;  // upper bound of erasure_zpart_chunks
     ArenaPlan plan;
     plan.off = arena_off;
-    const size_t o_pos = plan.take(4 * (size_t)s_all), o_src = plan.take(4 * (size_t)s_all);
+    const size_t o_pos = plan.take(4 * s_cap), o_src = plan.take(4 * s_cap);
+    const size_t ded_chunks = k::erasure_sample_lists_chunks(n_cells);
+    const size_t o_idx = plan.take(4 * (size_t)n_cells), o_fc = plan.take(4 * (size_t)n_cells), o_fr = plan.take(4 * (size_t)n_cells);
+    const size_t o_own = plan.take(4 * (size_t)domain_cells), o_csum = plan.take(4 * ded_chunks), o_coff = plan.take(4 * ded_chunks), o_state = plan.take(8);
     const size_t o_la = plan.take(4 * (size_t)n_lines), o_lb = plan.take(4 * (size_t)n_lines), o_lc = plan.take(4 * (size_t)n_lines);
     const size_t s_max = std::max<size_t>(s_use, K);
     const size_t o_px = plan.take(4 * s_max), o_py = plan.take(4 * s_max);
@@ -312,15 +298,25 @@ int interpolate_points(frieda_ctx* ctx, const uint32_t* d_cells, const uint32_t*
     auto W32 = [&](size_t off) { return reinterpret_cast<uint32_t*>(A + off); };
     hipStream_t s = c.stream;
     const k::Launch LN = c.launch();
-    FR_HIP(&c, hipMemcpyAsync(A + o_pos, pos.data(), 4 * (size_t)s_all, hipMemcpyHostToDevice, s));
-    FR_HIP(&c, hipMemcpyAsync(A + o_src, src.data(), 4 * (size_t)s_all, hipMemcpyHostToDevice, s));
+    FR_HIP(&c, hipMemcpyAsync(A + o_idx, cell_index, 4 * (size_t)n_cells, hipMemcpyHostToDevice, s));
+    k::erasure_sample_lists(LN, W32(o_idx), n_cells, domain_cells, ncols, log_cell, W32(o_own), W32(o_csum), W32(o_coff), W32(o_fc), W32(o_fr),
+                            W32(o_state), W32(o_pos), W32(o_src));
+    uint32_t state[2] = {0, 0};
+    FR_HIP(&c, hipMemcpyAsync(state, A + o_state, 8, hipMemcpyDeviceToHost, s));
     FR_HIP(&c, hipMemsetAsync(A + o_bad, 0, 4, s));
+    FR_HIP(&c, hipStreamSynchronize(s));  // (cell_index is host memory of this call; the counts decide whether there is anything to do)
+    FR_HIP(&c, hipGetLastError());
+    if (state[1]) return c.fail(FRIEDA_ERR_ARG, "points: cell index out of range");
+    const uint32_t s_all = (uint32_t)((size_t)state[0] << log_cell);  // distinct points offered
+    if (s_all < K + 2)
+        return c.fail(FRIEDA_ERR_ARG, "points: need at least 2^log_coef + 2 distinct points (the locator polynomial needs two spare samples)");
+    if (s_use > s_all) return c.fail(FRIEDA_ERR_ARG, "points: cells of 2^log_cell entries: need 2^(log_coef - log_cell) + 1 distinct cells");
     const size_t w_stride = al(4 * N) / 4, ev_stride = al(8 * N) / 4, blk_stride = al(4 * K) / 4;
     uint32_t* coef_out = d_coef ? d_coef : reinterpret_cast<uint32_t*>(A);
     // 1. the locator on the points it is built from: ratio of tangent derivatives
     k::erasure_points(LN, g0, W32(o_pos), s_use, W32(o_px), W32(o_py));
     if (by_cells) {
-        FR_HIP(&c, hipMemcpyAsync(A + o_lb, cell_pos.data(), 4 * (size_t)n_use_cells, hipMemcpyHostToDevice, s));  // (o_lb: free in this form)
+        k::erasure_cell_firsts(LN, W32(o_pos), n_use_cells, log_cell, W32(o_lb));  // (o_lb: free in this form)
         k::erasure_cellconst(LN, g0, W32(o_lb), n_use_cells, log_cell, W32(o_la));
         k::erasure_zeval_cells(LN, W32(o_px), s_use, log_cell, W32(o_la), n_use_cells, true, W32(o_zp), W32(o_z));
         k::erasure_known_weights_cells(LN, W32(o_px), s_use, n, log_cell, W32(o_z));
@@ -329,16 +325,16 @@ int interpolate_points(frieda_ctx* ctx, const uint32_t* d_cells, const uint32_t*
         k::erasure_zeval(LN, W32(o_px), W32(o_py), s_use, W32(o_la), W32(o_lb), W32(o_lc), n_lines, true, W32(o_zp), W32(o_z));
         k::erasure_known_weights(LN, W32(o_px), W32(o_py), s_use, n, W32(o_z));
     } else {
-        // Z_S = (product of the first K / 2 lines, by a tree) * (the last line).  A node over 2^j * 32 lines (degree 2^j * 32) is held as its
+        // Z_S by a tree over leaves of 32 lines (the one line beyond K / 2 rides in leaf 0).  A node over 2^j * 32 lines (degree 2^j * 32) is held as its
         // values on the canonic domain of 2^(j + 7) points; two children go to the parent's domain through their coefficients (the canonic
-        // domains of different sizes share no points) and multiply pointwise there.  The root (degree K / 2, 2 K values) -> coefficients ->
+        // domains of different sizes share no points) and multiply pointwise there.  The root (degree K / 2 + 1, 2 K values) -> coefficients ->
         // all of D' (o_ev, free until step 3).  Then Z_E = V_D / Z_S: its values on the first N points of D' -> its N coefficients -> its
         // values on D, of which the S entries are the weights of step 2 (no derivative needed on this route).
         k::erasure_lines(LN, g0, W32(o_pos), n_lines, W32(o_la), W32(o_lb), W32(o_lc));
         const k::ErasureDomain g7 = make_domain(7);
         k::erasure_points(LN, g7, nullptr, 128, W32(o_px), W32(o_py));
         uint32_t nodes = (uint32_t)(K / 64), d = 7;  // K / 2 lines in leaves of 32
-        k::erasure_lines32(LN, W32(o_px), W32(o_py), W32(o_la), W32(o_lb), W32(o_lc), (uint32_t)(K / 2), W32(o_ta));
+        k::erasure_lines32(LN, W32(o_px), W32(o_py), W32(o_la), W32(o_lb), W32(o_lc), n_lines, nodes, W32(o_ta));
         const uint32_t col_chunk = 32768;
         while (nodes > 1) {
             TwiddleSet tsd, tse;
@@ -362,7 +358,6 @@ int interpolate_points(frieda_ctx* ctx, const uint32_t* d_cells, const uint32_t*
         if (rc) return rc;
         k::circle_interpolate_block(LN, W32(o_ta), (size_t)1 << d, 1, d, d, 0, tsr.d_itw, tsr.ds, W32(o_tb), (size_t)1 << d);
         k::circle_evaluate(LN, W32(o_tb), (size_t)1 << d, 1, d, n + 1, ts1.d_tw, ts1.ds, W32(o_ev), ev_stride);
-        k::erasure_mulline(LN, g1, W32(o_la) + (n_lines - 1), W32(o_lb) + (n_lines - 1), W32(o_lc) + (n_lines - 1), (uint32_t)(2 * N), W32(o_ev));
         FR_HIP(&c, hipMemcpyAsync(A + o_tc, A + o_ev, 4 * K, hipMemcpyDeviceToDevice, s));  // Z_S on the block step 3 divides on
         k::erasure_ze(LN, g1, W32(o_ev), (uint32_t)N, n, W32(o_q));
         k::circle_interpolate_block(LN, W32(o_q), w_stride, 1, n, n + 1, 0, ts1.d_itw, ts1.ds, W32(o_w), w_stride);
@@ -390,7 +385,7 @@ int interpolate_points(frieda_ctx* ctx, const uint32_t* d_cells, const uint32_t*
     k::erasure_check(LN, d_cells, W32(o_src), W32(o_pos), s_all, ncols, log_cell, W32(o_w), w_stride, W32(o_bad));
     uint32_t bad = 0;
     FR_HIP(&c, hipMemcpyAsync(&bad, A + o_bad, 4, hipMemcpyDeviceToHost, s));
-    FR_HIP(&c, hipStreamSynchronize(s));  // pos / src are host memory of this call
+    FR_HIP(&c, hipStreamSynchronize(s));
     FR_HIP(&c, hipGetLastError());
     if (bad)
         return c.fail(FRIEDA_ERR_ARG, "points: the samples are not values of one polynomial of 2^log_coef coefficients (" + std::to_string(bad) +
