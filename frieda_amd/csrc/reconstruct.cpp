@@ -239,14 +239,14 @@ int interpolate_points(frieda_ctx* ctx, const uint32_t* d_cells, const uint32_t*
     // lines through pairs — or, for samples in cells of M >= 2 entries, the first K / M + 1 whole cells, Z_S a product over cells
     // Single points of a large polynomial take Z_S through a product tree (O(K log^2 K)) instead of K / 2 lines at each of K points
     // (O(K^2)); many small cells do too, as the single points they consist of (the per-cell form costs K * K / M factor evaluations:
-    // 38 ms against 9 ms for 2^16 cells of 16 on a 2^24 domain).  FRIEDA_ERASURE_TREE_MIN_LOG: smallest log_coef that takes the tree
+    // 38 ms against 4 ms for 2^16 cells of 16 on a 2^24 domain, 3.1 against 1.6 ms for 2^14 of them at 2^22; cells of 256 are level there).  FRIEDA_ERASURE_TREE_MIN_LOG: smallest log_coef that takes the tree
     // (default 15: 0.67 against 0.97 ms there; the parity tests lower it; 32 = never; read per call because the tests run both routes in one process).
     const uint32_t tree_min_log = [] {
         const char* e = getenv("FRIEDA_ERASURE_TREE_MIN_LOG");
         const int v = e ? atoi(e) : 15;
         return (uint32_t)(v < 6 ? 6 : v);
     }();
-    const bool by_cells = log_cell >= 1 && !(log_coef >= tree_min_log && 2 * log_coef >= 35 + log_cell);
+    const bool by_cells = log_cell >= 1 && !(log_coef >= tree_min_log && 2 * log_coef >= 32 + log_cell);
     const uint32_t n_use_cells = by_cells ? (uint32_t)(K >> log_cell) + 1 : 0;
     const uint32_t s_use = by_cells ? (uint32_t)((size_t)n_use_cells << log_cell) : (uint32_t)K + 2;
     const uint32_t n_lines = by_cells ? n_use_cells : s_use / 2;  // factors of Z_S
