@@ -11,6 +11,8 @@
 // HBM-bound: 3.75 B read + 4 B written per felt.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "kernels.h"
 
 namespace frieda {
@@ -40,40 +42,48 @@ __device__ __forceinline__ uint4 extract4(const uint32_t (&w)[5]) {
     return make_uint4(f[0], f[1], f[2], f[3]);
 }
 
+// T tiles of 256 quads per workgroup: T * 240 16-byte loads in flight per workgroup before anything waits (one tile per workgroup left
+// the kernel at 0.9 TB/s: too few bytes in flight per CU for the memory latency)
+template <int T>
 __global__ __launch_bounds__(256) void unpack30_aligned_kernel(const uint8_t* __restrict__ in, size_t len,
                                                                uint32_t* __restrict__ out, size_t n_quads, size_t in_bstride,
                                                                size_t out_bstride) {
     in += blockIdx.y * in_bstride;  // blob of a batch
     out = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(out) + blockIdx.y * out_bstride);
-    // the workgroup's 256 quads cover bytes [3840 b, 3840 (b + 1)) = 960 aligned dwords: stage them through LDS with
-    // coalesced loads, then every thread funnel-shifts its own 15-byte window
-    __shared__ __attribute__((aligned(16))) uint32_t stage[964];
-    const size_t d_base = (size_t)blockIdx.x * 960;
-    if ((reinterpret_cast<uintptr_t>(in) & 15) == 0 && (d_base + 964) * 4 <= len) {
-        // interior workgroup: 240 16-byte loads (3840 = 16 * 240, so every workgroup's window starts 16-byte aligned) + 1 dword
-        if (threadIdx.x < 240)
-            reinterpret_cast<uint4*>(stage)[threadIdx.x] = reinterpret_cast<const uint4*>(in + 4 * d_base)[threadIdx.x];
-        else if (threadIdx.x < 244)
-            stage[960 + (threadIdx.x - 240)] = reinterpret_cast<const uint32_t*>(in)[d_base + 960 + (threadIdx.x - 240)];
+    // the workgroup's 256 T quads cover bytes [3840 T b, 3840 T (b + 1)) = 960 T aligned dwords: stage them through LDS with
+    // coalesced loads, then every thread funnel-shifts its own 15-byte windows
+    constexpr uint32_t DW = 960u * T;
+    __shared__ __attribute__((aligned(16))) uint32_t stage[DW + 4];
+    const size_t d_base = (size_t)blockIdx.x * DW;
+    if ((reinterpret_cast<uintptr_t>(in) & 15) == 0 && (d_base + DW + 4) * 4 <= len) {
+        // interior workgroup: 240 T 16-byte loads (3840 = 16 * 240, so every workgroup's window starts 16-byte aligned) + 1 dword
+        const uint4* src = reinterpret_cast<const uint4*>(in + 4 * d_base);
+#pragma unroll
+        for (uint32_t u = threadIdx.x; u < 240u * T; u += 256) reinterpret_cast<uint4*>(stage)[u] = src[u];
+        if (threadIdx.x < 4) stage[DW + threadIdx.x] = reinterpret_cast<const uint32_t*>(in)[d_base + DW + threadIdx.x];
     } else {
-        for (uint32_t i = threadIdx.x; i < 964; i += 256) stage[i] = load_dword_guarded(in, len, d_base + i);
+        for (uint32_t i = threadIdx.x; i < DW + 4; i += 256) stage[i] = load_dword_guarded(in, len, d_base + i);
     }
     __syncthreads();
-    size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (t >= n_quads) return;
-    const uint32_t byte0 = 15u * threadIdx.x;  // relative to the workgroup's first byte (a multiple of 4)
-    const uint32_t d0 = byte0 >> 2;
-    uint32_t w[5];
 #pragma unroll
-    for (int i = 0; i < 5; i++) w[i] = stage[d0 + i];
-    uint4 v;
-    switch (byte0 & 3) {
-        case 0: v = extract4<0>(w); break;
-        case 1: v = extract4<8>(w); break;
-        case 2: v = extract4<16>(w); break;
-        default: v = extract4<24>(w); break;
+    for (int i = 0; i < T; i++) {
+        const uint32_t local = (uint32_t)i * 256u + threadIdx.x;  // quad inside the workgroup's window
+        const size_t t = (size_t)blockIdx.x * (256u * T) + local;
+        if (t >= n_quads) return;
+        const uint32_t byte0 = 15u * local;  // relative to the workgroup's first byte (a multiple of 4)
+        const uint32_t d0 = byte0 >> 2;
+        uint32_t w[5];
+#pragma unroll
+        for (int j = 0; j < 5; j++) w[j] = stage[d0 + j];
+        uint4 v;
+        switch (byte0 & 3) {
+            case 0: v = extract4<0>(w); break;
+            case 1: v = extract4<8>(w); break;
+            case 2: v = extract4<16>(w); break;
+            default: v = extract4<24>(w); break;
+        }
+        reinterpret_cast<uint4*>(out)[t] = v;
     }
-    reinterpret_cast<uint4*>(out)[t] = v;
 }
 
 // any alignment: one felt per thread from byte loads
@@ -102,8 +112,21 @@ void unpack30(const Launch& L, const uint8_t* d_bytes, size_t len, uint32_t* d_o
                    (n_out % 4 == 0) && (src_bstride % 4 == 0) && (L.bstride % 16 == 0);
     if (aligned) {
         size_t quads = n_out / 4;
-        dim3 grid((unsigned)((quads + 255) / 256), L.batch);
-        unpack30_aligned_kernel<<<grid, 256, 0, s>>>(d_bytes, len, d_out, quads, src_bstride, L.bstride);
+        static const int tiles = [] {  // tuning knob: quads per workgroup / 256 (1, 2, 4 or 8)
+            const char* e = getenv("FRIEDA_UNPACK_TILES");
+            const int v = e ? atoi(e) : 4;
+            return (v == 1 || v == 2 || v == 4 || v == 8) ? v : 4;
+        }();
+        const int T = quads >= 8192 ? tiles : 1;  // small blobs: as many workgroups as there are
+        dim3 grid((unsigned)((quads + 256 * (size_t)T - 1) / (256 * (size_t)T)), L.batch);
+        if (T == 8)
+            unpack30_aligned_kernel<8><<<grid, 256, 0, s>>>(d_bytes, len, d_out, quads, src_bstride, L.bstride);
+        else if (T == 4)
+            unpack30_aligned_kernel<4><<<grid, 256, 0, s>>>(d_bytes, len, d_out, quads, src_bstride, L.bstride);
+        else if (T == 2)
+            unpack30_aligned_kernel<2><<<grid, 256, 0, s>>>(d_bytes, len, d_out, quads, src_bstride, L.bstride);
+        else
+            unpack30_aligned_kernel<1><<<grid, 256, 0, s>>>(d_bytes, len, d_out, quads, src_bstride, L.bstride);
     } else {
         dim3 grid((unsigned)((n_out + 255) / 256), L.batch);
         unpack30_bytes_kernel<<<grid, 256, 0, s>>>(d_bytes, len, d_out, n_out, src_bstride, L.bstride);
