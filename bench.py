@@ -314,7 +314,27 @@ def measure_config(frieda_amd, torch, device, n, workload, K, BSZ, D, cfg):
         dt = (time.perf_counter() - t0) / K
         out["measured_loop"] = "commit_device per blob, asynchronous, one context"
         root0 = bytes(roots_dev[:32].cpu().numpy())
-        assert len({bytes(roots_dev[32 * i : 32 * i + 32].cpu().numpy()) for i in range(K)}) == K
+        all_roots = bytes(roots_dev.cpu().numpy())
+        assert len({all_roots[32 * i : 32 * i + 32] for i in range(K)}) == K
+        # the same stream over two contexts (streams) taking turns: one blob's narrow tree tops run under the other's wide launches
+        ctx2 = frieda_amd.Context(device)
+
+        def run2():
+            for i in range(K):
+                (ctx if i % 2 == 0 else ctx2).commit_device(blobs[i].data_ptr(), blob_len, 4, roots_dev.data_ptr() + 32 * i)
+            ctx.synchronize()
+            ctx2.synchronize()
+
+        roots_dev.zero_()
+        run2()
+        run2()
+        t0 = time.perf_counter()
+        run2()
+        dt2 = (time.perf_counter() - t0) / K
+        assert bytes(roots_dev.cpu().numpy()) == all_roots
+        ctx2.close()
+        out["two_contexts"] = {"measured_loop": "commit_device per blob, asynchronous, two contexts taking turns", "ms_per_blob": 1e3 * dt2,
+                               "value": elems / dt2, "frac_of_hbm_peak_wall": path_bytes / dt2 / 1e9 / HBM_PEAK_GBS}
 
         def lone():
             ctx.commit_device(blobs[0].data_ptr(), blob_len, 4, roots_dev.data_ptr())

@@ -61,6 +61,7 @@ def test_bench_line_carries_the_other_baseline_configs():
     for r in rows.values():
         assert r["ms_per_blob"] > 0 and 0 < r["frac_of_hbm_peak_wall"] < 1 and r["lone_call"]["ms"] >= r["ms_per_blob"] * 0.5 and r["dominant_kernel"]["frac"] > 0
     assert rows[(20, "commit_and_generate_proof")]["verified_proofs"] == 64
+    assert 0 < rows[(22, "commit")]["two_contexts"]["ms_per_blob"]  # the commit stream over two contexts taking turns
     lb = rows[(20, "commit_and_generate_proof")]["larger_batch"]  # 32 blobs per call instead of 4: the same bytes in flight as at 2^24
     assert lb["measured_loop"].startswith("32 blobs") and 0 < lb["ms_per_blob"] and lb["verified_proofs"] == 64
     assert d["roofline"]["traffic"] is None or d["roofline"]["traffic"] > 0
