@@ -1,5 +1,5 @@
 """commit() on a stream of distinct device-resident 2^n-domain blobs: one context one blob per call (the by_config row), two contexts
-alternating, and commit_batch_device with 2 / 4 / 8 blobs per call on one and on two contexts.  ms per blob.  Measurement aid."""
+alternating, and commit_batch_device with 2 / 4 / 8 / 16 blobs per call on one context.  ms per blob.  Measurement aid."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, frieda_amd
