@@ -157,8 +157,7 @@ __global__ __launch_bounds__(INTT_THREADS) void intt_tile12_kernel(InttArgs a) {
     uint32_t twd[NS][15];
 #pragma unroll
     for (int s = 0; s < NS; s++) {
-        constexpr uint32_t lo0 = LOG_W;
-        const uint32_t lo = lo0 + 4u * (uint32_t)s;
+        const uint32_t lo = LOG_W + 4u * (uint32_t)s;
         const uint32_t base = ((g >> lo) << (lo + 4)) | (g & ((1u << lo) - 1));
         pbase[s] = ipad(base);
 #pragma unroll

@@ -236,11 +236,12 @@ int interpolate_points(frieda_ctx* ctx, const uint32_t* d_cells, const uint32_t*
     if (s_cap < K + 2)
         return c.fail(FRIEDA_ERR_ARG, "points: need at least 2^log_coef + 2 distinct points (the locator polynomial needs two spare samples)");
     // S, the points the locator is built from (all offered points serve the check): the first K + 2 single points, Z_S a product of
-    // lines through pairs — or, for samples in cells of M >= 2 entries, the first K / M + 1 whole cells, Z_S a product over cells
+    // lines through pairs — or, for samples in cells of M >= 2 entries, the first K / M + 1 whole cells, Z_S a product over cells.
     // Single points of a large polynomial take Z_S through a product tree (O(K log^2 K)) instead of K / 2 lines at each of K points
     // (O(K^2)); many small cells do too, as the single points they consist of (the per-cell form costs K * K / M factor evaluations:
-    // 38 ms against 4 ms for 2^16 cells of 16 on a 2^24 domain, 3.1 against 1.6 ms for 2^14 of them at 2^22; cells of 256 are level there).  FRIEDA_ERASURE_TREE_MIN_LOG: smallest log_coef that takes the tree
-    // (default 15: 0.67 against 0.97 ms there; the parity tests lower it; 32 = never; read per call because the tests run both routes in one process).
+    // 38 ms against 4 ms for 2^16 cells of 16 on a 2^24 domain, 3.1 against 1.6 ms for 2^14 of them at 2^22; cells of 256 are level
+    // there).  FRIEDA_ERASURE_TREE_MIN_LOG: smallest log_coef that takes the tree (default 15: 0.67 against 0.97 ms there; the parity
+    // tests lower it; 32 = never; read per call because the tests run both routes in one process).
     const uint32_t tree_min_log = [] {
         const char* e = getenv("FRIEDA_ERASURE_TREE_MIN_LOG");
         const int v = e ? atoi(e) : 15;
@@ -250,6 +251,7 @@ int interpolate_points(frieda_ctx* ctx, const uint32_t* d_cells, const uint32_t*
     const uint32_t n_use_cells = by_cells ? (uint32_t)(K >> log_cell) + 1 : 0;
     const uint32_t s_use = by_cells ? (uint32_t)((size_t)n_use_cells << log_cell) : (uint32_t)K + 2;
     const uint32_t n_lines = by_cells ? n_use_cells : s_use / 2;  // factors of Z_S
+    const bool by_tree = !by_cells && log_coef >= tree_min_log;
     if (s_use > s_cap) return c.fail(FRIEDA_ERR_ARG, "points: cells of 2^log_cell entries: need 2^(log_coef - log_cell) + 1 distinct cells");
 
     // domains: D (log n) and the next canonic domain D' (log n + 1)
@@ -280,12 +282,11 @@ int interpolate_points(frieda_ctx* ctx, const uint32_t* d_cells, const uint32_t*
     const size_t o_la = plan.take(4 * (size_t)n_lines), o_lb = plan.take(4 * (size_t)n_lines), o_lc = plan.take(4 * (size_t)n_lines);
     const size_t s_max = std::max<size_t>(s_use, K);
     const size_t o_px = plan.take(4 * s_max), o_py = plan.take(4 * s_max);
-    const size_t o_zp = plan.take(4 * chunks * s_max), o_z = plan.take(4 * s_max), o_bad = plan.take(4);
+    const size_t o_zp = plan.take(by_tree ? 0 : 4 * chunks * s_max), o_z = plan.take(4 * s_max), o_bad = plan.take(4);  // (o_zp: partial products of the direct routes)
     const size_t o_w = plan.take(al(4 * N) * ncols);   // Z * p on D; later the re-encoded polynomial for the check
     const size_t o_q = plan.take(al(4 * N) * ncols);   // coefficients of Z * p
     const size_t o_ev = plan.take(al(8 * N) * ncols);  // Z * p on D'
     const size_t o_blk = plan.take(al(4 * K) * ncols);
-    const bool by_tree = !by_cells && log_coef >= tree_min_log;
     const size_t o_ta = plan.take(by_tree ? 8 * K : 0), o_tb = plan.take(by_tree ? 8 * K : 0), o_tc = plan.take(by_tree ? 16 * K : 0);
     int rc = c.ensure_arena(plan.off);
     if (rc) return rc;
@@ -313,8 +314,8 @@ int interpolate_points(frieda_ctx* ctx, const uint32_t* d_cells, const uint32_t*
     if (s_use > s_all) return c.fail(FRIEDA_ERR_ARG, "points: cells of 2^log_cell entries: need 2^(log_coef - log_cell) + 1 distinct cells");
     const size_t w_stride = al(4 * N) / 4, ev_stride = al(8 * N) / 4, blk_stride = al(4 * K) / 4;
     uint32_t* coef_out = d_coef ? d_coef : reinterpret_cast<uint32_t*>(A);
-    // 1. the locator on the points it is built from: ratio of tangent derivatives
-    k::erasure_points(LN, g0, W32(o_pos), s_use, W32(o_px), W32(o_py));
+    // 1. the locator on the points it is built from: ratio of tangent derivatives (direct routes) or V_D / Z_S carried to D (tree)
+    if (!by_tree) k::erasure_points(LN, g0, W32(o_pos), s_use, W32(o_px), W32(o_py));
     if (by_cells) {
         k::erasure_cell_firsts(LN, W32(o_pos), n_use_cells, log_cell, W32(o_lb));  // (o_lb: free in this form)
         k::erasure_cellconst(LN, g0, W32(o_lb), n_use_cells, log_cell, W32(o_la));
