@@ -141,6 +141,41 @@ def test_product_tree_route_matches_line_route(gpu_ctx, oracle, monkeypatch, L, 
     assert "not values of one polynomial" in gpu_ctx._L.frieda_last_error(gpu_ctx._h).decode()
 
 
+@pytest.mark.parametrize("L,n,m", [(14, 18, 0), (15, 17, 0), (12, 16, 2), (16, 20, 0)])
+def test_heavily_repeated_sample_list(gpu_ctx, oracle, L, n, m):
+    """The caller's list is de-duplicated on the device (owner table + ranked compaction over 2048-entry chunks): a list in which every
+    cell shows up one to four times, shuffled, with garbage in every copy but the first, still gives the truth — the first occurrence
+    counts, in list order, across chunk boundaries.  And a list whose distinct cells fall one short is refused."""
+    rng = np.random.default_rng(6400 + L + n + m)
+    ncols = 4
+    coef = rng.integers(0, P, (ncols, 1 << L), dtype=np.uint32)
+    d_c0, d_ev = DevBuf.from_array(gpu_ctx, coef), DevBuf(gpu_ctx, 4 * ncols << n)
+    _check(gpu_ctx, gpu_ctx._L.frieda_circle_evaluate(gpu_ctx._h, d_c0.ptr, ncols, L, n, d_ev.ptr))
+    ev = d_ev.to_array(np.uint32, (ncols, 1 << n))
+    need = ((1 << (L - m)) + 1) if m > 0 else (1 << L) + 2
+    distinct = rng.permutation(1 << (n - m))[:need].astype(np.uint32)
+    copies = rng.integers(1, 5, need)
+    lst = np.repeat(distinct, copies)
+    order = rng.permutation(lst.size)
+    lst = lst[order]
+    cells = np.ascontiguousarray(ev.reshape(ncols, -1, 1 << m)[:, lst, :].transpose(1, 0, 2))  # [n_list, ncols, 2^m]
+    seen = set()
+    for r, ci in enumerate(lst):  # every copy after the first carries garbage
+        if int(ci) in seen:
+            cells[r] = rng.integers(0, P, cells[r].shape, dtype=np.uint32)
+        seen.add(int(ci))
+    d_cells, d_c = DevBuf.from_array(gpu_ctx, cells), DevBuf(gpu_ctx, 4 * ncols << L)
+    _check(gpu_ctx, gpu_ctx._L.frieda_circle_interpolate_points(gpu_ctx._h, d_cells.ptr, lst.ctypes.data, lst.size, ncols, m, L, n, d_c.ptr))
+    assert np.array_equal(d_c.to_array(np.uint32, (ncols, 1 << L)), coef)
+    # one distinct cell fewer (all its copies removed): not enough samples, whatever the length of the list
+    keep = lst != distinct[0]
+    lst2, cells2 = np.ascontiguousarray(lst[keep]), np.ascontiguousarray(cells[keep])
+    assert lst2.size >= need - 1
+    d_cells2 = DevBuf.from_array(gpu_ctx, cells2)
+    assert gpu_ctx._L.frieda_circle_interpolate_points(gpu_ctx._h, d_cells2.ptr, lst2.ctypes.data, lst2.size, ncols, m, L, n, d_c.ptr) == 1
+    assert "distinct" in gpu_ctx._L.frieda_last_error(gpu_ctx._h).decode()
+
+
 def test_random_shapes_both_routes(gpu_ctx, oracle, monkeypatch):
     """Seeded sweep over (coefficients, blow-up, cell size, spare cells, columns) with the product tree forced on and off: always the
     truth.  Shapes the fixed cases do not name: 2^6 coefficients (a tree of one leaf), blow-up 0 .. 5, cells larger than the polynomial."""
