@@ -386,6 +386,24 @@ __global__ void erasure_gather_kernel(const uint32_t* __restrict__ src, const ui
     if (t < count) out[t] = src[pos[t]];
 }
 
+// One step of "the first entries of a transform, without the transform": the first 2^out_log entries of the bit-reversed evaluation depend
+// on the coefficient vector only through its fold along the layers above — at layer i (stride 2^i) an entry whose higher index bits are
+// zero is v[j] + T_{i-1}[0] * v[j + 2^i] — so `cnt` <= 4 layers collapse 2^(out_log + cnt) coefficients per column into 2^out_log:
+// out[c][j] = sum over m < 2^cnt of (product over the set bits b of m of T_{out_log + b - 1}[0]) * in[c][j + (m << out_log)].
+__global__ void erasure_fold_prefix_kernel(const uint32_t* __restrict__ in, size_t in_stride, uint32_t out_log, uint32_t cnt, const uint32_t* __restrict__ tw,
+                                           uint32_t dom_n, uint32_t* __restrict__ out, size_t out_stride) {
+    const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= ((size_t)1 << out_log)) return;
+    const uint32_t* src = in + (size_t)blockIdx.y * in_stride + j;
+    uint32_t t[4], val[16];
+    for (uint32_t b = 0; b < cnt; b++) t[b] = tw[tw_level_offset_dev(dom_n, out_log + b - 1)];
+    const uint32_t terms = 1u << cnt;
+    for (uint32_t m = 0; m < terms; m++) val[m] = src[(size_t)m << out_log];
+    for (uint32_t b = cnt; b-- > 0;)
+        for (uint32_t m = 0; m < (1u << b); m++) val[m] = m31_add(val[m], m31_mul(t[b], val[m + (1u << b)]));
+    out[(size_t)blockIdx.y * out_stride + j] = val[0];
+}
+
 // mismatch[0] += number of offered samples that differ from the re-encoded polynomial: ev[c][pos[t]] vs cells[src[t] + c * 2^log_cell]
 __global__ void erasure_check_kernel(const uint32_t* __restrict__ cells, const uint32_t* __restrict__ src, const uint32_t* __restrict__ pos,
                                      uint32_t count, uint32_t ncols, uint32_t log_cell, const uint32_t* __restrict__ ev, size_t ev_stride,
@@ -505,6 +523,14 @@ void erasure_ze(const Launch& L_, const ErasureDomain& g1, const uint32_t* d_zs,
     if (!count) return;
     Scope scope(L_, "erasure_ze", 8.0 * count);
     erasure_ze_kernel<<<(count + 2047) / 2048, 256, 0, L_.stream>>>(g1, d_zs, count, n, d_ze);
+}
+
+void erasure_fold_prefix(const Launch& L_, const uint32_t* d_in, size_t in_stride, uint32_t ncols, uint32_t out_log, uint32_t cnt, const uint32_t* d_tw,
+                         uint32_t dom_n, uint32_t* d_out, size_t out_stride) {
+    Scope scope(L_, "erasure_fold_prefix", 4.0 * ncols * (double)(((size_t)1 << (out_log + cnt)) + ((size_t)1 << out_log)));
+    const size_t outs = (size_t)1 << out_log;
+    dim3 grid((unsigned)((outs + 255) / 256), ncols);
+    erasure_fold_prefix_kernel<<<grid, 256, 0, L_.stream>>>(d_in, in_stride, out_log, cnt, d_tw, dom_n, d_out, out_stride);
 }
 
 void erasure_gather(const Launch& L_, const uint32_t* d_src, const uint32_t* d_pos, uint32_t count, uint32_t* d_out) {

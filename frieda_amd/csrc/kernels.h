@@ -78,6 +78,9 @@ void gen_twiddles(const Launch& L, uint32_t n, const TwiddleSeeds& seeds, uint32
 // d_coef[ncols][coef_stride] (2^L live words per column) -> d_out[ncols][out_stride] (2^n per column)
 void circle_evaluate(const Launch& L_, const uint32_t* d_coef, size_t coef_stride, uint32_t ncols, uint32_t L, uint32_t n,
                      const uint32_t* d_tw, DomainScalars ds, uint32_t* d_out, size_t out_stride);
+// the same, but only the first 2^out_log entries (L <= out_log <= n) of every column's bit-reversed evaluation are produced
+void circle_evaluate_prefix(const Launch& L_, const uint32_t* d_coef, size_t coef_stride, uint32_t ncols, uint32_t L, uint32_t n, uint32_t out_log,
+                            const uint32_t* d_tw, DomainScalars ds, uint32_t* d_out, size_t out_stride);
 
 // The same transform with its contiguous last pass fused with leaf hashing: when the shape allows it (4 columns, >= 12 real
 // layers, 16-byte aligned buffers) the last launch also produces the tree levels n .. n-6 of the Merkle tree over the 4 columns
@@ -156,6 +159,10 @@ void erasure_lines32(const Launch& L_, const uint32_t* d_px128, const uint32_t* 
                      uint32_t n_lines, uint32_t nodes, uint32_t* d_out);
 void erasure_pairmul(const Launch& L_, const uint32_t* d_ext, uint32_t n_nodes, uint32_t size, uint32_t* d_out);
 void erasure_ze(const Launch& L_, const ErasureDomain& g1, const uint32_t* d_zs, uint32_t count, uint32_t n, uint32_t* d_ze);
+// d_out[c][j] (j < 2^out_log) = the coefficient vector d_in[c][2^(out_log + cnt)] folded along `cnt` <= 4 layers of the domain of log size
+// dom_n (twiddle table d_tw): circle_evaluate_prefix of the result gives the same first 2^out_log entries as evaluating d_in itself
+void erasure_fold_prefix(const Launch& L_, const uint32_t* d_in, size_t in_stride, uint32_t ncols, uint32_t out_log, uint32_t cnt, const uint32_t* d_tw,
+                         uint32_t dom_n, uint32_t* d_out, size_t out_stride);
 void erasure_gather(const Launch& L_, const uint32_t* d_src, const uint32_t* d_pos, uint32_t count, uint32_t* d_out);
 // d_w[c][d_pos[t]] = d_z[t] * d_cells[d_src[t] + c * 2^log_cell] (d_w zeroed by the caller)
 void erasure_scatter(const Launch& L_, const uint32_t* d_cells, const uint32_t* d_src, const uint32_t* d_pos, const uint32_t* d_z, uint32_t count,

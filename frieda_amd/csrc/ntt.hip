@@ -675,14 +675,34 @@ void set_stages(NttArgs& a, uint32_t t) {
 
 FR_CLOCK_READER(frieda_debug_clock_ntt_last_tree, g_clock_ntt_last_tree)
 
+namespace {
+uint32_t evaluate_plan(const Launch& L_, const uint32_t* d_coef, size_t coef_stride, uint32_t ncols, uint32_t L, uint32_t n, uint32_t out_log,
+                       const uint32_t* d_tw, DomainScalars ds, uint32_t* d_out, size_t out_stride, const EncodeTreeSink* sink);
+}
+
 void circle_evaluate(const Launch& L_, const uint32_t* d_coef, size_t coef_stride, uint32_t ncols, uint32_t L, uint32_t n,
                      const uint32_t* d_tw, DomainScalars ds, uint32_t* d_out, size_t out_stride) {
-    (void)circle_evaluate_into_tree(L_, d_coef, coef_stride, ncols, L, n, d_tw, ds, d_out, out_stride, nullptr);
+    (void)evaluate_plan(L_, d_coef, coef_stride, ncols, L, n, n, d_tw, ds, d_out, out_stride, nullptr);
+}
+
+void circle_evaluate_prefix(const Launch& L_, const uint32_t* d_coef, size_t coef_stride, uint32_t ncols, uint32_t L, uint32_t n, uint32_t out_log,
+                            const uint32_t* d_tw, DomainScalars ds, uint32_t* d_out, size_t out_stride) {
+    (void)evaluate_plan(L_, d_coef, coef_stride, ncols, L, n, out_log < L ? L : (out_log > n ? n : out_log), d_tw, ds, d_out, out_stride, nullptr);
 }
 
 uint32_t circle_evaluate_into_tree(const Launch& L_, const uint32_t* d_coef, size_t coef_stride, uint32_t ncols, uint32_t L, uint32_t n,
                                const uint32_t* d_tw, DomainScalars ds, uint32_t* d_out, size_t out_stride, const EncodeTreeSink* sink) {
-    const size_t N = (size_t)1 << n;
+    return evaluate_plan(L_, d_coef, coef_stride, ncols, L, n, n, d_tw, ds, d_out, out_stride, sink);
+}
+
+namespace {
+// `out_log` (L <= out_log <= n): only the first 2^out_log entries of the bit-reversed evaluation are produced.  They depend on all the
+// coefficients through the real layers alone (a workgroup's index bits above its layers select its twiddles: the first entries are the
+// workgroups whose high index bits are zero), so the same passes run on a shorter grid.  N below is that number of outputs; the domain
+// (twiddle tables, index arithmetic inside the kernels) stays 2^n.
+uint32_t evaluate_plan(const Launch& L_, const uint32_t* d_coef, size_t coef_stride, uint32_t ncols, uint32_t L, uint32_t n, uint32_t out_log,
+                       const uint32_t* d_tw, DomainScalars ds, uint32_t* d_out, size_t out_stride, const EncodeTreeSink* sink) {
+    const size_t N = (size_t)1 << out_log;
     hipStream_t s = L_.stream;
     // algorithmic bytes of the encode: read 2^L, write 2^n words per column (16N(1 + 2^-B) for 4 columns),
     // split evenly over the passes
@@ -741,7 +761,7 @@ uint32_t circle_evaluate_into_tree(const Launch& L_, const uint32_t* d_coef, siz
     auto launch_pass = [&](uint32_t t, const char* name) {
         const bool aligned = ((a.in_stride | a.out_stride) & 3) == 0 && (a.in_mask & 3u) == 3u &&
                              ((reinterpret_cast<uintptr_t>(a.in) | reinterpret_cast<uintptr_t>(a.out) | L_.bstride) & 15) == 0;
-        if (sink && aligned && a.log_w == 0 && t == 12 && ncols == 4 && n >= TILE_LOG) {
+        if (sink && aligned && a.log_w == 0 && t == 12 && ncols == 4 && n >= TILE_LOG && out_log == n) {
             // the contiguous last pass of 12 layers over the 4 coordinate columns: fused with leaf hashing + 6 tree levels
             NttTreeArgs ta{};
             ta.a = a;
@@ -777,7 +797,7 @@ uint32_t circle_evaluate_into_tree(const Launch& L_, const uint32_t* d_coef, siz
             return e && *e == '1';
         }();
         const uint32_t hb_log = n - 1 - a.i_hi;  // high blocks = 2^hb_log
-        if (use_rep && aligned && t == 8 && a.log_w == MID_LOG_W && hb_log >= 1 && ((uint64_t)a.in_mask >> (a.i_hi + 1)) == 0 && ncols % 2 == 0) {
+        if (use_rep && out_log == n && aligned && t == 8 && a.log_w == MID_LOG_W && hb_log >= 1 && ((uint64_t)a.in_mask >> (a.i_hi + 1)) == 0 && ncols % 2 == 0) {
             // this pass reads the (replicated) coefficient vector: every high block has the same source tile
             a.rep_log = hb_log < 3 ? hb_log : 3;
             a.ncols = 2;
@@ -812,7 +832,7 @@ uint32_t circle_evaluate_into_tree(const Launch& L_, const uint32_t* d_coef, siz
     const uint32_t units = (rest + 3) / 4, padz = 4 * units - rest;
     const bool base_aligned = ((a.in_stride | a.out_stride) & 3) == 0 &&
                               ((reinterpret_cast<uintptr_t>(a.in) | reinterpret_cast<uintptr_t>(a.out) | L_.bstride) & 15) == 0;
-    if (rest > 0 && base_aligned && padz <= n - L && L >= 4 && (!no_pad8 || (padz == 0 && (units & 1) == 0))) {
+    if (rest > 0 && base_aligned && padz <= out_log - L && L >= 4 && (!no_pad8 || (padz == 0 && (units & 1) == 0))) {
         n_mid_fast = (units + 1) / 2;
         uint32_t top = L - 1 + padz, left = units;
         bool first = true;
@@ -859,6 +879,7 @@ uint32_t circle_evaluate_into_tree(const Launch& L_, const uint32_t* d_coef, siz
     launch_pass(last_t, "ntt_pass_last");
     return fused_levels;
 }
+}  // namespace
 
 }  // namespace k
 }  // namespace frieda

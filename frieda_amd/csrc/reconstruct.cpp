@@ -314,6 +314,8 @@ int interpolate_points(frieda_ctx* ctx, const uint32_t* d_cells, const uint32_t*
     if (s_use > s_all) return c.fail(FRIEDA_ERR_ARG, "points: cells of 2^log_cell entries: need 2^(log_coef - log_cell) + 1 distinct cells");
     const size_t w_stride = al(4 * N) / 4, ev_stride = al(8 * N) / 4, blk_stride = al(4 * K) / 4;
     uint32_t* coef_out = d_coef ? d_coef : reinterpret_cast<uint32_t*>(A);
+    const uint32_t* ev_first = nullptr;  // Z * p on the first 2^log_coef entries of D' (step 3)
+    size_t ev_first_stride = 0;
     // 1. the locator on the points it is built from: ratio of tangent derivatives (direct routes) or V_D / Z_S carried to D (tree)
     if (!by_tree) k::erasure_points(LN, g0, W32(o_pos), s_use, W32(o_px), W32(o_py));
     if (by_cells) {
@@ -358,7 +360,7 @@ int interpolate_points(frieda_ctx* ctx, const uint32_t* d_cells, const uint32_t*
         rc = c.get_twiddles(d, tsr);
         if (rc) return rc;
         k::circle_interpolate_block(LN, W32(o_ta), (size_t)1 << d, 1, d, d, 0, tsr.d_itw, tsr.ds, W32(o_tb), (size_t)1 << d);
-        k::circle_evaluate(LN, W32(o_tb), (size_t)1 << d, 1, d, n + 1, ts1.d_tw, ts1.ds, W32(o_ev), ev_stride);
+        k::circle_evaluate_prefix(LN, W32(o_tb), (size_t)1 << d, 1, d, n + 1, n, ts1.d_tw, ts1.ds, W32(o_ev), ev_stride);  // (first half of D': all that is read)
         FR_HIP(&c, hipMemcpyAsync(A + o_tc, A + o_ev, 4 * K, hipMemcpyDeviceToDevice, s));  // Z_S on the block step 3 divides on
         k::erasure_ze(LN, g1, W32(o_ev), (uint32_t)N, n, W32(o_q));
         k::circle_interpolate_block(LN, W32(o_q), w_stride, 1, n, n + 1, 0, ts1.d_itw, ts1.ds, W32(o_w), w_stride);
@@ -369,8 +371,30 @@ int interpolate_points(frieda_ctx* ctx, const uint32_t* d_cells, const uint32_t*
     FR_HIP(&c, hipMemsetAsync(A + o_w, 0, al(4 * N) * ncols, s));
     k::erasure_scatter(LN, d_cells, W32(o_src), W32(o_pos), W32(o_z), s_use, ncols, log_cell, W32(o_w), w_stride);
     k::circle_interpolate_block(LN, W32(o_w), w_stride, ncols, n, n, 0, ts0.d_itw, ts0.ds, W32(o_q), w_stride);
-    // 3. onto D', first block of 2^log_coef entries: p = (Z p) Z_S / V_D there
-    k::circle_evaluate(LN, W32(o_q), w_stride, ncols, n, n + 1, ts1.d_tw, ts1.ds, W32(o_ev), ev_stride);
+    // 3. onto the first 2^log_coef entries of D': p = (Z p) Z_S / V_D there.  Only that block is wanted, so the coefficient vector is
+    //    folded down to 2^log_coef entries (four layers per launch, buffers alternating) and a transform of that size finishes.
+    {
+        const uint32_t* cur = W32(o_q);
+        size_t cur_stride = w_stride;
+        uint32_t cur_log = n;
+        bool into_ev = true;
+        while (cur_log > log_coef) {
+            const uint32_t cnt = std::min<uint32_t>(4, cur_log - log_coef), out_log = cur_log - cnt;
+            uint32_t* dst = into_ev ? W32(o_ev) : W32(o_w);
+            const size_t dst_stride = into_ev ? ev_stride : w_stride;
+            k::erasure_fold_prefix(LN, cur, cur_stride, ncols, out_log, cnt, ts1.d_tw, n + 1, dst, dst_stride);
+            cur = dst;
+            cur_stride = dst_stride;
+            cur_log = out_log;
+            into_ev = !into_ev;
+        }
+        // (the transform's output takes the buffer the last fold did not write; step 2's o_q is free again)
+        uint32_t* dst = cur == W32(o_ev) ? W32(o_q) : W32(o_ev);
+        const size_t dst_stride = cur == W32(o_ev) ? w_stride : ev_stride;
+        k::circle_evaluate_prefix(LN, cur, cur_stride, ncols, log_coef, n + 1, log_coef, ts1.d_tw, ts1.ds, dst, dst_stride);
+        ev_first = dst;
+        ev_first_stride = dst_stride;
+    }
     k::erasure_points(LN, g1, nullptr, (uint32_t)K, W32(o_px), W32(o_py));
     if (by_cells)
         k::erasure_zeval_cells(LN, W32(o_px), (uint32_t)K, log_cell, W32(o_la), n_use_cells, false, W32(o_zp), W32(o_z));
@@ -378,7 +402,7 @@ int interpolate_points(frieda_ctx* ctx, const uint32_t* d_cells, const uint32_t*
         FR_HIP(&c, hipMemcpyAsync(A + o_z, A + o_tc, 4 * K, hipMemcpyDeviceToDevice, s));
     else
         k::erasure_zeval(LN, W32(o_px), W32(o_py), (uint32_t)K, W32(o_la), W32(o_lb), W32(o_lc), n_lines, false, W32(o_zp), W32(o_z));
-    k::erasure_divide(LN, W32(o_ev), ev_stride, W32(o_z), W32(o_px), (uint32_t)K, ncols, n, W32(o_blk), blk_stride);
+    k::erasure_divide(LN, ev_first, ev_first_stride, W32(o_z), W32(o_px), (uint32_t)K, ncols, n, W32(o_blk), blk_stride);
     // 4. that block back to coefficients
     k::circle_interpolate_block(LN, W32(o_blk), blk_stride, ncols, log_coef, n + 1, 0, ts1.d_itw, ts1.ds, coef_out, K);
     // 5. encode again and compare every sample that was offered
