@@ -306,7 +306,7 @@ int frieda_reconstruct_cells_device(frieda_ctx* ctx, const uint32_t* d_cells, co
  * pointwise division on a disjoint domain (erasure.hip).  With log_cell >= 1, S is the first 2^(log_coef - log_cell) + 1 whole
  * cells and Z_S the product of their cell polynomials pi^(log_cell - 1)(x) - k_cell instead.  Cost: five transforms + ~2^(2 log_coef
  * - log_cell) multiplications below 2^15 coefficients; from there on (single points, or many small cells) Z_S comes from a product
- * tree, O(K log^2 K) (a 15.7 MB blob from 2^20 + 2 points of its 2^24 codeword: 4.1 ms).
+ * tree, O(K log^2 K) (a 15.7 MB blob from 2^20 + 2 points of its 2^24 codeword: 3.2 ms).
  * 1 <= log_coef <= log_domain <= FRIEDA_MAX_LOG_DOMAIN - 1, log_domain >= 2.  Every sample offered,
  * used or not, is then compared with the re-encoded result: samples that are not values of one polynomial of 2^log_coef
  * coefficients give FRIEDA_ERR_ARG (and unspecified d_coef contents) instead of a wrong answer. */
