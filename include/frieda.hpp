@@ -148,9 +148,36 @@ class Context {
         for (uint32_t i = 0; i < count; i++) out.emplace_back(roots[i], Proof(ps[i]));
         return out;
     }
+    // The reconstructor's half of the README's sampling flow (/root/reference/README.md:56-69): any >= 2^log_coef + 2 distinct
+    // (position, value) pairs of the bit-reversed codeword — e.g. pooled from api::verify_samples of proofs with different seeds —
+    // give the blob's `len` bytes back (frieda_reconstruct_points_device: no linear system, every pair checked against the result;
+    // pairs that are not values of one polynomial throw Error).  Repeated positions are ignored (the first one counts).
+    std::vector<uint8_t> reconstruct_from_samples(const std::vector<uint32_t>& positions, const std::vector<QM31>& values, uint32_t log_coef,
+                                                  uint32_t log_domain, size_t len) {
+        if (positions.size() != values.size() || positions.empty()) throw Error(FRIEDA_ERR_ARG, "reconstruct_from_samples: one value per position");
+        std::vector<uint32_t> flat(4 * values.size());
+        for (size_t i = 0; i < values.size(); i++)
+            for (int c = 0; c < 4; c++) flat[4 * i + c] = values[i].v[c];  // [n_points][4 columns][1 entry]
+        DeviceBuffer d_cells(h_, 4 * flat.size()), d_out(h_, len + 8);
+        check(frieda_dev_upload(h_, d_cells.ptr, flat.data(), 4 * flat.size()), h_);
+        check(frieda_reconstruct_points_device(h_, static_cast<const uint32_t*>(d_cells.ptr), positions.data(), (uint32_t)positions.size(), 0, log_coef,
+                                               log_domain, len, d_out.ptr),
+              h_);
+        std::vector<uint8_t> out(len);
+        if (len) check(frieda_dev_download(h_, out.data(), d_out.ptr, len), h_);
+        return out;
+    }
     frieda_ctx* handle() { return h_; }
 
   private:
+    struct DeviceBuffer {  // frieda_dev_alloc / frieda_dev_free (Level B column storage), scoped
+        frieda_ctx* ctx;
+        void* ptr = nullptr;
+        DeviceBuffer(frieda_ctx* c, size_t bytes) : ctx(c) { check(frieda_dev_alloc(c, bytes ? bytes : 1, &ptr), c); }
+        DeviceBuffer(const DeviceBuffer&) = delete;
+        DeviceBuffer& operator=(const DeviceBuffer&) = delete;
+        ~DeviceBuffer() { frieda_dev_free(ctx, ptr); }
+    };
     frieda_ctx* h_ = nullptr;
 };
 

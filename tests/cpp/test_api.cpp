@@ -166,6 +166,41 @@ int main(int argc, char** argv) {
         Proof q = Proof::deserialize(p.serialize());
         CHECK(api::verify(q, std::nullopt));
     }
+    {  // the README's sampling loop (/root/reference/README.md:56-69) with what src/ has: a sample is a proof.  Clients with different
+       // seeds each verify theirs and learn where it sampled; the pooled (position, value) pairs rebuild the data once there are
+       // 2^L + 2 distinct ones; a forged pair in the pool is reported, never answered with wrong bytes.
+        std::vector<uint8_t> d(1024);
+        for (size_t i = 0; i < d.size(); i++) d[i] = (uint8_t)(i % 256);  // benches/commit.rs:6 -> 274 felts -> 2^7 coefficients per column
+        const uint32_t log_coef = 7, log_domain = 11;
+        const PcsConfig cfg{8, FriConfig{4, 0, 40}};
+        std::vector<uint32_t> positions;
+        std::vector<QM31> values;
+        std::vector<bool> have((size_t)1 << log_domain, false);
+        size_t distinct = 0;
+        for (uint64_t seed = 1; distinct < (1u << log_coef) + 2 && seed < 200; seed++) {
+            Proof p = api::generate_proof(d, seed, cfg);
+            auto pos = api::verify_samples(p, seed);
+            CHECK(pos.has_value());
+            if (!pos) break;
+            auto ev = p.evaluations();
+            for (size_t i = 0; i < pos->size(); i++) {
+                positions.push_back((*pos)[i]);  // (repeats across clients stay in the pool: the call ignores them)
+                values.push_back(ev[i]);
+                if (!have[(*pos)[i]]) have[(*pos)[i]] = true, distinct++;
+            }
+        }
+        CHECK(distinct >= (1u << log_coef) + 2);
+        Context& ctx = default_context();
+        CHECK(ctx.reconstruct_from_samples(positions, values, log_coef, log_domain, d.size()) == d);
+        values[3].v[1] = (values[3].v[1] + 1) % 0x7fffffffu;
+        bool refused = false;
+        try {
+            ctx.reconstruct_from_samples(positions, values, log_coef, log_domain, d.size());
+        } catch (const Error&) {
+            refused = true;
+        }
+        CHECK(refused);
+    }
     {  // too small a polynomial for the FRI configuration: the reference panics
         std::vector<uint8_t> tiny = {1, 2, 3};
         bool panicked = false;
