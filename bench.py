@@ -165,28 +165,35 @@ def cpu_baseline(sample_log, workload, calls, all_cores_log=22):
         "sample": f"{calls} x {name} on a 2^{sample_log} domain (same generator and config as the GPU workload), {dt:.1f} s of "
         f"single-thread CPU on a {os.cpu_count()}-core host; restated CPU path (oracle/), not the upstream Rust binary",
     }
-    # all cores: one blob per core, the C calls run outside the GIL (the oracle keeps no shared mutable state)
-    threads = _host_threads()
-    blobs = [splitmix64_bytes(100 + i, blob_len_for(all_cores_log)) for i in range(threads)]
-    t0 = time.perf_counter()
-    with ThreadPoolExecutor(max_workers=threads) as ex:
-        roots = list(ex.map(run, blobs))
-    dta = time.perf_counter() - t0
+    # many cores: one blob per core, the C calls run outside the GIL (the oracle keeps no shared mutable state)
     try:
         usable = len(os.sched_getaffinity(0))
     except AttributeError:
         usable = os.cpu_count() or 1
-    out["multi_core"] = {
-        "value": 4.0 * (1 << all_cores_log) * threads / dta,
-        "unit": "M31 field-elems/s",
-        "cores": threads,
-        "usable_cores": usable,
-        "all_usable_cores": threads == usable,
-        "nproc": os.cpu_count(),
-        "sample": f"{threads} distinct blobs, one {name} on a 2^{all_cores_log} domain per thread, {threads} threads = "
-        f"{'every core' if threads == usable else 'a capped share of the cores'} this process may run on ({usable} of {os.cpu_count()} on the host), {dta:.1f} s wall",
-        "first_root": bytes(roots[0]).hex(),
-    }
+
+    def leg(threads, log, what):
+        blobs = [splitmix64_bytes(100 + i, blob_len_for(log)) for i in range(threads)]
+        t0 = time.perf_counter()
+        with ThreadPoolExecutor(max_workers=threads) as ex:
+            roots = list(ex.map(run, blobs))
+        dta = time.perf_counter() - t0
+        return {
+            "value": 4.0 * (1 << log) * threads / dta,
+            "unit": "M31 field-elems/s",
+            "cores": threads,
+            "usable_cores": usable,
+            "all_usable_cores": threads == usable,
+            "nproc": os.cpu_count(),
+            "sample": f"{threads} distinct blobs, one {name} on a 2^{log} domain per thread, {threads} threads = {what} this process may run on "
+            f"({usable} of {os.cpu_count()} on the host), {dta:.1f} s wall",
+            "first_root": bytes(roots[0]).hex(),
+        }
+
+    threads = _host_threads()
+    out["multi_core"] = leg(threads, all_cores_log, "every core" if threads == usable else "a capped share of the cores")
+    # EVERY usable core (north_star: "the GPU box's own host cores"): one smaller proof per thread (~45 MB of oracle workspace each at 2^20)
+    every_log = min(20, all_cores_log)
+    out["multi_core_all"] = out["multi_core"] if (threads == usable and every_log == all_cores_log) else leg(usable, every_log, "every core")
     return out
 
 
@@ -512,6 +519,130 @@ def end_to_end(frieda_amd, torch, device, n, K, cfg, expect_roots=None):
     return out
 
 
+def spm_child(args):
+    """`bench.py --spm-child --gpus N`: ONE process drives all N devices through the C ABI's multi-GPU entry (frieda_multi_create,
+    frieda_prove_many, frieda_commit_many: multi.cpp — what a Rust caller of /root/reference/src/lib.rs:31-38 on an 8-GPU node would
+    use): host blobs, one host thread + two contexts + an upload ring per device, blob i -> device i mod N, one ncclAllGather of the
+    roots per call.  Workloads: BASELINE configs[3] as written (8 blobs of the 2^22 domain, generator seeds 100 .. 107,
+    /root/reference/benches/proof.rs:30-44 per blob) and N * k blobs of the headline domain (seeds 100 + j).  Prints one JSON line;
+    the rank-0 process of the per-rank run merges it as `single_process_multi` and checks the roots."""
+    N = args.gpus
+    devices = [int(x) for x in args.spm_devices.split(",")] if args.spm_devices else list(range(N))
+    out = {"devices": devices, "entry_points": "frieda_multi_create / frieda_prove_many / frieda_commit_many (one process, host blobs)"}
+    if args.dry_collective:  # CPU rehearsal of the spawn / merge plumbing: no GPU, no library
+        out["dry_run"] = True
+        sys.stdout.write(json.dumps(out) + "\n")
+        return 0
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)  # RCCL banners etc. must not land in the JSON
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
+    import frieda_amd
+
+    cfg = frieda_amd.PcsConfig(frieda_amd.FriConfig(4, 0, 20), 20)
+    t0 = time.perf_counter()
+    mc = frieda_amd.MultiContext(devices)
+    out["create_s"] = time.perf_counter() - t0
+    out["uses_rccl"] = mc.uses_rccl
+    n = args.log_domain
+
+    def timed(blobs, seeds, passes=3):
+        """best of `passes` (after one untimed call that sizes workspaces, upload rings and the communicator)"""
+        mc.prove_many(blobs, seeds, cfg)
+        mc.commit_many(blobs, 4)
+        tp = tc = None
+        for _ in range(passes):
+            t0 = time.perf_counter()
+            res = mc.prove_many(blobs, seeds, cfg)
+            d1 = time.perf_counter() - t0
+            roots = [r for r, _ in res]
+            assert all(p.commitment == r and frieda_amd.verify(p, s_) for (r, p), s_ in zip(res, seeds)), "a single-process multi-GPU proof does not verify"
+            del res
+            t0 = time.perf_counter()
+            croots = mc.commit_many(blobs, 4)
+            d2 = time.perf_counter() - t0
+            assert croots == roots, "frieda_commit_many and frieda_prove_many disagree on a root"
+            tp = d1 if tp is None else min(tp, d1)
+            tc = d2 if tc is None else min(tc, d2)
+        return tp, tc, roots
+
+    def block(log, blobs, seeds, tp, tc, roots):
+        cnt, elems = len(blobs), 4.0 * (1 << log)
+        return {"log_domain": log, "blobs": cnt, "blob_bytes": len(blobs[0]), "prove_ms_per_call": 1e3 * tp, "prove_ms_per_blob": 1e3 * tp / cnt,
+                "value": elems * cnt / tp, "unit": "M31 field-elems/s", "frac_of_hbm_peak_wall_per_gpu": algorithmic_bytes(log, "prove") * cnt / tp / 1e9 / HBM_PEAK_GBS / len(devices),
+                "commit_ms_per_call": 1e3 * tc, "commit_ms_per_blob": 1e3 * tc / cnt, "commit_value": elems * cnt / tc,
+                "verified_proofs": cnt, "roots": [r.hex() for r in roots], "host_memory": "pageable", "pcie_inclusive": True}
+
+    if n >= 22:
+        # configs[3] as written: one 2^22 blob per GPU at N = 8 (two per GPU at N = 4, ...)
+        blobs = [splitmix64_bytes(100 + i, blob_len_for(22)) for i in range(8)]
+        seeds = [blob_len_for(22)] * 8
+        c4 = block(22, blobs, seeds, *timed(blobs, seeds))
+        c4["workload"] = "BASELINE configs[3]: 8 independent 2^22-domain blobs, generator seeds 100..107, blob i -> device i mod N, one root all-gather"
+        gold = os.path.join(ROOT, "tests", "golden", "config4_roots.json")
+        if os.path.exists(gold):
+            want = json.load(open(gold))["roots"]
+            assert c4["roots"] == want, "configs[3] roots differ from tests/golden/config4_roots.json (the oracle's)"
+            c4["roots_equal_oracle_fixture"] = True
+        out["config4"] = c4
+    # the headline domain: k blobs per device
+    cnt = len(devices) * max(1, args.spm_blobs_per_gpu)
+    blobs = [splitmix64_bytes(100 + j, blob_len_for(n)) for j in range(cnt)]
+    seeds = [blob_len_for(n)] * cnt
+    hd = block(n, blobs, seeds, *timed(blobs, seeds, passes=2))
+    hd["workload"] = f"{cnt} independent 2^{n}-domain blobs (generator seeds 100 + j), blob j -> device j mod N"
+    out["headline"] = hd
+    out["gather_count"] = mc.gather_count
+    mc.close()
+    os.write(real_stdout, (json.dumps(out) + "\n").encode())
+    return 0
+
+
+def single_process_multi(args, n_devices, expect_root_of_seed=None):
+    """Spawn the --spm-child as a fresh interpreter (a child process, never an exec of this one), parse its line, compare the headline
+    roots with the per-rank run's (`expect_root_of_seed(seed) -> bytes or None`).  Every failure is reported in place: this block
+    must never cost the line its headline."""
+    import subprocess
+
+    argv = [sys.executable, os.path.abspath(__file__), "--spm-child", "--gpus", str(n_devices), "--log-domain", str(args.log_domain),
+            "--spm-blobs-per-gpu", str(args.spm_blobs_per_gpu)]
+    if args.spm_devices:
+        argv += ["--spm-devices", args.spm_devices]
+    if args.dry_collective:
+        argv += ["--dry-collective", args.dry_collective]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_PORT", "GROUP_RANK", "ROLE_RANK",
+                                                          "TORCHELASTIC_RUN_ID", "FRIEDA_BENCH_SELF_LAUNCHED", "FRIEDA_BENCH_FORCE_DIST")}
+    try:
+        proc = subprocess.Popen(argv, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        try:
+            so, se = proc.communicate(timeout=args.spm_timeout)
+        except subprocess.TimeoutExpired:
+            proc.kill()  # exactly the PID started above
+            proc.communicate()
+            return {"error": f"--spm-child did not finish within {args.spm_timeout:.0f} s"}
+        lines = [ln for ln in so.decode(errors="replace").splitlines() if ln.startswith("{")]
+        if proc.returncode != 0 or len(lines) != 1:
+            return {"error": f"--spm-child exited {proc.returncode}", "stderr_tail": se.decode(errors="replace")[-1500:]}
+        doc = json.loads(lines[0])
+        hd = doc.get("headline")
+        if hd and expect_root_of_seed is not None:
+            checked = 0
+            for j, r in enumerate(hd["roots"]):
+                want = expect_root_of_seed(100 + j)
+                if want is not None:
+                    if bytes.fromhex(r) != want:
+                        return {"error": f"root of the seed-{100 + j} blob differs between frieda_prove_many and the per-rank run", "child": doc}
+                    checked += 1
+            hd["roots_equal_per_rank_run"] = checked
+        for blk in ("headline", "config4"):  # the roots were compared; keep the line short
+            if doc.get(blk):
+                doc[blk]["roots"] = doc[blk]["roots"][:2]
+        return doc
+    except Exception as e:  # noqa: BLE001
+        return {"error": f"{type(e).__name__}: {e}"}
+
+
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -539,6 +670,11 @@ def parse_args(argv=None):
     ap.add_argument("--dry-collective", choices=["gloo"], default=None,
                     help="CPU rehearsal of the N > 1 plumbing: launcher, rendezvous, barriers, root all_gather and max-reduce over gloo; GPU work stubbed")
     ap.add_argument("--launch-timeout", type=float, default=1500.0, help="seconds the self-launcher waits for its ranks")
+    ap.add_argument("--spm-child", action="store_true", help="internal: the single-process multi-GPU leg (frieda_prove_many over --gpus devices), one JSON line")
+    ap.add_argument("--spm-devices", default=None, help="device list of the single-process leg, e.g. 0,0 (a device listed twice needs the RCCL test double)")
+    ap.add_argument("--spm-blobs-per-gpu", type=int, default=4, help="headline-size blobs per device in the single-process leg")
+    ap.add_argument("--spm-timeout", type=float, default=420.0, help="seconds the single-process leg may take")
+    ap.add_argument("--no-single-process-multi", action="store_true", help="skip the single_process_multi block of an N > 1 line")
     args = ap.parse_args(argv)
     if args.only_measured_loop:
         args.no_by_config = args.no_end_to_end = args.no_cpu_baseline = args.no_reconstruct = True
@@ -636,22 +772,30 @@ def dry_run(args):
     for r in range(world):
         exp = b"".join(hashlib.sha256(f"{r}:{i}".encode()).digest() for i in range(K))
         assert bytes(gathered[r].numpy()) == exp, "root gather mismatch"
+    dist.destroy_process_group()  # as in main(): nobody waits on rank 0's CPU legs
     if rank == 0:
         out = {
             "metric": "M31 field-elems/s committed (NTT+FRI+Merkle)", "value": 0.0, "unit": "M31 field-elems/s", "n_gpus": world,
             "steps": K, "warmup": args.warmup, "ms_per_step": 1e3 * float(t.item()) / max(K, 1), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "none (dry run: GPU work stubbed)", "dry_run": True,
             "config": {"workload": "dry-collective gloo: launcher + rendezvous + root all_gather only", "log_domain": args.log_domain},
-            "roots_gathered": int(gathered.numel() // 32),
+            "roots_gathered": int(gathered.numel() // 32), "roofline": None, "roofline_valu": None,
         }
+        if not args.no_cpu_baseline:  # the same CPU legs an N > 1 line of the real run carries (the GPU-side comparison of bench sizes needs a GPU)
+            out["cpu_baseline"] = cpu_baseline(args.cpu_sample_log, args.workload, 1, all_cores_log=min(22, args.cpu_sample_log))
+        else:
+            out["cpu_baseline"] = None
+        if not args.no_single_process_multi:
+            out["single_process_multi"] = single_process_multi(args, world, None)
         sys.stdout.write(json.dumps(out) + "\n")
         sys.stdout.flush()
-    dist.destroy_process_group()
     return 0
 
 
 def main():
     args = parse_args()
+    if args.spm_child:
+        sys.exit(spm_child(args))
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args))
     if args.dry_collective:
@@ -810,7 +954,8 @@ def main():
         dt = float(t.item())
         # every rank now holds every root: rank r's own K roots must sit in slot r
         torch.cuda.synchronize()
-        mine = bytes(gathered[32 * K * rank : 32 * K * (rank + 1)].cpu().numpy())
+        gathered_host = bytes(gathered.cpu().numpy())  # rank-major: the root of generator seed 100 + r * K + i at 32 * (r * K + i)
+        mine = gathered_host[32 * K * rank : 32 * K * (rank + 1)]
         assert mine == bytes(roots_all.cpu().numpy()), "root gather mismatch"
         if args.workload == "prove":
             assert mine == b"".join(r for r, _ in results)
@@ -980,7 +1125,9 @@ def main():
                                "frieda_ctx_blake2s_ceiling_ex): the chip holds its clock under this load; the ceiling is ~3950 SIMD cycles per "
                                "wave-compression (~1000 VALU instructions at ~3.9 cycles each in a mixed full-rate / half-rate stream)"}
 
-    if n >= 16:
+    if args.only_measured_loop:
+        valu = {"skipped": "--only-measured-loop: neither the ceiling nor the per-kernel replay was measured"}
+    elif n >= 16:
         first = valu_entry("ntt_last_tree7", float(1 << n), 7, "leaf + 6 node levels; the launch also runs 12 transform layers on 4 columns") or \
             valu_entry("tree5_leaf", float(1 << n), 5, "leaf + 4 node levels")
         fold = valu_entry("tree5_fold_circle", float(1 << (n - 1)), 5, "fold + leaf + 4 node levels of the first FRI layer") if args.workload == "prove" else None
@@ -1073,20 +1220,36 @@ def main():
         except Exception as e:  # noqa: BLE001
             rows.append({"error": f"{type(e).__name__}: {e}"})
         out["by_config"] = rows
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    # Every collective is behind us: leave the process group BEFORE rank 0's CPU legs, so that no rank waits on them (north_star wants
+    # the CPU figure "in the same run" at 1, 2, 4 and 8 GPUs: an N > 1 line carries cpu_baseline, roofline and roofline_valu too).
+    if use_dist:
+        dist.destroy_process_group()
+    if rank == 0 and not args.no_cpu_baseline:
         cb = cpu_baseline(args.cpu_sample_log, args.workload, 2 if args.cpu_sample_log <= 22 else 1, all_cores_log=min(22, args.cpu_sample_log))
-        if args.cpu_sample_log == n:  # the very same blob and configuration: the CPU root must be the GPU root
+        if args.cpu_sample_log == n:  # the very same blob and configuration (rank 0's first blob is the seed-100 blob): the CPU root must be the GPU root
             assert cb["root"] == out["root"], "CPU baseline root differs from the GPU root"
             cb["root_equals_gpu_root"] = True
         cb["reference_bench_sizes"] = reference_bench_sizes(ctx, frieda_amd, torch)
         out["cpu_baseline"] = cb
     elif rank == 0:
         out["cpu_baseline"] = None
+    ctx.close()
+    if pipe is not None:
+        pipe.close()
+    if rank == 0 and use_dist and args.workload == "prove" and not args.no_single_process_multi:
+        # The C ABI's own multi-GPU entry (frieda_prove_many / frieda_commit_many: one process, every device, host blobs) on the same
+        # node, in a fresh child process once this rank's device memory is released; the other ranks left the process group above and
+        # have exited (the CPU legs take tens of seconds; the child also warms up before it times anything).
+        del blobs, blob, all_blobs, roots_all, gathered
+        torch.cuda.empty_cache()
+
+        def root_of_seed(s_):
+            j = s_ - 100
+            return gathered_host[32 * j : 32 * j + 32] if 0 <= j < world * K else None
+
+        out["single_process_multi"] = single_process_multi(args, world, root_of_seed)
     if rank == 0:
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
-    ctx.close()
-    if use_dist:
-        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -38,6 +38,7 @@ def test_bench_line_small_domain(extra):
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0 and cb["root_equals_gpu_root"] is True
     assert cb["multi_core"]["cores"] >= 1 and cb["multi_core"]["value"] > 0 and cb["multi_core"]["usable_cores"] >= cb["multi_core"]["cores"]
+    assert cb["multi_core_all"]["all_usable_cores"] is True and cb["multi_core_all"]["cores"] == cb["multi_core_all"]["usable_cores"]  # every usable host core
     assert len(cb["reference_bench_sizes"]) == 5 and all(r["roots_equal"] and r["proofs_equal"] for r in cb["reference_bench_sizes"])
     if "commit" not in extra:
         assert d["verified_proofs"] == 9
@@ -68,7 +69,33 @@ def test_bench_line_carries_the_other_baseline_configs():
 
 
 def test_bench_forced_collective_one_rank():
-    """RCCL init, root all_gather, barrier and max-reduce with a single rank: the N > 1 code path on a one-GPU box."""
-    d = _bench(["--gpus", "1", "--log-domain", "16", "--steps", "6", "--warmup", "1", "--no-cpu-baseline", "--batch-extra", "0", "--sequential-extra", "0"],
+    """RCCL init, root all_gather, barrier and max-reduce with a single rank: the N > 1 code path on a one-GPU box.  The line of that
+    path is self-sufficient: cpu_baseline (computed by rank 0 after the process group is gone), roofline, roofline_valu, and the
+    single-process frieda_prove_many leg from a fresh child process with its roots checked against the per-rank run's."""
+    d = _bench(["--gpus", "1", "--log-domain", "16", "--cpu-sample-log", "16", "--steps", "6", "--warmup", "1", "--batch-extra", "0", "--sequential-extra", "0"],
                env_extra={"FRIEDA_BENCH_FORCE_DIST": "1"})
-    assert d["n_gpus"] == 1 and d["verified_proofs"] == 6 and d["cpu_baseline"] is None
+    assert d["n_gpus"] == 1 and d["verified_proofs"] == 6
+    assert d["cpu_baseline"]["root_equals_gpu_root"] is True and d["cpu_baseline"]["multi_core_all"]["all_usable_cores"] is True
+    assert d["roofline"]["frac"] > 0 and isinstance(d["roofline_valu"], list) and d["roofline_valu"][0]["frac"] > 0
+    spm = d["single_process_multi"]
+    assert spm.get("error") is None, spm
+    hd = spm["headline"]
+    assert spm["devices"] == [0] and hd["blobs"] == 4 and hd["verified_proofs"] == 4 and hd["roots_equal_per_rank_run"] == 4
+    assert hd["prove_ms_per_blob"] > 0 and hd["commit_ms_per_blob"] > 0 and hd["value"] > 0
+
+
+@pytest.mark.parametrize("slots,log_domain", [(2, 16), (3, 16), (2, 22)])
+def test_bench_single_process_leg_over_several_device_slots(slots, log_domain):
+    """`bench.py --spm-child` (what an N > 1 line's rank 0 spawns) over 2 and 3 device slots of this one GPU against the RCCL test double:
+    blob i -> slot i mod N, one root gather per call; at 2^22 also BASELINE configs[3] as written (seeds 100 .. 107) against the oracle's
+    roots in tests/golden/config4_roots.json."""
+    d = _bench(["--spm-child", "--gpus", str(slots), "--spm-devices", ",".join(["0"] * slots), "--log-domain", str(log_domain), "--spm-blobs-per-gpu", "2"],
+               env_extra={"FRIEDA_RCCL_PATH": os.path.join(ROOT, "tests", "cpp", "librccl_stub.so")})
+    assert d["devices"] == [0] * slots and d["uses_rccl"] is True and d["gather_count"] > 0
+    hd = d["headline"]
+    assert hd["blobs"] == 2 * slots and hd["verified_proofs"] == 2 * slots and len(set(hd["roots"])) == 2 * slots
+    if log_domain >= 22:
+        c4 = d["config4"]
+        assert c4["blobs"] == 8 and c4["verified_proofs"] == 8 and c4["roots_equal_oracle_fixture"] is True
+    else:
+        assert "config4" not in d

@@ -164,12 +164,27 @@ def _run_bench(argv, env_extra=None, timeout=300):
 def test_bench_self_launches_its_ranks(gpus):
     """`python bench.py --gpus N` (no torch.distributed.run, no WORLD_SIZE) spawns its N ranks itself and relays rank 0's single
     JSON line.  `--dry-collective gloo` keeps the launcher, rendezvous, barriers, root all_gather and max-reduce and stubs the GPU."""
-    r, docs = _run_bench(["--gpus", str(gpus), "--steps", "5", "--warmup", "1", "--dry-collective", "gloo"])
+    r, docs = _run_bench(["--gpus", str(gpus), "--steps", "5", "--warmup", "1", "--dry-collective", "gloo", "--cpu-sample-log", "12"])
     assert r.returncode == 0, r.stderr[-2000:]
     assert len(docs) == 1 and r.stdout.count("\n") == 1
     d = docs[0]
     assert d["n_gpus"] == gpus and d["steps"] == 5 and d["dry_run"] is True and d["scaling"] == "weak"
     assert d["roots_gathered"] == gpus * 5
+    # an N > 1 line is self-sufficient (north_star: the CPU figure "in the same run" at 1, 2, 4 and 8 GPUs): rank 0 adds the CPU legs
+    # after the process group is gone, and the single-process frieda_prove_many leg comes from a fresh child process
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0
+    assert cb["multi_core"]["value"] > 0 and cb["multi_core_all"]["all_usable_cores"] is True and cb["multi_core_all"]["cores"] == len(os.sched_getaffinity(0))
+    spm = d["single_process_multi"]
+    assert spm.get("error") is None and spm["dry_run"] is True and spm["devices"] == list(range(gpus))
+    assert "roofline" in d and "roofline_valu" in d
+
+
+def test_bench_single_process_leg_failure_is_reported_in_place():
+    """The extra leg must never cost the line its headline: a child that cannot start its devices is an `error` entry."""
+    r, docs = _run_bench(["--gpus", "2", "--steps", "2", "--dry-collective", "gloo", "--no-cpu-baseline", "--spm-timeout", "0.001"])
+    assert r.returncode == 0 and len(docs) == 1
+    assert "error" in docs[0]["single_process_multi"] and docs[0]["n_gpus"] == 2 and docs[0]["cpu_baseline"] is None
 
 
 def test_bench_under_an_external_launcher_does_not_respawn():
@@ -178,12 +193,16 @@ def test_bench_under_an_external_launcher_does_not_respawn():
 
     port = _free_port()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port",
-           str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--dry-collective", "gloo"]
+           str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--dry-collective", "gloo", "--cpu-sample-log", "10"]
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1 and '"n_gpus": 2' in lines[0]
+    import json
+
+    d = json.loads(lines[0])  # under the driver's launcher the line carries the same blocks
+    assert d["cpu_baseline"]["value"] > 0 and d["single_process_multi"]["dry_run"] is True
 
 
 def test_bench_self_launch_reports_a_failing_rank():
