@@ -135,10 +135,9 @@ def _host_threads():
 def cpu_baseline(sample_log, workload, calls, all_cores_log=22):
     """The CPU oracle (oracle/, a restated port of the reference's single-threaded CPU path; the reference itself is Rust +
     un-vendored stwo and cannot be built here) timed on this host: (1) one thread — the reference has no parallelism at all
-    (stwo pulled without `parallel`, Cargo.toml:12); (2) `multi_core`: one independent blob per thread on min(usable cores, 32)
-    threads (the line says how many and whether that is every usable core)."""
-    from concurrent.futures import ThreadPoolExecutor
-
+    (stwo pulled without `parallel`, Cargo.toml:12); (2) `multi_core` / `multi_core_all`: one independent blob per core on
+    min(usable cores, 32) and on EVERY usable core, one single-threaded worker process each (cpu_multi_child; the
+    line says how many cores and whether that is every usable one)."""
     from oracle import oracle as O
 
     O.build()
@@ -165,36 +164,80 @@ def cpu_baseline(sample_log, workload, calls, all_cores_log=22):
         "sample": f"{calls} x {name} on a 2^{sample_log} domain (same generator and config as the GPU workload), {dt:.1f} s of "
         f"single-thread CPU on a {os.cpu_count()}-core host; restated CPU path (oracle/), not the upstream Rust binary",
     }
-    # many cores: one blob per core, the C calls run outside the GIL (the oracle keeps no shared mutable state)
+    # many cores: one blob per core, one PROCESS per core, from a child interpreter that never touches the GPU (the many-core legs fork
+    # their workers; this process has initialised the GPU and must not be forked)
+    import subprocess
+
+    argv = [sys.executable, os.path.abspath(__file__), "--cpu-multi-child", "--workload", workload, "--cpu-sample-log", str(all_cores_log)]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_PORT")}
+    r = subprocess.run(argv, env=env, capture_output=True, text=True, timeout=900)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    if r.returncode != 0 or len(lines) != 1:
+        raise RuntimeError(f"--cpu-multi-child exited {r.returncode}: {r.stderr[-800:]}")
+    out.update(json.loads(lines[0]))
+    return out
+
+
+def cpu_multi_child(args):
+    """`bench.py --cpu-multi-child`: the many-core legs of the CPU baseline, one independent blob per core, one forked worker PROCESS per
+    core (256 threads of one process serialise on its address-space lock while the oracle's buffers fault in: a 2^20 proof per thread
+    took 25 s on the 256-core GPU host, slower in aggregate than 32 threads).  `multi_core`: min(usable cores, FRIEDA_BENCH_CPU_THREADS =
+    32) workers, one proof of the sample domain each — one GPU's share of an 8-GPU host; `multi_core_all`: EVERY usable core, one 2^20
+    proof each (~45 MB of oracle workspace per worker).  Prints one JSON line."""
+    import multiprocessing as mp
+
+    from oracle import oracle as O
+
+    O.build()
+    O.lib()  # loaded before the fork: the workers inherit it
+    workload = args.workload
+    name = "commit_and_generate_proof" if workload == "prove" else "commit"
     try:
         usable = len(os.sched_getaffinity(0))
     except AttributeError:
         usable = os.cpu_count() or 1
 
-    def leg(threads, log, what):
-        blobs = [splitmix64_bytes(100 + i, blob_len_for(log)) for i in range(threads)]
+    def leg(workers, log, what):
+        ctx = mp.get_context("fork")
+        start, q = ctx.Barrier(workers + 1), ctx.Queue()
+
+        def work(i):
+            from oracle import oracle as O2
+
+            data = splitmix64_bytes(100 + i, blob_len_for(log))
+            cfg = O2.make_config(20, 4, 0, 20)
+            start.wait()
+            root = O2.commit_and_generate_proof(data, data.size, cfg)[0] if workload == "prove" else O2.commit(data, 4)
+            q.put((i, bytes(root).hex()))
+
+        procs = [ctx.Process(target=work, args=(i,)) for i in range(workers)]
+        for p_ in procs:
+            p_.start()
+        start.wait()  # every worker holds its blob and stands at the line
         t0 = time.perf_counter()
-        with ThreadPoolExecutor(max_workers=threads) as ex:
-            roots = list(ex.map(run, blobs))
+        roots = dict(q.get(timeout=800) for _ in range(workers))
         dta = time.perf_counter() - t0
+        for p_ in procs:
+            p_.join(timeout=60)
         return {
-            "value": 4.0 * (1 << log) * threads / dta,
+            "value": 4.0 * (1 << log) * workers / dta,
             "unit": "M31 field-elems/s",
-            "cores": threads,
+            "cores": workers,
             "usable_cores": usable,
-            "all_usable_cores": threads == usable,
+            "all_usable_cores": workers == usable,
             "nproc": os.cpu_count(),
-            "sample": f"{threads} distinct blobs, one {name} on a 2^{log} domain per thread, {threads} threads = {what} this process may run on "
-            f"({usable} of {os.cpu_count()} on the host), {dta:.1f} s wall",
-            "first_root": bytes(roots[0]).hex(),
+            "sample": f"{workers} distinct blobs, one {name} on a 2^{log} domain per worker process, {workers} single-threaded workers = {what} this "
+            f"process may run on ({usable} of {os.cpu_count()} on the host), {dta:.1f} s wall",
+            "first_root": roots[0],
         }
 
-    threads = _host_threads()
-    out["multi_core"] = leg(threads, all_cores_log, "every core" if threads == usable else "a capped share of the cores")
-    # EVERY usable core (north_star: "the GPU box's own host cores"): one smaller proof per thread (~45 MB of oracle workspace each at 2^20)
+    all_cores_log = args.cpu_sample_log
+    workers = _host_threads()
+    out = {"multi_core": leg(workers, all_cores_log, "every core" if workers == usable else "a capped share of the cores")}
     every_log = min(20, all_cores_log)
-    out["multi_core_all"] = out["multi_core"] if (threads == usable and every_log == all_cores_log) else leg(usable, every_log, "every core")
-    return out
+    out["multi_core_all"] = out["multi_core"] if (workers == usable and every_log == all_cores_log) else leg(usable, every_log, "every core")
+    sys.stdout.write(json.dumps(out) + "\n")
+    return 0
 
 
 def reference_bench_sizes(ctx, frieda_amd, torch):
@@ -670,6 +713,7 @@ def parse_args(argv=None):
     ap.add_argument("--dry-collective", choices=["gloo"], default=None,
                     help="CPU rehearsal of the N > 1 plumbing: launcher, rendezvous, barriers, root all_gather and max-reduce over gloo; GPU work stubbed")
     ap.add_argument("--launch-timeout", type=float, default=1500.0, help="seconds the self-launcher waits for its ranks")
+    ap.add_argument("--cpu-multi-child", action="store_true", help="internal: the many-core legs of the CPU baseline (forked workers, no GPU), one JSON line")
     ap.add_argument("--spm-child", action="store_true", help="internal: the single-process multi-GPU leg (frieda_prove_many over --gpus devices), one JSON line")
     ap.add_argument("--spm-devices", default=None, help="device list of the single-process leg, e.g. 0,0 (a device listed twice needs the RCCL test double)")
     ap.add_argument("--spm-blobs-per-gpu", type=int, default=4, help="headline-size blobs per device in the single-process leg")
@@ -794,6 +838,8 @@ def dry_run(args):
 
 def main():
     args = parse_args()
+    if args.cpu_multi_child:
+        sys.exit(cpu_multi_child(args))
     if args.spm_child:
         sys.exit(spm_child(args))
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
