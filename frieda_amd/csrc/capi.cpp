@@ -82,6 +82,8 @@ int frieda_ctx_release_workspace(frieda_ctx* ctx) {
     if (ctx->c.pinned) FR_HIP(&ctx->c, hipHostFree(ctx->c.pinned));
     ctx->c.pinned = nullptr;
     ctx->c.pinned_bytes = 0;
+    if (ctx->c.pinned_in) FR_HIP(&ctx->c, hipHostFree(ctx->c.pinned_in));
+    ctx->c.pinned_in = nullptr;
     ctx->c.drop_twiddles();
     return FRIEDA_OK;
 }

@@ -246,6 +246,7 @@ Ctx::~Ctx() {
     delete timer;
     if (arena) (void)hipFree(arena);
     if (pinned) (void)hipHostFree(pinned);
+    if (pinned_in) (void)hipHostFree(pinned_in);
     if (own_stream && stream) (void)hipStreamDestroy(stream);
 }
 

@@ -91,6 +91,7 @@ struct Ctx {
     size_t arena_bytes = 0;
     void* pinned = nullptr;  // small pinned staging block for D2H of roots / nonces
     size_t pinned_bytes = 0;
+    void* pinned_in = nullptr;  // page-locked input block for lone small host blobs (read by the fused small-domain kernel in place)
     std::string err;
     double phase_ms[8] = {0};  // host wall-clock marks of the last prove() (ms since entry): enqueued, device done, queries, gather, assembled
     KernelTimerImpl* timer = nullptr;  // non-null while kernel timing is enabled

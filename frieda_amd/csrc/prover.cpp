@@ -40,6 +40,15 @@ int ensure_pinned(Ctx* ctx, size_t bytes) {
     return FRIEDA_OK;
 }
 
+// Small host blobs (the fused small-domain kernel, tree.hip) are not copied to the device at all: they are placed in a page-locked
+// block that the kernel reads directly (one PCIe read per workgroup instead of a copy command in front of the first launch).
+constexpr size_t SMALL_HOST_IN_BYTES = 16384;  // >= 15 << SMALL_MAX_LOG_COEF
+int ensure_pinned_in(Ctx* ctx) {
+    if (ctx->pinned_in) return FRIEDA_OK;
+    FR_HIP(ctx, hipHostMalloc(&ctx->pinned_in, SMALL_HOST_IN_BYTES, hipHostMallocDefault));
+    return FRIEDA_OK;
+}
+
 // validated domain shape shared by commit and prove
 struct Shape {
     CodecShape cs;
@@ -127,9 +136,14 @@ int commit_device(Ctx* ctx, const uint8_t* d_data, size_t len, uint32_t log_blow
 
     uint32_t* coef = reinterpret_cast<uint32_t*>(ctx->arena + o_coef);
     uint32_t* eval = reinterpret_cast<uint32_t*>(ctx->arena + o_eval);
-    k::unpack30(ctx->launch(), d_data, len, coef, sh.cs.n_padded);
-    k::encode_and_first_tree(ctx->launch(), coef, (size_t)1 << sh.L, sh.L, sh.n, tw.d_tw, tw.ds, eval, sh.N, nullptr, ctx->arena + o_scr, d_root,
-                             nullptr);
+    if (k::small_domain_shape(sh.L, sh.n)) {
+        k::small_encode_and_first_tree(ctx->launch(), d_data, len, 0, sh.L, sh.n, tw.d_tw, tw.ds, nullptr, 0, nullptr, ctx->arena + o_scr, d_root,
+                                       nullptr, nullptr, 0);
+    } else {
+        k::unpack30(ctx->launch(), d_data, len, coef, sh.cs.n_padded);
+        k::encode_and_first_tree(ctx->launch(), coef, (size_t)1 << sh.L, sh.L, sh.n, tw.d_tw, tw.ds, eval, sh.N, nullptr, ctx->arena + o_scr, d_root,
+                                 nullptr);
+    }
     FR_HIP(ctx, hipGetLastError());
     return FRIEDA_OK;
 }
@@ -151,6 +165,17 @@ int commit_host(Ctx* ctx, const uint8_t* data, size_t len, uint32_t log_blowup, 
     if (rc) return rc;
     rc = ensure_pinned(ctx, 4096);
     if (rc) return rc;
+    if (k::small_domain_shape(sh.L, sh.n) && len <= SMALL_HOST_IN_BYTES) {
+        // no copy commands at all: the kernels read the blob from page-locked host memory and write the root into it
+        rc = ensure_pinned_in(ctx);
+        if (rc) return rc;
+        if (len) memcpy(ctx->pinned_in, data, len);
+        rc = commit_device(ctx, static_cast<const uint8_t*>(ctx->pinned_in), len, log_blowup, static_cast<uint8_t*>(ctx->pinned), true);
+        if (rc) return rc;
+        FR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        memcpy(out_root, ctx->pinned, 32);
+        return FRIEDA_OK;
+    }
     if (len) FR_HIP(ctx, hipMemcpyAsync(ctx->arena + o_data, data, len, hipMemcpyHostToDevice, ctx->stream));
     rc = commit_device(ctx, ctx->arena + o_data, len, log_blowup, ctx->arena + o_root, true);
     if (rc) return rc;
@@ -220,8 +245,13 @@ int commit_batch_begin(Ctx* ctx, const uint8_t* data, size_t data_stride, size_t
     }
     uint32_t* coef = reinterpret_cast<uint32_t*>(A + o_coef);
     uint32_t* eval = reinterpret_cast<uint32_t*>(A + o_eval);
-    k::unpack30(LN, d_data, len, coef, sh.cs.n_padded, d_stride);
-    k::encode_and_first_tree(LN, coef, (size_t)1 << sh.L, sh.L, sh.n, tw.d_tw, tw.ds, eval, sh.N, nullptr, A + o_scr, A + o_root, nullptr);
+    if (k::small_domain_shape(sh.L, sh.n)) {
+        k::small_encode_and_first_tree(LN, d_data, len, d_stride, sh.L, sh.n, tw.d_tw, tw.ds, nullptr, 0, nullptr, A + o_scr, A + o_root, nullptr,
+                                       nullptr, 0);
+    } else {
+        k::unpack30(LN, d_data, len, coef, sh.cs.n_padded, d_stride);
+        k::encode_and_first_tree(LN, coef, (size_t)1 << sh.L, sh.L, sh.n, tw.d_tw, tw.ds, eval, sh.N, nullptr, A + o_scr, A + o_root, nullptr);
+    }
     FR_HIP(ctx, hipMemcpy2DAsync(ctx->pinned, 32, A + o_root, bstride, 32, count, hipMemcpyDeviceToHost, s));
     FR_HIP(ctx, hipGetLastError());
     ctx->commit_pending = count;
@@ -489,19 +519,30 @@ int prove_begin_batch(Ctx* ctx, const uint8_t* data, size_t data_stride, size_t 
     // ---- encode (src/proof.rs:38,44-50) ----
     const uint8_t* d_data = data;
     size_t d_data_stride = data_stride;
+    const bool small = k::small_domain_shape(sh.L, n) && !ctx->host_channel && last_log <= k::TAIL_LOG;
     if (!data_on_device) {
-        if (len && host_ptrs) {
-            for (uint32_t b = 0; b < count; b++) FR_HIP(ctx, hipMemcpyAsync(A + o_data + (size_t)b * bstride, host_ptrs[b], len, hipMemcpyHostToDevice, s));
+        if (small && count == 1 && len <= SMALL_HOST_IN_BYTES) {
+            // a lone small blob is not copied to the device: the first kernel reads it from page-locked host memory
+            rc = ensure_pinned_in(ctx);
+            if (rc) return rc;
+            const uint8_t* src = host_ptrs ? host_ptrs[0] : data;
+            if (len) memcpy(ctx->pinned_in, src, len);
+            d_data = static_cast<const uint8_t*>(ctx->pinned_in);
+            d_data_stride = 0;
         } else {
-            if (len && count == 1) FR_HIP(ctx, hipMemcpyAsync(A + o_data, data, len, hipMemcpyHostToDevice, s));
-            if (len && count > 1) FR_HIP(ctx, hipMemcpy2DAsync(A + o_data, bstride, data, data_stride, len, count, hipMemcpyHostToDevice, s));
+            if (len && host_ptrs) {
+                for (uint32_t b = 0; b < count; b++) FR_HIP(ctx, hipMemcpyAsync(A + o_data + (size_t)b * bstride, host_ptrs[b], len, hipMemcpyHostToDevice, s));
+            } else {
+                if (len && count == 1) FR_HIP(ctx, hipMemcpyAsync(A + o_data, data, len, hipMemcpyHostToDevice, s));
+                if (len && count > 1) FR_HIP(ctx, hipMemcpy2DAsync(A + o_data, bstride, data, data_stride, len, count, hipMemcpyHostToDevice, s));
+            }
+            d_data = A + o_data;
+            d_data_stride = bstride;
         }
-        d_data = A + o_data;
-        d_data_stride = bstride;
     }
     uint32_t* coef = reinterpret_cast<uint32_t*>(A + o_coef);
     uint32_t* eval = reinterpret_cast<uint32_t*>(A + first.o_vals);
-    k::unpack30(LN, d_data, len, coef, sh.cs.n_padded, d_data_stride);
+    if (!small) k::unpack30(LN, d_data, len, coef, sh.cs.n_padded, d_data_stride);
     ctx->phase_ms[5] = ms_since(t_entry);  // set-up before the first launch (workspace plan, twiddle lookup, ...) + that launch call
 
     for (uint32_t b = 0; b < count; b++) {
@@ -531,9 +572,14 @@ int prove_begin_batch(Ctx* ctx, const uint8_t* data, size_t data_stride, size_t 
             // no copy in the stream: the kernel that finishes the first tree reads these few words from the pinned block itself
             // (the block is next written by the transcript download behind the grind, i.e. after that kernel)
         }
-        // the encode's last pass runs fused with FriProver::commit_first_layer's leaf hashing (src/proof.rs:48-52)
-        k::encode_and_first_tree(LN, coef, (size_t)1 << sh.L, sh.L, n, tw.d_tw, tw.ds, eval, N, A + first.o_tree, nullptr, nullptr, d_tr,
-                                 reinterpret_cast<const DevTranscript*>(ctx->pinned), tr_host_pitch);
+        // the encode's last pass runs fused with FriProver::commit_first_layer's leaf hashing (src/proof.rs:48-52); small domains: unpack +
+        // encode + first tree in one launch, straight from the blob
+        if (small)
+            k::small_encode_and_first_tree(LN, d_data, len, d_data_stride, sh.L, n, tw.d_tw, tw.ds, eval, N, A + first.o_tree, nullptr, nullptr, d_tr,
+                                           reinterpret_cast<const DevTranscript*>(ctx->pinned), tr_host_pitch);
+        else
+            k::encode_and_first_tree(LN, coef, (size_t)1 << sh.L, sh.L, n, tw.d_tw, tw.ds, eval, N, A + first.o_tree, nullptr, nullptr, d_tr,
+                                     reinterpret_cast<const DevTranscript*>(ctx->pinned), tr_host_pitch);
         // FriProver::commit_inner_layers: layers above 2^11 points, one fused fold + tree each
         const FriLayerDev* cur = &first;
         bool circle = true;

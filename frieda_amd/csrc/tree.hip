@@ -546,6 +546,34 @@ __device__ uint32_t channel_after_root_quad(DevTranscript* tr, ChanRegs& cr, uin
 // of launches: a tree of 2^m leaves, m <= 17, is this launch plus the top kernel.
 constexpr uint32_t T9_LEVELS = 9;
 
+// Levels B .. (T9_LEVELS - 1) of a 256-node workgroup whose level-A hashes sit in RA (struct of arrays): 128 nodes one per lane,
+// then 64 .. 1 nodes one per quad.  Shared by tree9_kernel and the fused small-domain kernel below.
+__device__ __forceinline__ void tree9_upper(const TreeArgs& a, const uint32_t* RA, uint32_t* QQ, const QuadCtx& x, size_t wg_base, uint32_t t,
+                                            uint32_t q, uint32_t quad) {
+    // ---- level B (128 nodes): one per lane, results in the quad layout ----
+    if (t < 128) {
+        uint32_t m[16], h[8];
+        lds_children(RA, 256 + 4, t, m);
+        b2_merkle_block(m, h);
+        if (a.store_all) store_hash(a.layers + layer_off(a.tree_log, a.level_a - 1), (wg_base >> 1) + t, h);
+        q_put_hash(QQ, t, h);
+    }
+    __syncthreads();
+    // ---- levels of 64, 32, ..., 1 nodes: one per quad ----
+#pragma unroll
+    for (uint32_t l = 2; l < T9_LEVELS; l += 2) {
+        {
+            const bool last = l + 1 == T9_LEVELS;
+            uint8_t* gout = a.store_all ? a.layers + layer_off(a.tree_log, a.level_a - l) : (last ? a.last_out : nullptr);
+            quad_level<0>(QQ, x, quad < (256u >> l), gout, (wg_base >> l) + quad, q, !last);
+        }
+        if (l + 1 < T9_LEVELS) {
+            uint8_t* gout = a.store_all ? a.layers + layer_off(a.tree_log, a.level_a - (l + 1)) : nullptr;
+            quad_level<1>(QQ, x, quad < (256u >> (l + 1)), gout, (wg_base >> (l + 1)) + quad, q, true);
+        }
+    }
+}
+
 template <int MODE>
 __global__ __launch_bounds__(256) void tree9_kernel(TreeArgs a) {
     __shared__ __attribute__((aligned(16))) uint32_t RA[8 * (256 + 4)];
@@ -580,29 +608,140 @@ __global__ __launch_bounds__(256) void tree9_kernel(TreeArgs a) {
         lds_put(RA, 256 + 4, t, h);
     }
     __syncthreads();
-    // ---- level B (128 nodes): one per lane, results in the quad layout ----
-    if (t < 128) {
-        uint32_t m[16], h[8];
-        lds_children(RA, 256 + 4, t, m);
-        b2_merkle_block(m, h);
-        if (a.store_all) store_hash(a.layers + layer_off(a.tree_log, a.level_a - 1), (wg_base >> 1) + t, h);
-        q_put_hash(QQ, t, h);
+    tree9_upper(a, RA, QQ, x, wg_base, t, q, quad);
+}
+
+// ------------------------------------------------------------------------------------------------
+// small domains: unpack + encode + leaf hashes + nine tree levels in ONE launch
+// ------------------------------------------------------------------------------------------------
+// The reference's own bench inputs are 1 KiB .. 64 KiB (benches/commit.rs:6-10, benches/proof.rs:14-21): a 1 KiB blob is 2^7
+// coefficients per column on a 2^11 domain, and `commit` on it was four dependent launches of kernels shaped for megabytes (unpack 8.7
+// us, transform 15.4, tree 14.9, top 7.6).  For domains of 2^8 .. 2^13 points and polynomials of <= 2^9 coefficients a workgroup here
+// owns 256 consecutive evaluations of the bit-reversed domain and does everything for them: it stages the blob (<= 7.5 KB) in LDS,
+// unpacks the 30-bit felts (src/utils.rs:10-33), runs the circle FFT of its block — a block of 2^L consecutive outputs is an
+// independent size-2^L transform of the coefficient vector with that block's twiddles (ntt.hip, "Structure"); for L = 9 the one layer
+// that crosses workgroups is computed in its one-output form, c[j] +- T c[j + 256] —, hashes its 256 leaves and reduces them to one
+// hash exactly as tree9_kernel does.  The top kernel finishes the <= 32 hashes.  Same results, word for word, as the general path.
+constexpr uint32_t SMALL_MAX_LOG_COEF = 9, SMALL_MIN_LOG_DOMAIN = 8, SMALL_MAX_LOG_DOMAIN = 13;
+
+struct SmallFirstArgs {
+    const uint8_t* data;  // blob bytes: device memory or page-locked host memory (read once per workgroup)
+    size_t len, data_stride;
+    uint32_t L, n, init_y;
+    const uint32_t* tw;
+    uint32_t* eval;  // non-null (generate_proof): the evaluation, 4 columns of 2^n words
+    size_t eval_stride;
+    TreeArgs tree;  // store_all / layers / tree_log / level_a / last_out / skip_a / bstride
+};
+
+namespace {
+__device__ __forceinline__ uint32_t circle_twiddle_fwd(const uint32_t* __restrict__ tw, uint32_t h) {  // n >= 3: pairs (x, y) -> [y, -y, -x, x]
+    const uint32_t j = h >> 2, r = h & 3u;
+    const uint32_t v = tw[2 * j + (r < 2 ? 1 : 0)];
+    return (r == 1 || r == 2) ? m31_neg(v) : v;
+}
+
+__global__ __launch_bounds__(256) void small_first_kernel(SmallFirstArgs a) {
+    __shared__ __attribute__((aligned(16))) uint32_t BL[(15u << SMALL_MAX_LOG_COEF) / 4 + 4];  // the blob, zero beyond len, + a spare word
+    __shared__ __attribute__((aligned(16))) uint32_t CO[4u << SMALL_MAX_LOG_COEF];             // coefficients, column c at c << L
+    __shared__ __attribute__((aligned(16))) uint32_t V[4][256];
+    __shared__ __attribute__((aligned(16))) uint32_t RA[8 * (256 + 4)];
+    __shared__ __attribute__((aligned(16))) uint32_t QQ[2 * QBUF_WORDS];
+    latency_kernel_priority();
+    TreeArgs ta = a.tree;
+    tree_args_of_blob(ta);
+    const uint8_t* in = a.data + (size_t)blockIdx.y * a.data_stride;
+    uint32_t* eval = a.eval ? reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(a.eval) + (size_t)blockIdx.y * a.tree.bstride) : nullptr;
+    const uint32_t t = threadIdx.x, q = t & 3, quad = t >> 2, w = blockIdx.x;
+    const uint32_t L = a.L, n = a.n;
+    QuadCtx x;
+    quad_ctx_init(x, quad, q);
+    // ---- the bytes that can matter: 4 * 2^L felts of 30 bits ----
+    const uint32_t need_w = ((15u << L) + 3) / 4;
+    const size_t len = a.len;
+    const bool al4 = (reinterpret_cast<uintptr_t>(in) & 3) == 0;
+    for (uint32_t i = t; i < need_w; i += 256) {
+        const size_t b = 4 * (size_t)i;
+        uint32_t v = 0;
+        if (al4 && b + 4 <= len) {
+            v = reinterpret_cast<const uint32_t*>(in)[i];
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                if (b + k < len) v |= (uint32_t)in[b + k] << (8 * k);
+        }
+        BL[i] = v;
+    }
+    if (t == 0) BL[need_w] = 0;
+    // ---- the twiddles of this thread's butterflies, requested before the first barrier: layer i pairs tile elements i0, i0 + 2^i ----
+    const uint32_t top = L < 8 ? L : 8;  // layers 7 .. top of the block are replication (the coefficient vector is zero above 2^L)
+    const uint32_t p = t & 127, cb = t >> 7;
+    const uint32_t e = 256 * w + t;
+    uint32_t twd[8], t9 = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        twd[i] = 0;
+        if ((uint32_t)i < top) {
+            const uint32_t i0 = ((p >> i) << (i + 1)) | (p & ((1u << i) - 1));
+            const uint32_t h = (256 * w + i0) >> (i + 1);
+            twd[i] = i >= 1 ? a.tw[tw_level_offset_dev(n, (uint32_t)i - 1) + h] : circle_twiddle_fwd(a.tw, h);
+        }
+    }
+    if (L == 9) t9 = a.tw[tw_level_offset_dev(n, 7) + (e >> 9)];
+    __syncthreads();
+    // ---- bytes_to_felt_le: felt k = bits [30 k, 30 k + 30) ----
+    for (uint32_t k = t; k < (4u << L); k += 256) {
+        const uint32_t bit0 = 30 * k, wi = bit0 >> 5, sh = bit0 & 31;
+        const uint64_t acc = (uint64_t)BL[wi] | ((uint64_t)BL[wi + 1] << 32);
+        CO[k] = (uint32_t)(acc >> sh) & 0x3FFFFFFFu;
     }
     __syncthreads();
-    // ---- levels of 64, 32, ..., 1 nodes: one per quad ----
+    // ---- element e of the block entering layer min(L, 8) - 1 ----
 #pragma unroll
-    for (uint32_t l = 2; l < T9_LEVELS; l += 2) {
-        {
-            const bool last = l + 1 == T9_LEVELS;
-            uint8_t* gout = a.store_all ? a.layers + layer_off(a.tree_log, a.level_a - l) : (last ? a.last_out : nullptr);
-            quad_level<0>(QQ, x, quad < (256u >> l), gout, (wg_base >> l) + quad, q, !last);
+    for (int c = 0; c < 4; c++) {
+        const uint32_t* cc = CO + ((uint32_t)c << L);
+        uint32_t v;
+        if (L <= 8) {
+            v = cc[t & ((1u << L) - 1)];
+        } else {  // L == 9: layer 8 pairs e with e ^ 256, which another workgroup owns: our output of that butterfly alone
+            const uint32_t tt = m31_mul(cc[t + 256], t9);
+            v = (w & 1u) ? m31_sub(cc[t], tt) : m31_add(cc[t], tt);
         }
-        if (l + 1 < T9_LEVELS) {
-            uint8_t* gout = a.store_all ? a.layers + layer_off(a.tree_log, a.level_a - (l + 1)) : nullptr;
-            quad_level<1>(QQ, x, quad < (256u >> (l + 1)), gout, (wg_base >> (l + 1)) + quad, q, true);
+        V[c][t] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 7; i >= 0; i--) {
+        if ((uint32_t)i < top) {  // uniform
+            const uint32_t i0 = ((p >> i) << (i + 1)) | (p & ((1u << i) - 1)), i1 = i0 + (1u << i);
+#pragma unroll
+            for (int cc = 0; cc < 2; cc++) {
+                uint32_t* col = V[cb + 2 * cc];
+                const uint32_t x0 = col[i0], tt = m31_mul(col[i1], twd[i]);
+                col[i0] = m31_add(x0, tt);
+                col[i1] = m31_sub(x0, tt);
+            }
+            __syncthreads();
         }
     }
+    // ---- leaves, then the nine levels of tree9 ----
+    const uint32_t v0 = V[0][t], v1 = V[1][t], v2 = V[2][t], v3 = V[3][t];
+    if (eval) {
+        eval[e] = v0;
+        eval[a.eval_stride + e] = v1;
+        eval[2 * a.eval_stride + e] = v2;
+        eval[3 * a.eval_stride + e] = v3;
+    }
+    {
+        uint32_t h[8];
+        leaf_hash(v0, v1, v2, v3, h);
+        if (ta.store_all && !ta.skip_a) store_hash(ta.layers + layer_off(ta.tree_log, ta.level_a), e, h);
+        lds_put(RA, 256 + 4, t, h);
+    }
+    __syncthreads();
+    tree9_upper(ta, RA, QQ, x, (size_t)256 * w, t, q, quad);
 }
+}  // namespace
 
 // ------------------------------------------------------------------------------------------------
 // tree7q: the narrow middle of a tree (<= 32768 level-A nodes) hashed by quads across many workgroups
@@ -1163,6 +1302,43 @@ void encode_and_first_tree(const Launch& L, const uint32_t* d_coef, size_t coef_
     a.bstride = L.bstride;
     const uint32_t cur = n - (fused - 1);
     finish_tree(L, a, n, cur, d_layers ? d_layers + merkle_layer_offset(n, cur) : s0, s0, s1, d_root, tr, tr_init, tr_init_pitch);
+}
+
+bool small_domain_shape(uint32_t Lc, uint32_t n) {
+    static const bool off = getenv("FRIEDA_NO_SMALL_FUSED") != nullptr;  // A/B knob: the general path for every size
+    return !off && n >= SMALL_MIN_LOG_DOMAIN && n <= SMALL_MAX_LOG_DOMAIN && Lc <= SMALL_MAX_LOG_COEF && Lc <= n;
+}
+
+void small_encode_and_first_tree(const Launch& L, const uint8_t* d_data, size_t len, size_t data_stride, uint32_t Lc, uint32_t n,
+                                 const uint32_t* d_tw, DomainScalars ds, uint32_t* d_eval, size_t eval_stride, uint8_t* d_layers,
+                                 uint8_t* d_scratch, uint8_t* d_root, DevTranscript* tr, const DevTranscript* tr_init, size_t tr_init_pitch) {
+    uint8_t* s0 = d_scratch;
+    uint8_t* s1 = d_scratch ? d_scratch + ((size_t)32 << (n > 4 ? n - 4 : 0)) : nullptr;
+    SmallFirstArgs a{};
+    a.data = d_data;
+    a.len = len;
+    a.data_stride = data_stride;
+    a.L = Lc;
+    a.n = n;
+    a.init_y = ds.init_y;
+    a.tw = d_tw;
+    a.eval = d_eval;
+    a.eval_stride = eval_stride;
+    a.tree.tree_log = n;
+    a.tree.level_a = n;
+    a.tree.layers = d_layers;
+    a.tree.store_all = d_layers != nullptr;
+    a.tree.skip_a = d_layers != nullptr;  // the prover never reads the leaf hashes (plan_merkle_decommit, prover.cpp)
+    a.tree.last_out = s0;
+    a.tree.bstride = L.bstride;
+    const double N = (double)((size_t)1 << n);
+    {
+        // algorithmic bytes: the blob + the encode (16 N (1 + 2^-B)) + leaves (16 B in, 32 B out) + 8 node levels
+        Scope scope(L, "small_first", (double)len + 4.0 * 4.0 * (N + (double)((size_t)1 << Lc)) + 48.0 * N + node_levels_bytes(n - 1, T9_LEVELS - 1));
+        small_first_kernel<<<dim3(1u << (n - 8), L.batch), 256, 0, L.stream>>>(a);
+    }
+    const uint32_t cur = n - (T9_LEVELS - 1);
+    finish_tree(L, a.tree, n, cur, d_layers ? d_layers + merkle_layer_offset(n, cur) : s0, s0, s1, d_root, tr, tr_init, tr_init_pitch);
 }
 
 void merkle_tree4(const Launch& L, const uint32_t* c0, const uint32_t* c1, const uint32_t* c2, const uint32_t* c3, uint32_t m,
