@@ -137,6 +137,8 @@ extern "C" {
     pub fn frieda_merkle_root(ctx: *mut frieda_ctx, d_cols: *const u32, log_size: u32, d_root: *mut c_void) -> c_int;
     pub fn frieda_fold_circle_into_line(ctx: *mut frieda_ctx, d_dst: *mut u32, d_src: *const u32, log_domain: u32, alpha: *const u32) -> c_int;
     pub fn frieda_fold_line(ctx: *mut frieda_ctx, d_src: *const u32, line_log: u32, log_domain: u32, alpha: *const u32, d_dst: *mut u32) -> c_int;
+    /// evaluate + fold_circle_into_line + one fold_line in one pass over the evaluation (both challenges known to the caller)
+    pub fn frieda_circle_evaluate_fold2(ctx: *mut frieda_ctx, d_coeffs: *const u32, log_size: u32, log_domain: u32, d_evals: *mut u32, alpha0: *const u32, accumulate_line1: c_int, d_line1: *mut u32, alpha1: *const u32, d_line2: *mut u32) -> c_int;
     pub fn frieda_grind(ctx: *mut frieda_ctx, digest: *const u8, pow_bits: u32, nonce: *mut u64) -> c_int;
 }
 

@@ -141,6 +141,7 @@ def lib():
         "frieda_merkle_root": (C.c_int, [vp, vp, u32, vp]),
         "frieda_fold_circle_into_line": (C.c_int, [vp, vp, vp, u32, vp]),
         "frieda_fold_line": (C.c_int, [vp, vp, u32, u32, vp, vp]),
+        "frieda_circle_evaluate_fold2": (C.c_int, [vp, vp, u32, u32, vp, vp, C.c_int, vp, vp, vp]),
         "frieda_grind": (C.c_int, [vp, vp, u32, u64p]),
     }
     for name, (res, args) in sig.items():

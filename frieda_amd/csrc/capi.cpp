@@ -705,6 +705,31 @@ int frieda_fold_circle_into_line(frieda_ctx* ctx, uint32_t* d_dst, const uint32_
     FR_GUARD_END(ctx)
 }
 
+int frieda_circle_evaluate_fold2(frieda_ctx* ctx, const uint32_t* d_coeffs, uint32_t log_size, uint32_t log_domain, uint32_t* d_evals,
+                                 const uint32_t alpha0[4], int accumulate_line1, uint32_t* d_line1, const uint32_t alpha1[4], uint32_t* d_line2) {
+    if (!ctx || !d_coeffs || !d_evals || !alpha0 || !alpha1 || !d_line1 || !d_line2 || log_domain < 2 || log_domain > FRIEDA_MAX_LOG_DOMAIN ||
+        log_size > log_domain)
+        return FRIEDA_ERR_ARG;
+    FR_GUARD_BEGIN
+    for (int i = 0; i < 4; i++)
+        if (alpha0[i] >= P31 || alpha1[i] >= P31) return ctx->c.fail(FRIEDA_ERR_ARG, "alpha coordinates must be canonical M31 values");
+    FR_HIP(&ctx->c, hipSetDevice(ctx->c.device));
+    TwiddleSet ts;
+    int rc = ctx->c.get_twiddles(log_domain, ts);
+    if (rc) return rc;
+    k::EncodeFoldSink fs{};
+    fs.itw = ts.d_itw;
+    for (int i = 0; i < 4; i++) fs.alpha0[i] = alpha0[i], fs.alpha1[i] = alpha1[i];
+    fs.accumulate = accumulate_line1 != 0;
+    fs.line1 = d_line1;
+    fs.line2 = d_line2;
+    (void)k::circle_evaluate_fold2(ctx->c.launch(), d_coeffs, (size_t)1 << log_size, log_size, log_domain, ts.d_tw, ts.ds, d_evals,
+                                   (size_t)1 << log_domain, fs);
+    FR_HIP(&ctx->c, hipGetLastError());
+    return FRIEDA_OK;
+    FR_GUARD_END(ctx)
+}
+
 int frieda_fold_line(frieda_ctx* ctx, const uint32_t* d_src, uint32_t line_log, uint32_t log_domain, const uint32_t alpha[4],
                      uint32_t* d_dst) {
     if (!ctx || !d_dst || !d_src || !alpha || line_log < 1 || log_domain < 2 || line_log > log_domain - 1 ||

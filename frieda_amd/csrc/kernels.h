@@ -95,6 +95,18 @@ struct EncodeTreeSink {
     uint8_t* last_out;
 };
 constexpr uint32_t ENCODE_TREE_LEVELS = 7;
+// PolyOps::evaluate of the four coordinate columns + FriOps::fold_circle_into_line (alpha0; `accumulate`: line1 = line1 * alpha0^2 + fold,
+// the trait's form, else line1 = fold) + one FriOps::fold_line (alpha1) — the folds ride in the transform's last pass when the shape
+// allows (>= 2^12 coefficients per column, 16-byte aligned buffers: returns true), separate launches otherwise (returns false).
+struct EncodeFoldSink {
+    const uint32_t* itw;
+    uint32_t alpha0[4], alpha1[4];
+    bool accumulate;
+    uint32_t* line1;
+    uint32_t* line2;
+};
+bool circle_evaluate_fold2(const Launch& L_, const uint32_t* d_coef, size_t coef_stride, uint32_t L, uint32_t n, const uint32_t* d_tw,
+                           DomainScalars ds, uint32_t* d_out, size_t out_stride, const EncodeFoldSink& fs);
 uint32_t circle_evaluate_into_tree(const Launch& L_, const uint32_t* d_coef, size_t coef_stride, uint32_t ncols, uint32_t L, uint32_t n,
                                const uint32_t* d_tw, DomainScalars ds, uint32_t* d_out, size_t out_stride, const EncodeTreeSink* sink);
 

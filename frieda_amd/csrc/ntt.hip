@@ -465,22 +465,13 @@ struct NttTreeArgs {
 };
 
 
-FR_CLOCK_DECL(g_clock_ntt_last_tree)
-// REG_ONLY: stop after the five register levels (256 nodes of level n - 4 per workgroup): see tree5r_kernel in tree.hip
-template <bool STORE_ALL, bool REG_ONLY = false>
-__global__ __launch_bounds__(NTT_THREADS) void ntt_last_tree_kernel(NttTreeArgs A) {
-    __shared__ uint32_t lds[TILE_WORDS];
-    __shared__ __attribute__((aligned(16))) uint32_t RC[8 * (256 + 4)];
-    __shared__ __attribute__((aligned(16))) uint32_t RD[8 * (128 + 4)];
-    const NttArgs& a = A.a;
-    uint32_t g_tie = threadIdx.x;
-    FR_CLOCK_BEGIN(g_tie)
-    const uint32_t g = g_tie;
-    const uint32_t hblk = blockIdx.x;  // i_hi == 11, i_lo == 0, log_w == 0: one contiguous 4096-word tile per workgroup
+// The contiguous last pass (layers 11 .. 0, one 4096-word tile per column) on all four coordinate columns of workgroup `hblk`, the
+// results kept in registers: v[c][r] = column c at tile element 16 g + r (global index (hblk << 12) + 16 g + r).  Shared by the
+// kernel that hashes them (ntt_last_tree_kernel) and the one that folds them (ntt_last_fold_kernel).
+template <bool STORE_ALL>
+__device__ __forceinline__ void last_pass_four_columns(const NttArgs& a, uint32_t* lds, uint32_t g, uint32_t hblk, const uint32_t* in, uint32_t* out,
+                                                       uint32_t (&v)[4][16]) {
     const uint32_t gbase = hblk << TILE_LOG;
-    const uint32_t* in = a.in + blockIdx.z * a.bstride_w;
-    uint32_t* out = a.out + blockIdx.z * a.bstride_w;
-
     uint32_t pbase[3];
     uint32_t twd[3][15];
 #pragma unroll
@@ -512,7 +503,6 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_last_tree_kernel(NttTreeArgs 
 #pragma unroll
     for (int kk = 0; kk < 4; kk++) pre[kk] = *reinterpret_cast<const uint4*>(in + ((gbase | piece_e(kk)) & a.in_mask));
 
-    uint32_t v[4][16];  // the thread's 16 consecutive points (tile elements 16 g .. 16 g + 15) of every column
 #pragma unroll
     for (int c = 0; c < 4; c++) {
 #pragma unroll
@@ -566,6 +556,27 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_last_tree_kernel(NttTreeArgs 
             o[3] = make_uint4(v[c][12], v[c][13], v[c][14], v[c][15]);
         }
     }
+
+}
+
+FR_CLOCK_DECL(g_clock_ntt_last_tree)
+// REG_ONLY: stop after the five register levels (256 nodes of level n - 4 per workgroup): see tree5r_kernel in tree.hip
+template <bool STORE_ALL, bool REG_ONLY = false>
+__global__ __launch_bounds__(NTT_THREADS) void ntt_last_tree_kernel(NttTreeArgs A) {
+    __shared__ uint32_t lds[TILE_WORDS];
+    __shared__ __attribute__((aligned(16))) uint32_t RC[8 * (256 + 4)];
+    __shared__ __attribute__((aligned(16))) uint32_t RD[8 * (128 + 4)];
+    const NttArgs& a = A.a;
+    uint32_t g_tie = threadIdx.x;
+    FR_CLOCK_BEGIN(g_tie)
+    const uint32_t g = g_tie;
+    const uint32_t hblk = blockIdx.x;  // i_hi == 11, i_lo == 0, log_w == 0: one contiguous 4096-word tile per workgroup
+    const uint32_t gbase = hblk << TILE_LOG;
+    const uint32_t* in = a.in + blockIdx.z * a.bstride_w;
+    uint32_t* out = a.out + blockIdx.z * a.bstride_w;
+
+    uint32_t v[4][16];  // the thread's 16 consecutive points (tile elements 16 g .. 16 g + 15) of every column
+    last_pass_four_columns<STORE_ALL>(a, lds, g, hblk, in, out, v);
 
     // ---- 16 leaves -> 1 node of level n - 4, in registers ----
     const uint32_t m = a.n;
@@ -671,13 +682,88 @@ void set_stages(NttArgs& a, uint32_t t) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The last transform pass fused with the first FRI fold round (Level B: frieda_circle_evaluate_fold2)
+// ------------------------------------------------------------------------------------------------
+// The same workgroup-holds-4096-points-of-all-four-coordinates situation, folded instead of hashed: a thread's 16 consecutive points
+// are 8 pairs of fold_circle_into_line, whose 8 results are 4 pairs of the first fold_line (stwo backend/cpu/fri.rs; the pairs
+// (2i, 2i + 1) of the bit-reversed order are adjacent).  The evaluation, the first line layer and the second leave in one pass over
+// the tile: 16-byte stores only, nothing re-read.  ACC: FriOps::fold_circle_into_line's accumulate form, dst = dst * alpha^2 + fold.
+struct NttFoldArgs {
+    NttArgs a;
+    const uint32_t* itw;
+    uint32_t inv_init_y;
+    uint32_t alpha0[4], alpha1[4];
+    uint32_t* line1;  // 4 coordinate columns of 2^(n-1) words
+    uint32_t* line2;  // 4 coordinate columns of 2^(n-2) words
+};
+
+template <bool ACC>
+__global__ __launch_bounds__(NTT_THREADS) void ntt_last_fold_kernel(NttFoldArgs A) {
+    __shared__ uint32_t lds[TILE_WORDS];
+    const NttArgs& a = A.a;
+    const uint32_t g = threadIdx.x, hblk = blockIdx.x;
+    uint32_t v[4][16];
+    last_pass_four_columns<true>(a, lds, g, hblk, a.in, a.out, v);
+    const uint32_t n = a.n;
+    const size_t e0 = ((size_t)hblk << TILE_LOG) + 16u * g;  // this thread's first point
+    const QM31Mat am0 = qm_matrix({A.alpha0[0], A.alpha0[1], A.alpha0[2], A.alpha0[3]});
+    const QM31Mat am1 = qm_matrix({A.alpha1[0], A.alpha1[1], A.alpha1[2], A.alpha1[3]});
+    // inverse twiddles: circle pairs i = e0 / 2 + k read inverse-Y[i] = [iy, -iy, -ix, ix] from inverse level 0 (two (x, y) pairs
+    // cover the 8); line pairs j = e0 / 4 + k read inverse level 0 at j (the same four words)
+    const uint4 t0 = *reinterpret_cast<const uint4*>(A.itw + (e0 >> 2));
+    const uint32_t ix[2] = {t0.x, t0.z}, iy[2] = {t0.y, t0.w};
+    const uint32_t il[4] = {t0.x, t0.y, t0.z, t0.w};
+    const size_t s1 = (size_t)1 << (n - 1), s2 = (size_t)1 << (n - 2);
+    QM31 l1[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const int pr = k >> 2, r = k & 3;
+        const uint32_t it = r == 0 ? iy[pr] : (r == 1 ? m31_neg(iy[pr]) : (r == 2 ? m31_neg(ix[pr]) : ix[pr]));
+        l1[k] = qm_fold_pair(QM31{v[0][2 * k], v[1][2 * k], v[2][2 * k], v[3][2 * k]},
+                             QM31{v[0][2 * k + 1], v[1][2 * k + 1], v[2][2 * k + 1], v[3][2 * k + 1]}, it, am0);
+    }
+    uint32_t* d1 = A.line1 + (e0 >> 1);
+    if (ACC) {
+        const QM31 al = {A.alpha0[0], A.alpha0[1], A.alpha0[2], A.alpha0[3]};
+        const QM31 asq = qm_mul(al, al);
+        uint4 o[4][2];
+#pragma unroll
+        for (int c = 0; c < 4; c++) o[c][0] = reinterpret_cast<const uint4*>(d1 + c * s1)[0], o[c][1] = reinterpret_cast<const uint4*>(d1 + c * s1)[1];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            auto w = [&](int c) { const uint4 q4 = o[c][k >> 2]; return (k & 3) == 0 ? q4.x : ((k & 3) == 1 ? q4.y : ((k & 3) == 2 ? q4.z : q4.w)); };
+            l1[k] = qm_add(qm_mul(QM31{w(0), w(1), w(2), w(3)}, asq), l1[k]);
+        }
+    }
+    {
+        uint4* p0 = reinterpret_cast<uint4*>(d1);
+        uint4* p1 = reinterpret_cast<uint4*>(d1 + s1);
+        uint4* p2 = reinterpret_cast<uint4*>(d1 + 2 * s1);
+        uint4* p3 = reinterpret_cast<uint4*>(d1 + 3 * s1);
+        p0[0] = make_uint4(l1[0].a, l1[1].a, l1[2].a, l1[3].a), p0[1] = make_uint4(l1[4].a, l1[5].a, l1[6].a, l1[7].a);
+        p1[0] = make_uint4(l1[0].b, l1[1].b, l1[2].b, l1[3].b), p1[1] = make_uint4(l1[4].b, l1[5].b, l1[6].b, l1[7].b);
+        p2[0] = make_uint4(l1[0].c, l1[1].c, l1[2].c, l1[3].c), p2[1] = make_uint4(l1[4].c, l1[5].c, l1[6].c, l1[7].c);
+        p3[0] = make_uint4(l1[0].d, l1[1].d, l1[2].d, l1[3].d), p3[1] = make_uint4(l1[4].d, l1[5].d, l1[6].d, l1[7].d);
+    }
+    QM31 l2[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) l2[k] = qm_fold_pair(l1[2 * k], l1[2 * k + 1], il[k], am1);
+    uint32_t* d2 = A.line2 + (e0 >> 2);
+    *reinterpret_cast<uint4*>(d2) = make_uint4(l2[0].a, l2[1].a, l2[2].a, l2[3].a);
+    *reinterpret_cast<uint4*>(d2 + s2) = make_uint4(l2[0].b, l2[1].b, l2[2].b, l2[3].b);
+    *reinterpret_cast<uint4*>(d2 + 2 * s2) = make_uint4(l2[0].c, l2[1].c, l2[2].c, l2[3].c);
+    *reinterpret_cast<uint4*>(d2 + 3 * s2) = make_uint4(l2[0].d, l2[1].d, l2[2].d, l2[3].d);
+}
+
 }  // namespace
 
 FR_CLOCK_READER(frieda_debug_clock_ntt_last_tree, g_clock_ntt_last_tree)
 
 namespace {
 uint32_t evaluate_plan(const Launch& L_, const uint32_t* d_coef, size_t coef_stride, uint32_t ncols, uint32_t L, uint32_t n, uint32_t out_log,
-                       const uint32_t* d_tw, DomainScalars ds, uint32_t* d_out, size_t out_stride, const EncodeTreeSink* sink);
+                       const uint32_t* d_tw, DomainScalars ds, uint32_t* d_out, size_t out_stride, const EncodeTreeSink* sink,
+                       const EncodeFoldSink* fsink = nullptr);
 }
 
 void circle_evaluate(const Launch& L_, const uint32_t* d_coef, size_t coef_stride, uint32_t ncols, uint32_t L, uint32_t n,
@@ -695,13 +781,26 @@ uint32_t circle_evaluate_into_tree(const Launch& L_, const uint32_t* d_coef, siz
     return evaluate_plan(L_, d_coef, coef_stride, ncols, L, n, n, d_tw, ds, d_out, out_stride, sink);
 }
 
+bool circle_evaluate_fold2(const Launch& L_, const uint32_t* d_coef, size_t coef_stride, uint32_t L, uint32_t n, const uint32_t* d_tw,
+                           DomainScalars ds, uint32_t* d_out, size_t out_stride, const EncodeFoldSink& fs) {
+    if (evaluate_plan(L_, d_coef, coef_stride, 4, L, n, n, d_tw, ds, d_out, out_stride, nullptr, &fs)) return true;
+    // shapes the fused pass does not take: the three operations as they are
+    if (!fs.accumulate) (void)hipMemsetAsync(fs.line1, 0, sizeof(uint32_t) * ((size_t)4 << (n - 1)), L_.stream);
+    fold_circle_into_line(L_, fs.line1, (size_t)1 << (n - 1), d_out, out_stride, n, fs.itw, ds, Alpha{{fs.alpha0[0], fs.alpha0[1], fs.alpha0[2], fs.alpha0[3]}});
+    fold_line(L_, fs.line1, (size_t)1 << (n - 1), n - 1, n, fs.itw, ds, Alpha{{fs.alpha1[0], fs.alpha1[1], fs.alpha1[2], fs.alpha1[3]}}, fs.line2,
+              (size_t)1 << (n - 2));
+    return false;
+}
+
 namespace {
 // `out_log` (L <= out_log <= n): only the first 2^out_log entries of the bit-reversed evaluation are produced.  They depend on all the
 // coefficients through the real layers alone (a workgroup's index bits above its layers select its twiddles: the first entries are the
 // workgroups whose high index bits are zero), so the same passes run on a shorter grid.  N below is that number of outputs; the domain
 // (twiddle tables, index arithmetic inside the kernels) stays 2^n.
+// `fsink`: the last pass also folds (ntt_last_fold_kernel) when the shape allows; the return value is then 1, else 0.
 uint32_t evaluate_plan(const Launch& L_, const uint32_t* d_coef, size_t coef_stride, uint32_t ncols, uint32_t L, uint32_t n, uint32_t out_log,
-                       const uint32_t* d_tw, DomainScalars ds, uint32_t* d_out, size_t out_stride, const EncodeTreeSink* sink) {
+                       const uint32_t* d_tw, DomainScalars ds, uint32_t* d_out, size_t out_stride, const EncodeTreeSink* sink,
+                       const EncodeFoldSink* fsink) {
     const size_t N = (size_t)1 << out_log;
     hipStream_t s = L_.stream;
     // algorithmic bytes of the encode: read 2^L, write 2^n words per column (16N(1 + 2^-B) for 4 columns),
@@ -755,6 +854,16 @@ uint32_t evaluate_plan(const Launch& L_, const uint32_t* d_coef, size_t coef_str
     a.init_y = ds.init_y;
     a.bstride_w = L_.bstride / 4;
     uint32_t cpw4 = MAX_COLS_PER_WG;
+    // A workgroup takes its columns one after the other (they share the twiddle registers), so a pass is at least columns x one tile's
+    // load - stages - store chain long: ~17 us for 4 columns however small the transform (2^18 and 2^20 domains take the same time).
+    // While the launch cannot fill the chip anyway (< 512 tiles), one column per workgroup: four times the workgroups, a quarter of
+    // the chain, the twiddles fetched four times (they are a few hundred KB at these sizes).
+    static const uint32_t cpw_small = [] {
+        const char* e = getenv("FRIEDA_NTT_CPW_SMALL");  // tuning knob: columns per workgroup of launches below 1024 tiles
+        const uint32_t v = e ? (uint32_t)atoi(e) : 1u;
+        return (v >= 1 && v <= MAX_COLS_PER_WG) ? v : 1u;
+    }();
+    if ((N >> TILE_LOG) * (size_t)L_.batch < 512) cpw4 = cpw_small;  // (at 512 tiles the 4-column form is ahead again: 29 vs 32 us)
     while (ncols % cpw4) cpw4--;
     // one pass over layers a.i_hi .. a.i_lo
     uint32_t fused_levels = 0;
@@ -785,6 +894,27 @@ uint32_t evaluate_plan(const Launch& L_, const uint32_t* d_coef, size_t coef_str
             else
                 ntt_last_tree_kernel<false><<<grid, NTT_THREADS, 0, s>>>(ta);
             fused_levels = levels;
+            return;
+        }
+        if (fsink && aligned && a.log_w == 0 && t == 12 && ncols == 4 && n >= TILE_LOG + 2 && out_log == n && L_.batch == 1 &&
+            ((reinterpret_cast<uintptr_t>(fsink->line1) | reinterpret_cast<uintptr_t>(fsink->line2) | reinterpret_cast<uintptr_t>(fsink->itw)) & 15) == 0) {
+            // the contiguous last pass over the 4 coordinate columns, folded twice in registers
+            NttFoldArgs fa{};
+            fa.a = a;
+            fa.a.ncols = 4;
+            fa.itw = fsink->itw;
+            fa.inv_init_y = ds.inv_init_y;
+            for (int i = 0; i < 4; i++) fa.alpha0[i] = fsink->alpha0[i], fa.alpha1[i] = fsink->alpha1[i];
+            fa.line1 = fsink->line1;
+            fa.line2 = fsink->line2;
+            // algorithmic bytes: this pass's share of the encode + fold_circle_into_line (24 N) + fold_line at N / 2 (12 N)
+            Scope scope(L_, "ntt_last_fold2", enc_bytes / ((n_mid_fast ? n_mid_fast : n_mid_generic) + 1) + 36.0 * (double)N);
+            const dim3 grid((unsigned)(N >> TILE_LOG), 1, 1);
+            if (fsink->accumulate)
+                ntt_last_fold_kernel<true><<<grid, NTT_THREADS, 0, s>>>(fa);
+            else
+                ntt_last_fold_kernel<false><<<grid, NTT_THREADS, 0, s>>>(fa);
+            fused_levels = 1;
             return;
         }
         Scope scope(L_, name, enc_bytes / ((n_mid_fast ? n_mid_fast : n_mid_generic) + 1));

@@ -337,6 +337,17 @@ int frieda_fold_circle_into_line(frieda_ctx* ctx, uint32_t* d_dst, const uint32_
 int frieda_fold_line(frieda_ctx* ctx, const uint32_t* d_src, uint32_t line_log, uint32_t log_domain,
                      const uint32_t alpha[4], uint32_t* d_dst);
 
+/* PolyOps::evaluate of the four coordinate columns of a SecureCirclePoly (d_coeffs[4][2^log_size] -> d_evals[4][2^log_domain]) +
+ * FriOps::fold_circle_into_line with alpha0 (accumulate_line1 != 0: the trait's form d_line1 = d_line1 * alpha0^2 + fold; 0: d_line1 =
+ * fold) + one FriOps::fold_line with alpha1 (d_line2[4][2^(log_domain-2)]), in ONE pass over the evaluation where the shape allows
+ * (log_size >= 12, 16-byte aligned buffers), as the three operations otherwise; the results are those of the three separate calls.
+ * For callers that hold both folding challenges: a verifier re-executing a round, FRI with fold_step 2, BASELINE configs[1].  The
+ * prover of src/proof.rs draws alpha1 only after committing to line 1 (its fused fold + tree launches are inside
+ * frieda_commit_and_generate_proof). */
+int frieda_circle_evaluate_fold2(frieda_ctx* ctx, const uint32_t* d_coeffs, uint32_t log_size, uint32_t log_domain, uint32_t* d_evals,
+                                 const uint32_t alpha0[4], int accumulate_line1, uint32_t* d_line1, const uint32_t alpha1[4],
+                                 uint32_t* d_line2);
+
 /* GrindOps::grind: smallest nonce with trailing_zeros(mix_u64(digest, nonce)) >= pow_bits */
 int frieda_grind(frieda_ctx* ctx, const uint8_t digest[32], uint32_t pow_bits, uint64_t* nonce);
 

@@ -230,6 +230,42 @@ def test_config2_ntt_plus_fold_round(gpu_ctx, oracle):
     assert np.array_equal(d_2.to_array(np.uint32, (4, 1 << (n - 2))), l2)
 
 
+@pytest.mark.parametrize("L,n", [(16, 20), (12, 14), (12, 16), (13, 17), (17, 18), (18, 18), (11, 15), (5, 9), (1, 2), (0, 2)],
+                         ids=lambda v: str(v))
+@pytest.mark.parametrize("accumulate", [0, 1])
+def test_circle_evaluate_fold2_matches_the_three_calls(gpu_ctx, oracle, L, n, accumulate):
+    """frieda_circle_evaluate_fold2 (configs[1] in one pass: the folds ride in the transform's last pass when log_size >= 12; the three
+    operations otherwise) against the oracle's evaluate / fold_circle_into_line / fold_line, every word of all three buffers; with
+    `accumulate` line 1 starts from random contents (FriOps::fold_circle_into_line's dst * alpha^2 + fold)."""
+    rng = np.random.default_rng(900 + 32 * L + n + accumulate)
+    coef = rng.integers(0, P, (4, 1 << L), dtype=np.uint32)
+    alphas = rng.integers(0, P, (2, 4), dtype=np.uint32)
+    start = rng.integers(0, P, (4, 1 << (n - 1)), dtype=np.uint32)
+    ev = oracle.circle_evaluate(coef, n)
+    l1 = oracle.fold_circle_into_line(ev, alphas[0], dst=start.copy() if accumulate else None)
+    l2 = oracle.fold_line(l1, n, alphas[1])
+    d_c, d_e = DevBuf.from_array(gpu_ctx, coef), DevBuf(gpu_ctx, 16 << n)
+    d_1, d_2 = DevBuf.from_array(gpu_ctx, start), DevBuf(gpu_ctx, max(16 << (n - 2), 16))
+    _check(gpu_ctx, gpu_ctx._L.frieda_circle_evaluate_fold2(gpu_ctx._h, d_c.ptr, L, n, d_e.ptr, alphas[0].ctypes.data, accumulate, d_1.ptr,
+                                                          alphas[1].ctypes.data, d_2.ptr))
+    assert np.array_equal(d_e.to_array(np.uint32, (4, 1 << n)), ev)
+    assert np.array_equal(d_1.to_array(np.uint32, (4, 1 << (n - 1))), l1)
+    assert np.array_equal(d_2.to_array(np.uint32, (4, 1 << (n - 2))), l2)
+
+
+def test_circle_evaluate_fold2_rejects_bad_arguments(gpu_ctx):
+    import frieda_amd
+
+    d = DevBuf(gpu_ctx, 1 << 12)
+    good = np.array([1, 2, 3, 4], dtype=np.uint32)
+    bad = np.array([1, 2, 3, P], dtype=np.uint32)  # not canonical
+    L_ = gpu_ctx._L
+    assert L_.frieda_circle_evaluate_fold2(gpu_ctx._h, d.ptr, 3, 1, d.ptr, good.ctypes.data, 0, d.ptr, good.ctypes.data, d.ptr) == frieda_amd._lib.ERR_ARG
+    assert L_.frieda_circle_evaluate_fold2(gpu_ctx._h, d.ptr, 5, 4, d.ptr, good.ctypes.data, 0, d.ptr, good.ctypes.data, d.ptr) == frieda_amd._lib.ERR_ARG
+    assert L_.frieda_circle_evaluate_fold2(gpu_ctx._h, d.ptr, 2, 4, d.ptr, bad.ctypes.data, 0, d.ptr, good.ctypes.data, d.ptr) == frieda_amd._lib.ERR_ARG
+    assert L_.frieda_circle_evaluate_fold2(gpu_ctx._h, None, 2, 4, d.ptr, good.ctypes.data, 0, d.ptr, good.ctypes.data, d.ptr) == frieda_amd._lib.ERR_ARG
+
+
 # ------------------------------------------------------------------------------------------------
 # Level A
 # ------------------------------------------------------------------------------------------------
