@@ -47,6 +47,9 @@ extern "C" {
     pub fn frieda_ctx_release_workspace(ctx: *mut frieda_ctx) -> c_int;
     pub fn frieda_ctx_set_twiddle_cache(ctx: *mut frieda_ctx, enabled: c_int) -> c_int;
     pub fn frieda_ctx_set_host_channel(ctx: *mut frieda_ctx, enabled: c_int) -> c_int;
+    /// per-context tuning / A-B option, named like the environment variable that sets its default
+    pub fn frieda_ctx_set_option(ctx: *mut frieda_ctx, name: *const c_char, value: i64) -> c_int;
+    /// test hook (include/frieda_hip_testing.h), not part of the boundary
     pub fn frieda_ctx_test_set_draw_bound(ctx: *mut frieda_ctx, bound: u32) -> c_int;
     pub fn frieda_ctx_set_kernel_timing(ctx: *mut frieda_ctx, enabled: c_int) -> c_int;
     pub fn frieda_ctx_last_prove_phases(ctx: *const frieda_ctx, out_ms: *mut f64) -> c_int;

@@ -12,6 +12,7 @@ _ROOT = os.path.dirname(_PKG)
 # FRIEDA_HIP_LIB: an alternative build of the same library (A/B experiments: tools/build_variant.sh); never a fallback
 LIB_PATH = os.environ.get("FRIEDA_HIP_LIB") or os.path.join(_PKG, "lib", "libfrieda_hip.so")
 HEADER_PATH = os.path.join(_ROOT, "include", "frieda_hip.h")
+TESTING_HEADER_PATH = os.path.join(_ROOT, "include", "frieda_hip_testing.h")  # test hooks: not part of the drop-in boundary
 
 OK, ERR_ARG, ERR_HIP, ERR_INVARIANT, ERR_NOMEM, ERR_FORMAT = 0, 1, 2, 3, 4, 5
 
@@ -34,8 +35,8 @@ def build(force=False):
 
 
 def declared_symbols():
-    """Every function name include/frieda_hip.h declares."""
-    text = open(HEADER_PATH).read()
+    """Every function name include/frieda_hip.h (the boundary) and include/frieda_hip_testing.h (test hooks) declare."""
+    text = open(HEADER_PATH).read() + open(TESTING_HEADER_PATH).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(frieda_[a-z0-9_]+)\s*\(", text)))
 
@@ -66,6 +67,7 @@ def lib():
         "frieda_ctx_release_workspace": (C.c_int, [vp]),
         "frieda_ctx_set_twiddle_cache": (C.c_int, [vp, C.c_int]),
         "frieda_ctx_set_host_channel": (C.c_int, [vp, C.c_int]),
+        "frieda_ctx_set_option": (C.c_int, [vp, C.c_char_p, C.c_int64]),
         "frieda_ctx_test_set_draw_bound": (C.c_int, [vp, u32]),
         "frieda_ctx_set_kernel_timing": (C.c_int, [vp, C.c_int]),
         "frieda_ctx_last_prove_phases": (C.c_int, [vp, C.POINTER(C.c_double)]),

@@ -100,6 +100,11 @@ class Context:
     def set_twiddle_cache(self, enabled):
         _check(self._L.frieda_ctx_set_twiddle_cache(self._h, int(bool(enabled))), self._h)
 
+    def set_option(self, name, value):
+        """A tuning / A-B option of this context alone (frieda_ctx_set_option): `name` is the environment variable that sets its default
+        at context creation, e.g. "FRIEDA_HOST_DECOMMIT"; every option selects another kernel or plan for the same result."""
+        _check(self._L.frieda_ctx_set_option(self._h, name.encode(), int(value)), self._h)
+
     def set_host_channel(self, enabled):
         """Evaluate the Fiat-Shamir channel on the host between layers instead of inside the device kernels."""
         _check(self._L.frieda_ctx_set_host_channel(self._h, int(bool(enabled))), self._h)

@@ -7,6 +7,7 @@
 #include <new>
 
 #include "host.h"
+#include "../../include/frieda_hip_testing.h"
 
 using namespace frieda;
 
@@ -53,6 +54,11 @@ int frieda_ctx_create(int device, void* stream, frieda_ctx** out) {
             return FRIEDA_ERR_HIP;
         }
         ctx->c.own_stream = true;
+    }
+    if (k::ntt_opt_in_dynamic_lds() != hipSuccess) {
+        (void)hipGetLastError();
+        frieda_ctx_destroy(ctx);
+        return FRIEDA_ERR_HIP;
     }
     *out = ctx;
     return FRIEDA_OK;
@@ -149,6 +155,15 @@ int frieda_ctx_last_transcript(const frieda_ctx* ctx, uint32_t* n_layers, uint32
         for (int w = 0; w < 8; w++)
             for (int b = 0; b < 4; b++) digest_before_grind[4 * w + b] = (uint8_t)(t.digest_before_grind[w] >> (8 * b));
     return FRIEDA_OK;
+}
+
+int frieda_ctx_set_option(frieda_ctx* ctx, const char* name, int64_t value) {
+    if (!ctx || !name) return FRIEDA_ERR_ARG;
+    FR_GUARD_BEGIN
+    FR_NO_JOB(&ctx->c);
+    if (!k::tuning_set(ctx->c.tuning, name, (long)value)) return ctx->c.fail(FRIEDA_ERR_ARG, std::string("unknown option or value out of range: ") + name);
+    return FRIEDA_OK;
+    FR_GUARD_END(ctx)
 }
 
 int frieda_ctx_test_set_draw_bound(frieda_ctx* ctx, uint32_t bound) {

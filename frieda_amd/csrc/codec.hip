@@ -112,11 +112,7 @@ void unpack30(const Launch& L, const uint8_t* d_bytes, size_t len, uint32_t* d_o
                    (n_out % 4 == 0) && (src_bstride % 4 == 0) && (L.bstride % 16 == 0);
     if (aligned) {
         size_t quads = n_out / 4;
-        static const int tiles = [] {  // tuning knob: quads per workgroup / 256 (1, 2, 4 or 8)
-            const char* e = getenv("FRIEDA_UNPACK_TILES");
-            const int v = e ? atoi(e) : 4;
-            return (v == 1 || v == 2 || v == 4 || v == 8) ? v : 4;
-        }();
+        const int tiles = (int)L.tune->unpack_tiles;  // tuning knob: quads per workgroup / 256 (1, 2, 4 or 8)
         const int T = quads >= 8192 ? tiles : 1;  // small blobs: as many workgroups as there are
         dim3 grid((unsigned)((quads + 256 * (size_t)T - 1) / (256 * (size_t)T)), L.batch);
         if (T == 8)

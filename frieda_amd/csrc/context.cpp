@@ -1,4 +1,6 @@
 // context.cpp — device context: stream, workspace arena, per-domain twiddle cache; host circle-group helpers.
+#include <cstring>
+#include <cstdlib>
 #include <string.h>
 
 #include <cstdio>
@@ -96,7 +98,72 @@ void timer_end(KernelTimer* t, hipStream_t s) {
 }
 }  // namespace k
 
-k::Launch Ctx::launch() const { return k::Launch{stream, reinterpret_cast<k::KernelTimer*>(timer)}; }
+k::Launch Ctx::launch() const {
+    k::Launch l{stream, reinterpret_cast<k::KernelTimer*>(timer)};
+    l.tune = &tuning;
+    return l;
+}
+
+namespace k {
+namespace {
+struct KnobDesc {
+    const char* name;
+    long lo, hi;
+    void (*set)(Tuning&, long);
+};
+const KnobDesc KNOBS[] = {
+    {"FRIEDA_T5_WIDE_LOG", 16, 24, [](Tuning& t, long v) { t.t5_wide_log = (uint32_t)v; }},
+    {"FRIEDA_T5_REG3_LOG", 0, 30, [](Tuning& t, long v) { t.t5_reg3_log = (uint32_t)v; }},
+    {"FRIEDA_T9_MAX_LOG", 8, 19, [](Tuning& t, long v) { t.t9_max_log = (uint32_t)v; }},
+    {"FRIEDA_TOP_MAX_LOG", 9, 11, [](Tuning& t, long v) { t.top_max_log = (uint32_t)v; }},
+    {"FRIEDA_NTT_CPW", 1, 4, [](Tuning& t, long v) { t.ntt_cpw = (uint32_t)v; }},
+    {"FRIEDA_NTT_CPW_SMALL", 1, 4, [](Tuning& t, long v) { t.ntt_cpw_small = (uint32_t)v; }},
+    {"FRIEDA_NTT_REP", 0, 1, [](Tuning& t, long v) { t.ntt_rep = v != 0; }},
+    {"FRIEDA_NTT_NO_PAD8", 0, 1, [](Tuning& t, long v) { t.ntt_no_pad8 = v != 0; }},
+    {"FRIEDA_NTT_TREE_REG_ONLY", 0, 1, [](Tuning& t, long v) { t.ntt_tree_reg_only = v != 0; }},
+    {"FRIEDA_NO_ENCODE_TREE_FUSION", 0, 1, [](Tuning& t, long v) { t.no_encode_tree_fusion = v != 0; }},
+    {"FRIEDA_NO_SMALL_FUSED", 0, 1, [](Tuning& t, long v) { t.no_small_fused = v != 0; }},
+    {"FRIEDA_UNPACK_TILES", 1, 8, [](Tuning& t, long v) { if (v == 1 || v == 2 || v == 4 || v == 8) t.unpack_tiles = (uint32_t)v; }},
+    {"FRIEDA_INTT_GENERIC", 0, 1, [](Tuning& t, long v) { t.intt_generic = v != 0; }},
+    {"FRIEDA_ERASURE_TREE_MIN_LOG", 6, 32, [](Tuning& t, long v) { t.erasure_tree_min_log = (uint32_t)v; }},
+    {"FRIEDA_TAIL_RUN_LOG", 4, 11, [](Tuning& t, long v) { t.tail_run_log = (uint32_t)v; }},
+    {"FRIEDA_HOST_DECOMMIT", 0, 1, [](Tuning& t, long v) { t.host_decommit = v != 0; }},
+    {"FRIEDA_GATHER_COPY", 0, 1, [](Tuning& t, long v) { t.gather_copy = v != 0; }},
+    {"FRIEDA_TEST_GRIND_FIRST_LOG", 0, 40, [](Tuning& t, long v) { t.test_grind_first_log = (v >= 8) ? (uint32_t)v : 0u; }},
+};
+}  // namespace
+
+bool tuning_set(Tuning& t, const char* name, long value) {
+    if (!name) return false;
+    for (const KnobDesc& k : KNOBS) {
+        if (strcmp(k.name, name) == 0) {
+            if (value < k.lo || value > k.hi) return false;
+            k.set(t, value);
+            return true;
+        }
+    }
+    return false;
+}
+
+Tuning tuning_from_env() {
+    Tuning t;
+    for (const KnobDesc& k : KNOBS) {
+        const char* e = getenv(k.name);
+        if (!e) continue;
+        // a variable that is set but empty / not a number switches a boolean knob on, as `getenv(...) != nullptr` used to
+        char* end = nullptr;
+        long v = strtol(e, &end, 10);
+        if (end == e) v = 1;
+        (void)tuning_set(t, k.name, v);
+    }
+    return t;
+}
+
+const Tuning& tuning_defaults() {
+    static const Tuning d;  // compiled-in defaults, immutable
+    return d;
+}
+}  // namespace k
 
 int Ctx::set_kernel_timing(bool enabled) {
     if (enabled && !timer) timer = new KernelTimerImpl();

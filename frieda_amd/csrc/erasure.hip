@@ -22,7 +22,8 @@
 //   3. evaluate Z * p on the next canonic domain D' (2N points, disjoint from D) and take its first block of K entries; there
 //      p = (Z p) Z_S / V_D pointwise: K values of p on a sub-coset of D'
 //   4. inverse transform of that block (intt.hip) -> the coefficients of p
-//   5. encode p again and compare EVERY offered sample: samples that are not values of one polynomial are reported, not returned
+//   5. encode p again and compare EVERY offered sample (every distinct cell: a repeated index is dropped by the de-duplication, first
+//      occurrence wins, and is not compared): samples that are not values of one polynomial are reported, not returned
 //
 // Cost: (K + 2)(K / 2 + 1) + K (K / 2 + 1) line evaluations for the two products — quadratic in the polynomial, not in the domain —
 // plus five transforms.  Exact arithmetic: consistent samples give the polynomial.
@@ -429,21 +430,24 @@ size_t erasure_zpart_chunks(uint32_t count, uint32_t n_lines) {
 
 size_t erasure_sample_lists_chunks(uint32_t n_cells) { return ((size_t)n_cells + DED_CHUNK - 1) / DED_CHUNK; }
 
-void erasure_sample_lists(const Launch& L_, const uint32_t* d_idx, uint32_t n_cells, uint32_t domain_cells, uint32_t ncols, uint32_t log_cell,
-                          uint32_t* d_owner, uint32_t* d_chunk_sum, uint32_t* d_chunk_off, uint32_t* d_first_cell, uint32_t* d_first_row,
-                          uint32_t* d_state, uint32_t* d_pos, uint32_t* d_src) {
-    if (!n_cells) return;
+hipError_t erasure_sample_lists(const Launch& L_, const uint32_t* d_idx, uint32_t n_cells, uint32_t domain_cells, uint32_t ncols, uint32_t log_cell,
+                                uint32_t* d_owner, uint32_t* d_chunk_sum, uint32_t* d_chunk_off, uint32_t* d_first_cell, uint32_t* d_first_row,
+                                uint32_t* d_state, uint32_t* d_pos, uint32_t* d_src) {
+    if (!n_cells) return hipSuccess;
     Scope scope(L_, "erasure_sample_lists", 20.0 * n_cells + 8.0 * ((double)n_cells * (double)((size_t)1 << log_cell)));
     hipStream_t s = L_.stream;
     const unsigned chunks = (unsigned)erasure_sample_lists_chunks(n_cells);
-    (void)hipMemsetAsync(d_owner, 0xFF, 4 * (size_t)domain_cells, s);
-    (void)hipMemsetAsync(d_state, 0, 8, s);
+    // (a failed memset would feed garbage into the claim and offset kernels: reported, not ignored)
+    hipError_t e = hipMemsetAsync(d_owner, 0xFF, 4 * (size_t)domain_cells, s);
+    if (e == hipSuccess) e = hipMemsetAsync(d_state, 0, 8, s);
+    if (e != hipSuccess) return e;
     dedup_claim_kernel<<<(n_cells + 255) / 256, 256, 0, s>>>(d_idx, n_cells, domain_cells, d_owner, d_state);
     dedup_count_kernel<<<chunks, DED_THREADS, 0, s>>>(d_idx, d_owner, n_cells, domain_cells, d_chunk_sum);
     dedup_offsets_kernel<<<1, 1024, 0, s>>>(d_chunk_sum, chunks, d_chunk_off, d_state);
     dedup_emit_kernel<<<chunks, DED_THREADS, 0, s>>>(d_idx, d_owner, n_cells, domain_cells, d_chunk_off, d_first_cell, d_first_row);
     const size_t pts_cap = (size_t)n_cells << log_cell;
     dedup_expand_kernel<<<(unsigned)((pts_cap + 255) / 256), 256, 0, s>>>(d_first_cell, d_first_row, d_state, ncols, log_cell, d_pos, d_src);
+    return hipSuccess;
 }
 
 void erasure_cell_firsts(const Launch& L_, const uint32_t* d_pos, uint32_t n_cells, uint32_t log_cell, uint32_t* d_out) {

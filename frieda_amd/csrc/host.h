@@ -84,6 +84,7 @@ struct Ctx {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     bool cache_twiddles = true;
+    k::Tuning tuning = k::tuning_from_env();  // per-context knobs (kernels.h): environment defaults, frieda_ctx_set_option overrides
     uint32_t test_draw_bound = 2u * P31;  // test hook: acceptance bound of draw_felt (see frieda_ctx_test_set_draw_bound)
     bool host_channel = false;  // evaluate the Fiat-Shamir channel on the host between layers (diagnostic / fallback path)
     std::map<uint32_t, TwiddleSet> twiddles;

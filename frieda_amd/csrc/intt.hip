@@ -301,7 +301,7 @@ void circle_interpolate_block(const Launch& L_, const uint32_t* d_block, size_t 
     const uint32_t scale = (1u << (31 - L)) % P31;  // 2^-L = 2^(31-L) mod P
     // 12 or more layers over 16-byte aligned buffers: the first 12 layers, then the strided ones 8 and 4 at a time, as passes of
     // intt_tile12_kernel; what is left (L mod 4 layers) and every other shape goes through the generic kernel below.
-    static const bool no_fast = getenv("FRIEDA_INTT_GENERIC") != nullptr;  // A/B knob
+    const bool no_fast = L_.tune->intt_generic;  // A/B knob
     const bool aligned = ((in_stride | out_stride) & 3) == 0 && ((reinterpret_cast<uintptr_t>(d_block) | reinterpret_cast<uintptr_t>(d_coef)) & 15) == 0;
     uint32_t done = 0;
     if (L >= ITILE_LOG && aligned && !no_fast) {

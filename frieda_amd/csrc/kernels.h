@@ -25,11 +25,40 @@ __device__ __forceinline__ size_t tw_level_offset_dev(uint32_t n, uint32_t lv) {
 // blockIdx.y — blockIdx.z in the transforms — times bstride); the DevTranscripts form a contiguous array indexed by b;
 // twiddle tables are shared.  batch == 1, bstride == 0 is the single-blob case.
 struct KernelTimer;
+// Tuning and A/B knobs, PER CONTEXT: a context takes its defaults from the FRIEDA_* environment variables when it is
+// created and frieda_ctx_set_option changes one for that context alone; nothing here is process-wide state.  Every knob selects
+// another kernel / plan for the SAME result.
+struct Tuning {
+    uint32_t t5_wide_log = 18;   // FRIEDA_T5_WIDE_LOG: smallest launch (nodes) of the register-subtree kernel
+    uint32_t t5_reg3_log = 0;    // FRIEDA_T5_REG3_LOG: leaf / fold launches of >= 2^v nodes stop after their three register levels (0 = never)
+    uint32_t t9_max_log = 17;    // FRIEDA_T9_MAX_LOG: largest level-A size of the nine-level kernel
+    uint32_t top_max_log = 9;    // FRIEDA_TOP_MAX_LOG: largest hand-over size of the top kernel (9 .. 11)
+    uint32_t ntt_cpw = 4;        // FRIEDA_NTT_CPW: columns per workgroup of the generic transform kernel
+    uint32_t ntt_cpw_small = 1;  // FRIEDA_NTT_CPW_SMALL: columns per workgroup of fast-kernel launches below 512 tiles
+    bool ntt_rep = false;        // FRIEDA_NTT_REP: the first strided pass as ntt_tile12_rep_kernel
+    bool ntt_no_pad8 = false;    // FRIEDA_NTT_NO_PAD8: no padded / 4-layer fast passes
+    bool ntt_tree_reg_only = false;      // FRIEDA_NTT_TREE_REG_ONLY: the fused encode + leaf launch stops after its five register levels
+    bool no_encode_tree_fusion = false;  // FRIEDA_NO_ENCODE_TREE_FUSION: last transform pass and leaf launch as two kernels
+    bool no_small_fused = false;         // FRIEDA_NO_SMALL_FUSED: the general path for small domains too
+    uint32_t unpack_tiles = 4;           // FRIEDA_UNPACK_TILES: 1, 2, 4 or 8 tiles of 256 quads per unpacker workgroup
+    bool intt_generic = false;           // FRIEDA_INTT_GENERIC: every inverse pass through the generic one-column kernel
+    uint32_t erasure_tree_min_log = 15;  // FRIEDA_ERASURE_TREE_MIN_LOG: smallest log2(coefficients) whose locator is built by the product tree
+    uint32_t tail_run_log = 9;           // FRIEDA_TAIL_RUN_LOG: layers of more than 2^v points use the multi-workgroup kernels
+    bool host_decommit = false;          // FRIEDA_HOST_DECOMMIT: openings by the host planner + gather launch
+    bool gather_copy = false;            // FRIEDA_GATHER_COPY: fallback path stages lists and results through device memory + copies
+    uint32_t test_grind_first_log = 0;   // FRIEDA_TEST_GRIND_FIRST_LOG: test hook, a short first nonce range (0 = off)
+};
+Tuning tuning_from_env();
+// `name`: the environment variable's name ("FRIEDA_NTT_REP"); false = unknown name or value out of range
+bool tuning_set(Tuning& t, const char* name, long value);
+const Tuning& tuning_defaults();  // (for Launch objects built without a context)
+
 struct Launch {
     hipStream_t stream;
     KernelTimer* timer;
     uint32_t batch = 1;
     size_t bstride = 0;
+    const Tuning* tune = &tuning_defaults();
 };
 void timer_begin(KernelTimer* t, hipStream_t s, const char* name, double alg_bytes);
 void timer_end(KernelTimer* t, hipStream_t s);
@@ -95,6 +124,8 @@ struct EncodeTreeSink {
     uint8_t* last_out;
 };
 constexpr uint32_t ENCODE_TREE_LEVELS = 7;
+// the generic transform kernel's 68 KiB of dynamic LDS: opt-in for the current device (once per context, at creation)
+hipError_t ntt_opt_in_dynamic_lds();
 // PolyOps::evaluate of the four coordinate columns + FriOps::fold_circle_into_line (alpha0; `accumulate`: line1 = line1 * alpha0^2 + fold,
 // the trait's form, else line1 = fold) + one FriOps::fold_line (alpha1) — the folds ride in the transform's last pass when the shape
 // allows (>= 2^12 coefficients per column, 16-byte aligned buffers: returns true), separate launches otherwise (returns false).
@@ -159,7 +190,7 @@ void erasure_known_weights_cells(const Launch& L_, const uint32_t* d_px, uint32_
 // [domain_cells], d_chunk_sum / d_chunk_off [erasure_sample_lists_chunks(n_cells)], d_first_cell / d_first_row [n_cells]; d_pos / d_src
 // [n_cells << log_cell].  erasure_cell_firsts: d_out[i] = d_pos[i << log_cell].
 size_t erasure_sample_lists_chunks(uint32_t n_cells);
-void erasure_sample_lists(const Launch& L_, const uint32_t* d_idx, uint32_t n_cells, uint32_t domain_cells, uint32_t ncols, uint32_t log_cell,
+hipError_t erasure_sample_lists(const Launch& L_, const uint32_t* d_idx, uint32_t n_cells, uint32_t domain_cells, uint32_t ncols, uint32_t log_cell,
                           uint32_t* d_owner, uint32_t* d_chunk_sum, uint32_t* d_chunk_off, uint32_t* d_first_cell, uint32_t* d_first_row,
                           uint32_t* d_state, uint32_t* d_pos, uint32_t* d_src);
 void erasure_cell_firsts(const Launch& L_, const uint32_t* d_pos, uint32_t n_cells, uint32_t log_cell, uint32_t* d_out);
@@ -226,7 +257,7 @@ void tree_first_layer(const Launch& L, const uint32_t* cols, size_t stride, uint
 // d_root receives it (commit).  tr / tr_init as tree_first_layer.
 // small domains (2^8 .. 2^13 points, <= 2^9 coefficients per column: the reference's 1 KiB - 4 KiB bench inputs): unpack + encode +
 // first tree as ONE launch + the top kernel, straight from the blob's bytes (device or page-locked host memory)
-bool small_domain_shape(uint32_t Lc, uint32_t n);
+bool small_domain_shape(const Tuning& tn, uint32_t Lc, uint32_t n);
 void small_encode_and_first_tree(const Launch& L, const uint8_t* d_data, size_t len, size_t data_stride, uint32_t Lc, uint32_t n,
                                  const uint32_t* d_tw, DomainScalars ds, uint32_t* d_eval, size_t eval_stride, uint8_t* d_layers,
                                  uint8_t* d_scratch, uint8_t* d_root, DevTranscript* tr, const DevTranscript* tr_init, size_t tr_init_pitch);

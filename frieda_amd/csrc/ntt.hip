@@ -27,7 +27,6 @@
 // twice its HBM time.
 #include <hip/hip_runtime.h>
 
-#include <atomic>
 #include <cstdlib>
 
 #include "clock_stamps.h"
@@ -781,6 +780,13 @@ uint32_t circle_evaluate_into_tree(const Launch& L_, const uint32_t* d_coef, siz
     return evaluate_plan(L_, d_coef, coef_stride, ncols, L, n, n, d_tw, ds, d_out, out_stride, sink);
 }
 
+hipError_t ntt_opt_in_dynamic_lds() {
+    // The opt-in belongs to the CURRENT device's function object: called once per context at creation (frieda_multi drives several
+    // devices from one process), so no process-wide flag is kept.
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(ntt_tile_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)(MAX_COLS_PER_WG * TILE_WORDS * sizeof(uint32_t)));
+}
+
 bool circle_evaluate_fold2(const Launch& L_, const uint32_t* d_coef, size_t coef_stride, uint32_t L, uint32_t n, const uint32_t* d_tw,
                            DomainScalars ds, uint32_t* d_out, size_t out_stride, const EncodeFoldSink& fs) {
     if (evaluate_plan(L_, d_coef, coef_stride, 4, L, n, n, d_tw, ds, d_out, out_stride, nullptr, &fs)) return true;
@@ -813,29 +819,12 @@ uint32_t evaluate_plan(const Launch& L_, const uint32_t* d_coef, size_t coef_str
         return 0;
     }
     // columns per workgroup: the largest divisor of ncols that is <= 4 (the 4 coordinate columns share every twiddle)
-    static const uint32_t cpw_max = [] {
-        const char* e = getenv("FRIEDA_NTT_CPW");  // tuning knob: columns per workgroup (1, 2 or 4)
-        uint32_t v = e ? (uint32_t)atoi(e) : MAX_COLS_PER_WG;
-        return (v >= 1 && v <= MAX_COLS_PER_WG) ? v : MAX_COLS_PER_WG;
-    }();
+    const uint32_t cpw_max = L_.tune->ntt_cpw <= MAX_COLS_PER_WG ? L_.tune->ntt_cpw : MAX_COLS_PER_WG;  // tuning knob (1, 2 or 4)
     uint32_t cpw = cpw_max;
     while (ncols % cpw) cpw--;
     const size_t lds_bytes = (size_t)cpw * TILE_WORDS * sizeof(uint32_t);
-    // 4 column tiles = 68 KiB of dynamic LDS: above the 64 KiB default.  The opt-in belongs to the current device's function
-    // object, and frieda_multi drives several devices from one process (one host thread each): one flag per device, set only
-    // after the attribute call has returned (a thread that loses the race repeats the call, which is harmless).
-    {
-        static std::atomic<bool> lds_opt_in[64];
-        int dev = 0;
-        (void)hipGetDevice(&dev);
-        const bool tracked = dev >= 0 && dev < 64;
-        if (!tracked || !lds_opt_in[dev].load(std::memory_order_acquire)) {
-            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ntt_tile_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                     (int)(MAX_COLS_PER_WG * TILE_WORDS * sizeof(uint32_t)));
-            if (e == hipSuccess && tracked) lds_opt_in[dev].store(true, std::memory_order_release);
-            if (e != hipSuccess) (void)hipGetLastError();  // the launch check behind the pass reports a refused launch
-        }
-    }
+    // (4 column tiles = 68 KiB of dynamic LDS, above the 64 KiB default: every context opts its device's function object in when it
+    // is created, ntt_opt_in_dynamic_lds below)
 
     // real layers i = L-1 .. 0; the last pass takes up to 12 of them, the strided passes before it up to 8 each
     const uint32_t last_t = L < TILE_LOG ? L : TILE_LOG;
@@ -858,11 +847,7 @@ uint32_t evaluate_plan(const Launch& L_, const uint32_t* d_coef, size_t coef_str
     // load - stages - store chain long: ~17 us for 4 columns however small the transform (2^18 and 2^20 domains take the same time).
     // While the launch cannot fill the chip anyway (< 512 tiles), one column per workgroup: four times the workgroups, a quarter of
     // the chain, the twiddles fetched four times (they are a few hundred KB at these sizes).
-    static const uint32_t cpw_small = [] {
-        const char* e = getenv("FRIEDA_NTT_CPW_SMALL");  // tuning knob: columns per workgroup of launches below 1024 tiles
-        const uint32_t v = e ? (uint32_t)atoi(e) : 1u;
-        return (v >= 1 && v <= MAX_COLS_PER_WG) ? v : 1u;
-    }();
+    const uint32_t cpw_small = L_.tune->ntt_cpw_small;  // tuning knob: columns per workgroup of launches below 512 tiles
     if ((N >> TILE_LOG) * (size_t)L_.batch < 512) cpw4 = cpw_small;  // (at 512 tiles the 4-column form is ahead again: 29 vs 32 us)
     while (ncols % cpw4) cpw4--;
     // one pass over layers a.i_hi .. a.i_lo
@@ -879,7 +864,7 @@ uint32_t evaluate_plan(const Launch& L_, const uint32_t* d_coef, size_t coef_str
             ta.last_out = sink->last_out;
             ta.bstride = L_.bstride;
             // algorithmic bytes: this pass's share of the encode + leaves (16 B in, 32 B out) + 6 node levels (96 B per node)
-            static const bool reg_only = getenv("FRIEDA_NTT_TREE_REG_ONLY") != nullptr;  // A/B knob
+            const bool reg_only = L_.tune->ntt_tree_reg_only;  // A/B knob
             const uint32_t levels = reg_only ? 5u : ENCODE_TREE_LEVELS;
             double bytes = enc_bytes / ((n_mid_fast ? n_mid_fast : n_mid_generic) + 1) + 48.0 * (double)N;
             for (uint32_t l = 1; l < levels; l++) bytes += 96.0 * (double)(N >> l);
@@ -922,10 +907,7 @@ uint32_t evaluate_plan(const Launch& L_, const uint32_t* d_coef, size_t coef_str
         // cuts the pass's fetches from the memory side to the unique coefficients but is no faster (142 vs 140 us at 2^24, 41 vs 35 us at
         // 2^22, profiles/r03_ntt_mid_rep_ab.txt) — the pass is bound by its butterflies and LDS round trips, not by the re-reads,
         // which the L2 / Infinity Cache absorb.
-        static const bool use_rep = [] {
-            const char* e = getenv("FRIEDA_NTT_REP");
-            return e && *e == '1';
-        }();
+        const bool use_rep = L_.tune->ntt_rep;
         const uint32_t hb_log = n - 1 - a.i_hi;  // high blocks = 2^hb_log
         if (use_rep && out_log == n && aligned && t == 8 && a.log_w == MID_LOG_W && hb_log >= 1 && ((uint64_t)a.in_mask >> (a.i_hi + 1)) == 0 && ncols % 2 == 0) {
             // this pass reads the (replicated) coefficient vector: every high block has the same source tile
@@ -958,7 +940,7 @@ uint32_t evaluate_plan(const Launch& L_, const uint32_t* d_coef, size_t coef_str
     // words beyond 2^L read as zero instead of wrapping), which costs less than the generic kernel saves (44.8 -> 28 us at 2^22, 623 ->
     // 3xx us for the 9 strided layers of a 2^25 domain).  Needs padz <= log_blowup_factor and 16-byte aligned buffers; otherwise the
     // generic passes below take over.
-    static const bool no_pad8 = getenv("FRIEDA_NTT_NO_PAD8") != nullptr;  // A/B knob: generic kernel unless a pass has exactly 8 real layers
+    const bool no_pad8 = L_.tune->ntt_no_pad8;  // A/B knob: generic kernel unless a pass has exactly 8 real layers
     const uint32_t units = (rest + 3) / 4, padz = 4 * units - rest;
     const bool base_aligned = ((a.in_stride | a.out_stride) & 3) == 0 &&
                               ((reinterpret_cast<uintptr_t>(a.in) | reinterpret_cast<uintptr_t>(a.out) | L_.bstride) & 15) == 0;

@@ -136,7 +136,7 @@ int commit_device(Ctx* ctx, const uint8_t* d_data, size_t len, uint32_t log_blow
 
     uint32_t* coef = reinterpret_cast<uint32_t*>(ctx->arena + o_coef);
     uint32_t* eval = reinterpret_cast<uint32_t*>(ctx->arena + o_eval);
-    if (k::small_domain_shape(sh.L, sh.n)) {
+    if (k::small_domain_shape(ctx->tuning, sh.L, sh.n)) {
         k::small_encode_and_first_tree(ctx->launch(), d_data, len, 0, sh.L, sh.n, tw.d_tw, tw.ds, nullptr, 0, nullptr, ctx->arena + o_scr, d_root,
                                        nullptr, nullptr, 0);
     } else {
@@ -165,7 +165,7 @@ int commit_host(Ctx* ctx, const uint8_t* data, size_t len, uint32_t log_blowup, 
     if (rc) return rc;
     rc = ensure_pinned(ctx, 4096);
     if (rc) return rc;
-    if (k::small_domain_shape(sh.L, sh.n) && len <= SMALL_HOST_IN_BYTES) {
+    if (k::small_domain_shape(ctx->tuning, sh.L, sh.n) && len <= SMALL_HOST_IN_BYTES) {
         // no copy commands at all: the kernels read the blob from page-locked host memory and write the root into it
         rc = ensure_pinned_in(ctx);
         if (rc) return rc;
@@ -245,7 +245,7 @@ int commit_batch_begin(Ctx* ctx, const uint8_t* data, size_t data_stride, size_t
     }
     uint32_t* coef = reinterpret_cast<uint32_t*>(A + o_coef);
     uint32_t* eval = reinterpret_cast<uint32_t*>(A + o_eval);
-    if (k::small_domain_shape(sh.L, sh.n)) {
+    if (k::small_domain_shape(ctx->tuning, sh.L, sh.n)) {
         k::small_encode_and_first_tree(LN, d_data, len, d_stride, sh.L, sh.n, tw.d_tw, tw.ds, nullptr, 0, nullptr, A + o_scr, A + o_root, nullptr,
                                        nullptr, 0);
     } else {
@@ -519,7 +519,7 @@ int prove_begin_batch(Ctx* ctx, const uint8_t* data, size_t data_stride, size_t 
     // ---- encode (src/proof.rs:38,44-50) ----
     const uint8_t* d_data = data;
     size_t d_data_stride = data_stride;
-    const bool small = k::small_domain_shape(sh.L, n) && !ctx->host_channel && last_log <= k::TAIL_LOG;
+    const bool small = k::small_domain_shape(ctx->tuning, sh.L, n) && !ctx->host_channel && last_log <= k::TAIL_LOG;
     if (!data_on_device) {
         if (small && count == 1 && len <= SMALL_HOST_IN_BYTES) {
             // a lone small blob is not copied to the device: the first kernel reads it from page-locked host memory
@@ -586,11 +586,7 @@ int prove_begin_batch(Ctx* ctx, const uint8_t* data, size_t data_stride, size_t 
         uint32_t kx = 0;
         // layers of more than 2^TAIL_RUN_LOG points go through the multi-workgroup kernels (a 2^11 layer is faster there than in
         // the one-workgroup tail); FRIEDA_TAIL_RUN_LOG is a tuning knob
-        static const uint32_t tail_run_log = [] {
-            const char* e = getenv("FRIEDA_TAIL_RUN_LOG");
-            uint32_t v = e ? (uint32_t)atoi(e) : 9u;
-            return v >= 4 && v <= k::TAIL_LOG ? v : 9u;
-        }();
+        const uint32_t tail_run_log = ctx->tuning.tail_run_log;
         while (kx < n_inner && inner[kx].log > tail_run_log) {
             k::fold_and_tree(LN, circle, cols(*cur, 0), (size_t)1 << cur->log, cur->log, n, tw.d_itw, tw.ds, cols(inner[kx], 0),
                              A + inner[kx].o_tree, d_tr);
@@ -616,16 +612,13 @@ int prove_begin_batch(Ctx* ctx, const uint8_t* data, size_t data_stride, size_t 
         J.grind_base = 0;
         // first range: 16x the expected search (a miss has probability e^-16; workgroups without work leave at once)
         J.grind_chunk = (uint64_t)1 << std::max<uint32_t>(22, std::min<uint32_t>(cfg.pow_bits, 36) + 4);
-        if (const char* e = getenv("FRIEDA_TEST_GRIND_FIRST_LOG")) {  // test hook: a short first range exercises the retry loop
-            const int v = atoi(e);
-            if (v >= 8 && v <= 40) J.grind_chunk = (uint64_t)1 << v;
-        }
+        if (ctx->tuning.test_grind_first_log) J.grind_chunk = (uint64_t)1 << ctx->tuning.test_grind_first_log;  // test hook: the retry loop runs
         k::grind_dev(LN, d_tr, d_gnext, cfg.pow_bits, J.grind_base, J.grind_chunk, /*next_zeroed=*/true);
         rc = download_transcripts(ctx, J);
         if (rc) return rc;
         // mix_u64(nonce), query sampling and every opening of the proof, written in proof order into the pinned block
         J.dev_decommit = cfg.n_queries <= k::DECOMMIT_MAX_QUERIES && 1 + n_inner <= k::DECOMMIT_MAX_LAYERS && n <= k::DECOMMIT_MAX_LOG_DOMAIN &&
-                         !getenv("FRIEDA_HOST_DECOMMIT");
+                         !ctx->tuning.host_decommit;
         if (J.dev_decommit) launch_decommit(ctx, J, LN);
         FR_HIP(ctx, hipGetLastError());
         ctx->phase_ms[0] = ms_since(J.t_start);  // commit phase fully enqueued
@@ -864,7 +857,7 @@ int prove_finish_batch(Ctx* ctx, uint8_t* out_commitments, std::vector<ProofData
         // the index and output regions of the arena are laid out back to back (words region, then hashes region), so the
         // hash part may start right behind the words actually used
         k::Launch L1 = ctx->launch();  // the gather works on absolute indices: a single-blob launch
-        if (out_bytes <= ((size_t)1 << 20) && !getenv("FRIEDA_GATHER_COPY")) {
+        if (out_bytes <= ((size_t)1 << 20) && !ctx->tuning.gather_copy) {
             // small openings (the usual case): the kernel reads its index lists from, and writes its results to, the pinned
             // staging block directly over PCIe — one launch instead of copy + launch + copy (each copy costs 10-20 us of setup)
             k::gather(L1, reinterpret_cast<const uint32_t*>(A), hidx, nw, reinterpret_cast<uint32_t*>(hp), hidx + nw, nh, hp + wbytes);

@@ -181,10 +181,11 @@ int frieda_circle_interpolate_cells_any(frieda_ctx* ctx, const uint32_t* d_cells
                                         uint32_t log_cell, uint32_t log_coef, uint32_t log_domain, uint32_t* d_coef, uint32_t* out_used) {
     if (!ctx || !d_cells || !cell_index || !d_coef || ncols == 0 || ncols > 1024) return FRIEDA_ERR_ARG;
     if (log_cell > log_coef || log_coef > log_domain || log_domain < 1 || log_domain > FRIEDA_MAX_LOG_DOMAIN) return FRIEDA_ERR_ARG;
+    FR_GUARD_BEGIN
+    FR_NO_JOB(&ctx->c);  // before the host-side selection below (up to 65536 x 256 x 256 multiplications): a busy context answers at once
     if (log_coef - log_cell > 8) return ctx->c.fail(FRIEDA_ERR_ARG, "cells (any): at most 256 cells are needed in this form (the host-side selection)");
     const uint32_t R = 1u << (log_coef - log_cell);
     if (n_avail < R || n_avail > 65536) return ctx->c.fail(FRIEDA_ERR_ARG, "cells (any): need between 2^(log_coef - log_cell) and 65536 cells");
-    FR_GUARD_BEGIN
     for (uint32_t r = 0; r < n_avail; r++)
         if ((uint64_t)cell_index[r] >= ((uint64_t)1 << (log_domain - log_cell))) return ctx->c.fail(FRIEDA_ERR_ARG, "cells: cell index out of range");
     std::vector<uint32_t> chosen;
@@ -204,8 +205,8 @@ int frieda_reconstruct_cells_device(frieda_ctx* ctx, const uint32_t* d_cells, co
     if (!ctx || !d_cells || !cell_index || (len && !d_out_bytes)) return FRIEDA_ERR_ARG;
     if (log_coef > FRIEDA_MAX_LOG_DOMAIN) return FRIEDA_ERR_ARG;
     const size_t n_felts = (size_t)4 << log_coef;
-    if ((8 * len + 29) / 30 > n_felts) return ctx->c.fail(FRIEDA_ERR_ARG, "len does not fit the polynomial");
     FR_GUARD_BEGIN
+    if ((8 * len + 29) / 30 > n_felts) return ctx->c.fail(FRIEDA_ERR_ARG, "len does not fit the polynomial");
     FR_HIP(&ctx->c, hipSetDevice(ctx->c.device));
     const size_t coef_bytes = (sizeof(uint32_t) * n_felts + 255) & ~(size_t)255;
     int rc = interpolate_cells(ctx, d_cells, cell_index, n_cells, 4, log_cell, log_coef, log_domain, nullptr, coef_bytes);
@@ -231,7 +232,9 @@ int interpolate_points(frieda_ctx* ctx, const uint32_t* d_cells, const uint32_t*
     // The distinct sampled positions (first occurrence of every cell wins) and where their values sit in the caller's buffer are worked out
     // on the device (erasure_sample_lists): only their number comes back, for the argument checks below.
     const uint32_t domain_cells = (uint32_t)(N >> log_cell);
-    if ((((uint64_t)n_cells * ncols) << log_cell) > 0x100000000ull) return c.fail(FRIEDA_ERR_ARG, "points: sample buffer beyond 2^32 words");
+    // n_cells * ncols * 2^log_cell <= 2^32, checked without forming the product (n_cells < 2^32, ncols <= 2^10, log_cell <= 27: it can reach
+    // 2^69); every 32-bit position computed in erasure.hip relies on this bound
+    if ((uint64_t)n_cells > (0x100000000ull >> log_cell) / ncols) return c.fail(FRIEDA_ERR_ARG, "points: sample buffer beyond 2^32 words");
     const size_t s_cap = (size_t)n_cells << log_cell;  // points offered, repeats included
     if (s_cap < K + 2)
         return c.fail(FRIEDA_ERR_ARG, "points: need at least 2^log_coef + 2 distinct points (the locator polynomial needs two spare samples)");
@@ -241,12 +244,8 @@ int interpolate_points(frieda_ctx* ctx, const uint32_t* d_cells, const uint32_t*
     // (O(K^2)); many small cells do too, as the single points they consist of (the per-cell form costs K * K / M factor evaluations:
     // 38 ms against 4 ms for 2^16 cells of 16 on a 2^24 domain, 3.1 against 1.6 ms for 2^14 of them at 2^22; cells of 256 are level
     // there).  FRIEDA_ERASURE_TREE_MIN_LOG: smallest log_coef that takes the tree (default 15: 0.67 against 0.97 ms there; the parity
-    // tests lower it; 32 = never; read per call because the tests run both routes in one process).
-    const uint32_t tree_min_log = [] {
-        const char* e = getenv("FRIEDA_ERASURE_TREE_MIN_LOG");
-        const int v = e ? atoi(e) : 15;
-        return (uint32_t)(v < 6 ? 6 : v);
-    }();
+    // tests lower it per context; 32 = never).
+    const uint32_t tree_min_log = c.tuning.erasure_tree_min_log;
     const bool by_cells = log_cell >= 1 && !(log_coef >= tree_min_log && 2 * log_coef >= 32 + log_cell);
     const uint32_t n_use_cells = by_cells ? (uint32_t)(K >> log_cell) + 1 : 0;
     const uint32_t s_use = by_cells ? (uint32_t)((size_t)n_use_cells << log_cell) : (uint32_t)K + 2;
@@ -300,8 +299,8 @@ int interpolate_points(frieda_ctx* ctx, const uint32_t* d_cells, const uint32_t*
     hipStream_t s = c.stream;
     const k::Launch LN = c.launch();
     FR_HIP(&c, hipMemcpyAsync(A + o_idx, cell_index, 4 * (size_t)n_cells, hipMemcpyHostToDevice, s));
-    k::erasure_sample_lists(LN, W32(o_idx), n_cells, domain_cells, ncols, log_cell, W32(o_own), W32(o_csum), W32(o_coff), W32(o_fc), W32(o_fr),
-                            W32(o_state), W32(o_pos), W32(o_src));
+    FR_HIP(&c, k::erasure_sample_lists(LN, W32(o_idx), n_cells, domain_cells, ncols, log_cell, W32(o_own), W32(o_csum), W32(o_coff), W32(o_fc), W32(o_fr),
+                            W32(o_state), W32(o_pos), W32(o_src)));
     uint32_t state[2] = {0, 0};
     FR_HIP(&c, hipMemcpyAsync(state, A + o_state, 8, hipMemcpyDeviceToHost, s));
     FR_HIP(&c, hipMemsetAsync(A + o_bad, 0, 4, s));
@@ -433,8 +432,8 @@ int frieda_reconstruct_points_device(frieda_ctx* ctx, const uint32_t* d_cells, c
     if (!ctx || !d_cells || !cell_index || (len && !d_out_bytes) || n_cells == 0) return FRIEDA_ERR_ARG;
     if (log_coef > FRIEDA_MAX_LOG_DOMAIN) return FRIEDA_ERR_ARG;
     const size_t n_felts = (size_t)4 << log_coef;
-    if ((8 * len + 29) / 30 > n_felts) return ctx->c.fail(FRIEDA_ERR_ARG, "len does not fit the polynomial");
     FR_GUARD_BEGIN
+    if ((8 * len + 29) / 30 > n_felts) return ctx->c.fail(FRIEDA_ERR_ARG, "len does not fit the polynomial");
     FR_HIP(&ctx->c, hipSetDevice(ctx->c.device));
     const size_t coef_bytes = (sizeof(uint32_t) * n_felts + 255) & ~(size_t)255;
     int rc = interpolate_points(ctx, d_cells, cell_index, n_cells, 4, log_cell, log_coef, log_domain, nullptr, coef_bytes);

@@ -1127,26 +1127,16 @@ __global__ __launch_bounds__(256) void grind_dev_kernel(GrindArgs a) {
 //            workgroup)
 enum TreeKernel { T_WIDE, T_WIDE3, T_NINE, T_SMALL };
 constexpr uint32_t T9_MIN_LOG = 8;
-uint32_t env_knob(const char* name, uint32_t dflt, uint32_t lo, uint32_t hi) {
-    const char* e = getenv(name);
-    const uint32_t v = e ? (uint32_t)atoi(e) : dflt;
-    return v >= lo && v <= hi ? v : dflt;
-}
-// tuning knobs (defaults = measured best): largest level-A size of the nine-level kernel; largest hand-over size of the top kernel
-const uint32_t T5_WIDE_LOG = env_knob("FRIEDA_T5_WIDE_LOG", 18, 16, 24);  // smallest launch (nodes) of the register-subtree kernel
-// smallest launch (level-A nodes) whose leaf / fold kernel stops after its three register levels (0 = never)
-const uint32_t T5_REG3_LOG = env_knob("FRIEDA_T5_REG3_LOG", 0, 0, 30);
-const uint32_t T9_MAX_LOG = env_knob("FRIEDA_T9_MAX_LOG", 17, 8, 19);
-const uint32_t TOP_MAX_LOG = env_knob("FRIEDA_TOP_MAX_LOG", 9, 9, 11);
-
-TreeKernel tree_kernel_for(uint32_t level_a, uint32_t batch, bool aligned16, bool reg3_ok = false) {
+// tuning knobs (kernels.h Tuning: defaults = measured best): smallest launch of the register-subtree kernel; three-register-level form;
+// largest level-A size of the nine-level kernel; largest hand-over size of the top kernel
+TreeKernel tree_kernel_for(const Tuning& tn, uint32_t level_a, uint32_t batch, bool aligned16, bool reg3_ok = false) {
     uint32_t batch_log = 0;
     while ((2u << batch_log) <= batch) batch_log++;
-    if (reg3_ok && aligned16 && T5_REG3_LOG && level_a >= 10 && level_a + batch_log >= T5_REG3_LOG) return T_WIDE3;
+    if (reg3_ok && aligned16 && tn.t5_reg3_log && level_a >= 10 && level_a + batch_log >= tn.t5_reg3_log) return T_WIDE3;
     // the register-subtree kernel uses 16-byte column accesses; anything unaligned (Level B callers may pass any pointers)
     // takes a 256-unit kernel, which produces the same hashes
-    if (aligned16 && level_a >= 10 && level_a + batch_log >= T5_WIDE_LOG) return T_WIDE;
-    if (level_a >= T9_MIN_LOG && level_a <= T9_MAX_LOG) return T_NINE;
+    if (aligned16 && level_a >= 10 && level_a + batch_log >= tn.t5_wide_log) return T_WIDE;
+    if (level_a >= T9_MIN_LOG && level_a <= tn.t9_max_log) return T_NINE;
     return T_SMALL;
 }
 uint32_t tree_kernel_levels(TreeKernel k, uint32_t level_a) {
@@ -1164,7 +1154,7 @@ bool tree_args_aligned16(const TreeArgs& a) {
 uint32_t launch_tree_a(const Launch& L, int mode, const TreeArgs& a, const char* name, double (*bytes_of)(int, uint32_t, uint32_t)) {
     const size_t total = (size_t)1 << a.level_a;
     // the three-level form only where every level is kept (its last level is four times what the root-only scratch holds)
-    const TreeKernel k = tree_kernel_for(a.level_a, L.batch, tree_args_aligned16(a), mode != T_NODE && a.store_all);
+    const TreeKernel k = tree_kernel_for(*L.tune, a.level_a, L.batch, tree_args_aligned16(a), mode != T_NODE && a.store_all);
     const uint32_t levels = tree_kernel_levels(k, a.level_a);
     const uint32_t units = (k == T_WIDE || k == T_WIDE3) ? T5_UNITS : 256u;
     const dim3 grid((unsigned)((total + units - 1) / units), L.batch);
@@ -1220,7 +1210,7 @@ void finish_tree(const Launch& L, const TreeArgs& a, uint32_t m, uint32_t cur, c
                  uint8_t* root_out, DevTranscript* tr, const DevTranscript* tr_init, size_t tr_init_pitch) {
     uint8_t* layers = a.store_all ? a.layers : nullptr;
     auto bytes_of = [](int, uint32_t la, uint32_t levels) -> double { return node_levels_bytes(la, levels); };
-    while (cur > TOP_MAX_LOG) {
+    while (cur > L.tune->top_max_log) {
         TreeArgs b = a;
         b.skip_a = 0;
         b.level_a = cur - 1;
@@ -1282,7 +1272,7 @@ void build_tree(const Launch& L, int mode, TreeArgs a, uint32_t m, uint8_t* laye
 void encode_and_first_tree(const Launch& L, const uint32_t* d_coef, size_t coef_stride, uint32_t Lc, uint32_t n, const uint32_t* d_tw,
                            DomainScalars ds, uint32_t* d_eval, size_t eval_stride, uint8_t* d_layers, uint8_t* d_scratch, uint8_t* d_root,
                            DevTranscript* tr, const DevTranscript* tr_init, size_t tr_init_pitch) {
-    static const bool no_fuse = getenv("FRIEDA_NO_ENCODE_TREE_FUSION") != nullptr;  // A/B knob
+    const bool no_fuse = L.tune->no_encode_tree_fusion;  // A/B knob
     uint8_t* s0 = d_scratch;
     uint8_t* s1 = d_scratch ? d_scratch + ((size_t)32 << (n > 4 ? n - 4 : 0)) : nullptr;
     EncodeTreeSink sink{d_layers, s0};
@@ -1304,9 +1294,8 @@ void encode_and_first_tree(const Launch& L, const uint32_t* d_coef, size_t coef_
     finish_tree(L, a, n, cur, d_layers ? d_layers + merkle_layer_offset(n, cur) : s0, s0, s1, d_root, tr, tr_init, tr_init_pitch);
 }
 
-bool small_domain_shape(uint32_t Lc, uint32_t n) {
-    static const bool off = getenv("FRIEDA_NO_SMALL_FUSED") != nullptr;  // A/B knob: the general path for every size
-    return !off && n >= SMALL_MIN_LOG_DOMAIN && n <= SMALL_MAX_LOG_DOMAIN && Lc <= SMALL_MAX_LOG_COEF && Lc <= n;
+bool small_domain_shape(const Tuning& tn, uint32_t Lc, uint32_t n) {
+    return !tn.no_small_fused /* A/B knob: the general path for every size */ && n >= SMALL_MIN_LOG_DOMAIN && n <= SMALL_MAX_LOG_DOMAIN && Lc <= SMALL_MAX_LOG_COEF && Lc <= n;
 }
 
 void small_encode_and_first_tree(const Launch& L, const uint8_t* d_data, size_t len, size_t data_stride, uint32_t Lc, uint32_t n,

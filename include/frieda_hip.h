@@ -75,10 +75,11 @@ int frieda_ctx_release_workspace(frieda_ctx* ctx);
  * configurations whose last FRI layer exceeds 2^11 points always use the host policy. */
 int frieda_ctx_set_host_channel(frieda_ctx* ctx, int enabled);
 
-/* TEST HOOK, not part of the protocol: the acceptance bound of Channel::draw_felt (stwo: every drawn word must be < 2P, else
- * redraw — a ~4e-9 event).  A lower bound makes the redraw branch fire on most draws so that it can be compared against the
- * oracle; proofs made with a non-default bound do not verify.  0 restores 2P. */
-int frieda_ctx_test_set_draw_bound(frieda_ctx* ctx, uint32_t bound);
+/* Tuning and A/B options of THIS context (none is needed in normal use; every option selects another kernel or plan for the SAME
+ * result — DESIGN.md §8b lists them).  `name` is the name of the environment variable that sets the option's default when a context
+ * is created, e.g. "FRIEDA_TAIL_RUN_LOG", "FRIEDA_NO_ENCODE_TREE_FUSION", "FRIEDA_HOST_DECOMMIT"; a context never re-reads the
+ * environment after creation and no option is process-wide.  FRIEDA_ERR_ARG: unknown name or value out of range. */
+int frieda_ctx_set_option(frieda_ctx* ctx, const char* name, int64_t value);
 
 /* measurement aid: when enabled, HIP events are recorded on the ctx stream around every kernel launch.
  * frieda_ctx_kernel_timing_report synchronises the stream and writes a JSON object
@@ -307,9 +308,13 @@ int frieda_reconstruct_cells_device(frieda_ctx* ctx, const uint32_t* d_cells, co
  * cells and Z_S the product of their cell polynomials pi^(log_cell - 1)(x) - k_cell instead.  Cost: five transforms + ~2^(2 log_coef
  * - log_cell) multiplications below 2^15 coefficients; from there on (single points, or many small cells) Z_S comes from a product
  * tree, O(K log^2 K) (a 15.7 MB blob from 2^20 + 2 points of its 2^24 codeword: 3.2 ms).
- * 1 <= log_coef <= log_domain <= FRIEDA_MAX_LOG_DOMAIN - 1, log_domain >= 2.  Every sample offered,
+ * 1 <= log_coef <= log_domain <= FRIEDA_MAX_LOG_DOMAIN - 1, log_domain >= 2.  Every DISTINCT cell offered,
  * used or not, is then compared with the re-encoded result: samples that are not values of one polynomial of 2^log_coef
- * coefficients give FRIEDA_ERR_ARG (and unspecified d_coef contents) instead of a wrong answer. */
+ * coefficients give FRIEDA_ERR_ARG (and unspecified d_coef contents) instead of a wrong answer.  A repeated cell index is dropped
+ * before that (the first occurrence in the list counts; later ones are neither used nor checked): a caller pooling samples from
+ * several peers should de-duplicate by index itself if it wants a conflicting repeat reported.  The first call at a size builds the
+ * twiddle tables of the product tree's domains (2^7 .. 2^(log_coef + 1) points, about twice the largest in total, kept by the
+ * context): the times quoted are for the calls after it. */
 int frieda_circle_interpolate_points(frieda_ctx* ctx, const uint32_t* d_cells, const uint32_t* cell_index, uint32_t n_cells, uint32_t ncols,
                                      uint32_t log_cell, uint32_t log_coef, uint32_t log_domain, uint32_t* d_coef);
 /* the same for frieda's 4-column layout, followed by the packer: sampled points -> the original len bytes */

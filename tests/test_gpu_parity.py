@@ -289,7 +289,7 @@ def test_commit_matches_oracle_ragged(gpu_ctx, oracle, n_bytes, B):
 def test_fused_encode_tree_matches_oracle(gpu_ctx, oracle, n_bytes, B):
     """The last transform pass fused with leaf hashing (ntt_last_tree7) against the oracle: commit root, whole proof, and every
     stored tree level and the evaluation through the openings of 300 queries.  (The unfused build variants behind the getenv
-    knobs are read once per process; tests/test_gpu_shapes.py::test_knob_variants_in_subprocess runs them.)"""
+    options are per context; tests/test_gpu_shapes.py::test_knob_variants_on_their_own_context runs them.)"""
     import frieda_amd
 
     data = splitmix64_bytes(77 + B, n_bytes).tobytes()
@@ -1227,12 +1227,15 @@ def test_grind_retry_loop(gpu_ctx, oracle, monkeypatch):
     blobs = [splitmix64_bytes(9500 + i, 900).tobytes() for i in range(6)]
     expect = [oracle.commit_and_generate_proof(b, i, oracle.make_config(18, 4, 0, 8)) for i, b in enumerate(blobs)]
     assert len({p.c.proof_of_work for _, p in expect}) > 1
-    monkeypatch.setenv("FRIEDA_TEST_GRIND_FIRST_LOG", "10")  # 1024 nonces, then 2048, 4096, ...
-    got = gpu_ctx.commit_and_generate_proof_batch(blobs, list(range(len(blobs))), cfg)
-    for (er, ep), (gr, gp) in zip(expect, got):
-        assert er == gr and ep.serialize() == gp.serialize()
-    r, p = gpu_ctx.commit_and_generate_proof(blobs[0], 0, cfg)
-    assert r == expect[0][0] and p.serialize() == expect[0][1].serialize()
+    gpu_ctx.set_option("FRIEDA_TEST_GRIND_FIRST_LOG", 10)  # 1024 nonces, then 2048, 4096, ... (this context only)
+    try:
+        got = gpu_ctx.commit_and_generate_proof_batch(blobs, list(range(len(blobs))), cfg)
+        for (er, ep), (gr, gp) in zip(expect, got):
+            assert er == gr and ep.serialize() == gp.serialize()
+        r, p = gpu_ctx.commit_and_generate_proof(blobs[0], 0, cfg)
+        assert r == expect[0][0] and p.serialize() == expect[0][1].serialize()
+    finally:
+        gpu_ctx.set_option("FRIEDA_TEST_GRIND_FIRST_LOG", 0)
 
 
 def test_release_workspace(gpu_ctx):
@@ -1278,21 +1281,18 @@ def test_openings_device_path_host_path_and_fallbacks(gpu_ctx, oracle, monkeypat
         data = resolve_input(spec, None)
         o_root, o_proof = oracle.commit_and_generate_proof(data, seed, oracle.make_config(*cfg))
         for host in (False, True):
-            if host:
-                monkeypatch.setenv("FRIEDA_HOST_DECOMMIT", "1")
-            else:
-                monkeypatch.delenv("FRIEDA_HOST_DECOMMIT", raising=False)
+            gpu_ctx.set_option("FRIEDA_HOST_DECOMMIT", int(host))
             r, p = gpu_ctx.commit_and_generate_proof(data, seed, _cfg(frieda_amd, *cfg))
             assert r == o_root and p.serialize() == o_proof.serialize(), (spec, host)
     # batch through the forced host path
-    monkeypatch.setenv("FRIEDA_HOST_DECOMMIT", "1")
+    gpu_ctx.set_option("FRIEDA_HOST_DECOMMIT", 1)
     cfg = _cfg(frieda_amd, 6, 4, 0, 20)
     blobs = [splitmix64_bytes(9900 + i, 3000).tobytes() for i in range(5)]
     got = gpu_ctx.commit_and_generate_proof_batch(blobs, [1, 2, 3, 4, 5], cfg)
     for i, (ra, pa) in enumerate(got):
         o_root, o_proof = oracle.commit_and_generate_proof(blobs[i], i + 1, oracle.make_config(6, 4, 0, 20))
         assert ra == o_root and pa.serialize() == o_proof.serialize()
-    monkeypatch.delenv("FRIEDA_HOST_DECOMMIT", raising=False)
+    gpu_ctx.set_option("FRIEDA_HOST_DECOMMIT", 0)
     # 1000 queries on a 2^14 domain: ~970 unique, 14 * 970 table slots > the kernel's capacity -> it reports overflow, host plans
     # 1100 queries: above the kernel's limit, host plans from the start
     data = splitmix64_bytes(9950, 15000).tobytes()

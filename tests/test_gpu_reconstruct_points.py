@@ -125,11 +125,12 @@ def test_product_tree_route_matches_line_route(gpu_ctx, oracle, monkeypatch, L, 
     d_cells, d_c = DevBuf.from_array(gpu_ctx, cells), DevBuf(gpu_ctx, 4 * ncols << L)
     got = {}
     for route, min_log in (("lines", "32"), ("tree", "6")):
-        monkeypatch.setenv("FRIEDA_ERASURE_TREE_MIN_LOG", min_log)
+        gpu_ctx.set_option("FRIEDA_ERASURE_TREE_MIN_LOG", int(min_log))
         poison = np.full((ncols, 1 << L), 0xEEEEEEEE, dtype=np.uint32)  # the second route must write its own answer
         _check(gpu_ctx, gpu_ctx._L.frieda_dev_upload(gpu_ctx._h, d_c.ptr, poison.ctypes.data, poison.nbytes))
         _check(gpu_ctx, gpu_ctx._L.frieda_circle_interpolate_points(gpu_ctx._h, d_cells.ptr, idx.ctypes.data, n_pts, ncols, 0, L, n, d_c.ptr))
         got[route] = d_c.to_array(np.uint32, (ncols, 1 << L)).copy()
+    gpu_ctx.set_option("FRIEDA_ERASURE_TREE_MIN_LOG", 6)  # (the corrupted-sample checks below take the tree route; reset at the end)
     assert np.array_equal(got["tree"], coef) and np.array_equal(got["lines"], coef)
     if n <= 12:
         vals = np.ascontiguousarray(cells[:, :, 0])
@@ -137,8 +138,10 @@ def test_product_tree_route_matches_line_route(gpu_ctx, oracle, monkeypatch, L, 
     # a corrupted word among the points the locator is built from, tree route
     cells[3, ncols - 1, 0] = (int(cells[3, ncols - 1, 0]) + 1) % P
     d_bad = DevBuf.from_array(gpu_ctx, cells)
-    assert gpu_ctx._L.frieda_circle_interpolate_points(gpu_ctx._h, d_bad.ptr, idx.ctypes.data, n_pts, ncols, 0, L, n, d_c.ptr) == 1
-    assert "not values of one polynomial" in gpu_ctx._L.frieda_last_error(gpu_ctx._h).decode()
+    rc_bad = gpu_ctx._L.frieda_circle_interpolate_points(gpu_ctx._h, d_bad.ptr, idx.ctypes.data, n_pts, ncols, 0, L, n, d_c.ptr)
+    msg = gpu_ctx._L.frieda_last_error(gpu_ctx._h).decode()
+    gpu_ctx.set_option("FRIEDA_ERASURE_TREE_MIN_LOG", 15)  # the default, for the tests that follow on this context
+    assert rc_bad == 1 and "not values of one polynomial" in msg
 
 
 @pytest.mark.parametrize("L,n,m", [(14, 18, 0), (15, 17, 0), (12, 16, 2), (16, 20, 0)])
@@ -198,10 +201,11 @@ def test_random_shapes_both_routes(gpu_ctx, oracle, monkeypatch):
         cells = _cells(ev, idx, m)
         d_cells, d_c = DevBuf.from_array(gpu_ctx, cells), DevBuf(gpu_ctx, 4 * ncols << L)
         for min_log in ("6", "32"):
-            monkeypatch.setenv("FRIEDA_ERASURE_TREE_MIN_LOG", min_log)
+            gpu_ctx.set_option("FRIEDA_ERASURE_TREE_MIN_LOG", int(min_log))
             rc = gpu_ctx._L.frieda_circle_interpolate_points(gpu_ctx._h, d_cells.ptr, idx.ctypes.data, n_cells, ncols, m, L, n, d_c.ptr)
             assert rc == 0, (case, L, n, m, ncols, n_cells, min_log, gpu_ctx._L.frieda_last_error(gpu_ctx._h))
             assert np.array_equal(d_c.to_array(np.uint32, (ncols, 1 << L)), coef), (case, L, n, m, ncols, n_cells, min_log)
+    gpu_ctx.set_option("FRIEDA_ERASURE_TREE_MIN_LOG", 15)
 
 
 def _encode_on_device(gpu_ctx, data, B):

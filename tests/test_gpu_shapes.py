@@ -162,39 +162,39 @@ def test_circle_evaluate_mb_scale_shapes(gpu_ctx, oracle, L, n, ncols):
     assert np.array_equal(got, exp)
 
 
-KNOB_SCRIPT = r"""
-import sys
-sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
-import frieda_amd
-from oracle import oracle as O
-from conftest import splitmix64_bytes
-ctx = frieda_amd.Context(0)
-for L, B in ((16, 4), (18, 2), (13, 7), (12, 4)):
-    length = (4 << L) * 30 // 8 - 4321
-    data = splitmix64_bytes(3000 + L, length).tobytes()
-    assert ctx.commit(data, B) == O.commit(data, B), ("commit", L, B)
-    cfg = frieda_amd.PcsConfig(frieda_amd.FriConfig(B, 0, 40), 6)
-    r, p = ctx.commit_and_generate_proof(data, 9, cfg)
-    o_r, o_p = O.commit_and_generate_proof(data, 9, O.make_config(6, B, 0, 40))
-    assert r == o_r and p.serialize() == o_p.serialize(), ("prove", L, B)
-print("knob ok")
-"""
-
-
 @pytest.mark.parametrize("knob", ["FRIEDA_NO_ENCODE_TREE_FUSION", "FRIEDA_NTT_NO_PAD8", "FRIEDA_NTT_TREE_REG_ONLY", "FRIEDA_T5_REG3_LOG=18", "FRIEDA_NTT_CPW=2",
-                                  "FRIEDA_HOST_DECOMMIT"])
-def test_knob_variants_in_subprocess(gpu_ctx, knob):
-    """The A/B knobs of DESIGN.md §8b select other kernels / templates for the same result (unfused encode + leaf launch, generic
-    strided pass instead of the padded 8-layer one, the register-only tree variants).  They are read once per process, so each
-    variant runs in a child process: commit root and whole proof against the oracle on four shapes."""
-    import os
-    import subprocess
-    import sys
+                                  "FRIEDA_HOST_DECOMMIT", "FRIEDA_NO_SMALL_FUSED", "FRIEDA_NTT_CPW_SMALL=4", "FRIEDA_NTT_REP", "FRIEDA_TAIL_RUN_LOG=6",
+                                  "FRIEDA_T9_MAX_LOG=12", "FRIEDA_UNPACK_TILES=1", "FRIEDA_T5_WIDE_LOG=16"])
+def test_knob_variants_on_their_own_context(oracle, knob):
+    """The A/B options of DESIGN.md §8b select other kernels / templates for the same result (unfused encode + leaf launch, generic
+    strided pass instead of the padded 8-layer one, the register-only tree variants, ...).  They are PER CONTEXT
+    (frieda_ctx_set_option; the environment only sets a new context's defaults), so each variant runs on its own context in this
+    process: commit root and whole proof against the oracle on five shapes."""
+    import frieda_amd
 
-    from conftest import ROOT
-
-    env = dict(os.environ)
     name, _, val = knob.partition("=")
-    env[name] = val or "1"
-    r = subprocess.run([sys.executable, "-c", KNOB_SCRIPT, ROOT], capture_output=True, text=True, timeout=600, env=env)
-    assert r.returncode == 0 and "knob ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+    ctx = frieda_amd.Context(0)
+    try:
+        ctx.set_option(name, int(val or "1"))
+        for L, B in ((16, 4), (18, 2), (13, 7), (12, 4), (7, 4)):
+            length = (4 << L) * 30 // 8 - 4321 if L > 8 else (4 << L) * 30 // 8 - 7
+            data = splitmix64_bytes(3000 + L, length).tobytes()
+            assert ctx.commit(data, B) == oracle.commit(data, B), ("commit", L, B)
+            cfg = frieda_amd.PcsConfig(frieda_amd.FriConfig(B, 0, 40), 6)
+            r, p = ctx.commit_and_generate_proof(data, 9, cfg)
+            o_r, o_p = oracle.commit_and_generate_proof(data, 9, oracle.make_config(6, B, 0, 40))
+            assert r == o_r and p.serialize() == o_p.serialize(), ("prove", L, B)
+    finally:
+        ctx.close()
+
+
+def test_options_are_per_context_and_checked(gpu_ctx):
+    import frieda_amd
+
+    with pytest.raises(frieda_amd.FriedaError):
+        gpu_ctx.set_option("FRIEDA_NO_SUCH_OPTION", 1)
+    with pytest.raises(frieda_amd.FriedaError):
+        gpu_ctx.set_option("FRIEDA_TAIL_RUN_LOG", 99)
+    other = frieda_amd.Context(0)
+    other.set_option("FRIEDA_TAIL_RUN_LOG", 5)  # leaves gpu_ctx (and every other context) alone: nothing to observe but no error
+    other.close()

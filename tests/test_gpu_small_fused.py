@@ -89,37 +89,24 @@ def test_small_device_blobs_unaligned_and_batched(gpu_ctx, oracle, L, B):
         assert g_root == o_root and g_proof.serialize() == o_proof.serialize()
 
 
-def test_reference_bench_inputs_both_paths_in_child_processes(gpu_ctx):
-    """The reference's bench inputs (i % 256 for 1024 / 4096 bytes) through the fused path and, with FRIEDA_NO_SMALL_FUSED=1, through the
-    general one: the same known roots (tests/golden/vectors.json) and the same proof bytes."""
-    import os
-    import subprocess
-    import sys
+def test_reference_bench_inputs_fused_and_general_path(gpu_ctx):
+    """The reference's bench inputs (i % 256 for 1024 / 4096 bytes) through the fused path and, on a context with FRIEDA_NO_SMALL_FUSED
+    set, through the general one: the same known roots (tests/golden/vectors.json) and the same proof bytes."""
+    import frieda_amd
 
-    from conftest import ROOT
-
-    script = r"""
-import sys
-sys.path.insert(0, sys.argv[1])
-import frieda_amd, hashlib
-ctx = frieda_amd.Context(0)
-cfg = frieda_amd.PcsConfig(frieda_amd.FriConfig(4, 0, 20), 20)
-for n in (1024, 4096):
-    data = bytes(i % 256 for i in range(n))
-    r = ctx.commit(data, 4)
-    r2, p = ctx.commit_and_generate_proof(data, n, cfg)
-    assert r == r2 and frieda_amd.verify(p, n)
-    print(n, r.hex(), hashlib.sha256(p.serialize()).hexdigest())
-"""
-    outs = []
-    for knob in (None, "1"):
-        env = dict(os.environ)
-        env.pop("FRIEDA_NO_SMALL_FUSED", None)
-        if knob:
-            env["FRIEDA_NO_SMALL_FUSED"] = knob
-        r = subprocess.run([sys.executable, "-c", script, ROOT], capture_output=True, text=True, timeout=300, env=env)
-        assert r.returncode == 0, r.stderr[-2000:]
-        outs.append(r.stdout)
-    assert outs[0] == outs[1]
-    assert "1024 636256479b7a848e6664d0d423ec1f84c3d41788c6f783e99ab4e5d058d8264c" in outs[0]
-    assert "4096 1e6e5ced9bc64793a1b87dcca719af859cd34406d02147f6849b8f02c914ec74" in outs[0]
+    general = frieda_amd.Context(0)
+    general.set_option("FRIEDA_NO_SMALL_FUSED", 1)
+    cfg = frieda_amd.PcsConfig(frieda_amd.FriConfig(4, 0, 20), 20)
+    known = {1024: "636256479b7a848e6664d0d423ec1f84c3d41788c6f783e99ab4e5d058d8264c", 4096: "1e6e5ced9bc64793a1b87dcca719af859cd34406d02147f6849b8f02c914ec74"}
+    try:
+        for n in (1024, 4096):
+            data = bytes(i % 256 for i in range(n))
+            outs = []
+            for ctx in (gpu_ctx, general):
+                r = ctx.commit(data, 4)
+                r2, p = ctx.commit_and_generate_proof(data, n, cfg)
+                assert r == r2 and frieda_amd.verify(p, n)
+                outs.append((r.hex(), p.serialize()))
+            assert outs[0] == outs[1] and outs[0][0] == known[n]
+    finally:
+        general.close()

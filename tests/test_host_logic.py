@@ -224,7 +224,7 @@ def test_rust_bindings_declare_every_symbol():
 
     from frieda_amd import _lib
 
-    hdr = re.sub(r"/\*.*?\*/", "", open(_lib.HEADER_PATH).read(), flags=re.S)
+    hdr = re.sub(r"/\*.*?\*/", "", open(_lib.HEADER_PATH).read() + open(_lib.TESTING_HEADER_PATH).read(), flags=re.S)
     decl = {}
     for m in re.finditer(r"\b(frieda_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", hdr):
         args = m.group(2).strip()

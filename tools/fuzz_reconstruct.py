@@ -68,7 +68,7 @@ def run(budget, seed, ctx=None):
             idx = nrng.permutation(total)[:n_cells].astype(np.uint32)
             cells = np.ascontiguousarray(ev.reshape(4, -1, 1 << m)[:, idx, :].transpose(1, 0, 2))
             tree = rng.random() < 0.5
-            os.environ["FRIEDA_ERASURE_TREE_MIN_LOG"] = "6" if tree else "32"
+            ctx.set_option("FRIEDA_ERASURE_TREE_MIN_LOG", 6 if tree else 32)
             corrupt = rng.random() < 0.2
             if corrupt:
                 cells[rng.randrange(n_cells), rng.randrange(4), rng.randrange(1 << m)] ^= 1 << rng.randrange(30)
@@ -82,7 +82,7 @@ def run(budget, seed, ctx=None):
             else:
                 assert ctx.reconstruct_from_points(cells, idx, L, n, size) == data, ("points", size, B, m, n_cells, tree)
                 counts["points_cells" if m > 0 else ("points_tree" if tree and L >= 6 else "points_lines")] += 1
-    os.environ.pop("FRIEDA_ERASURE_TREE_MIN_LOG", None)
+    ctx.set_option("FRIEDA_ERASURE_TREE_MIN_LOG", 15)
     return counts, time.time() - t0
 
 
