@@ -25,7 +25,7 @@ __device__ __forceinline__ size_t tw_level_offset_dev(uint32_t n, uint32_t lv) {
 // blockIdx.y — blockIdx.z in the transforms — times bstride); the DevTranscripts form a contiguous array indexed by b;
 // twiddle tables are shared.  batch == 1, bstride == 0 is the single-blob case.
 struct KernelTimer;
-// Tuning and A/B knobs (DESIGN.md §8b), PER CONTEXT: a context takes its defaults from the FRIEDA_* environment variables when it is
+// Tuning and A/B knobs (DESIGN.md §10), PER CONTEXT: a context takes its defaults from the FRIEDA_* environment variables when it is
 // created and frieda_ctx_set_option changes one for that context alone; nothing here is process-wide state.  Every knob selects
 // another kernel / plan for the SAME result.
 struct Tuning {

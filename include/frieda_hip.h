@@ -76,7 +76,7 @@ int frieda_ctx_release_workspace(frieda_ctx* ctx);
 int frieda_ctx_set_host_channel(frieda_ctx* ctx, int enabled);
 
 /* Tuning and A/B options of THIS context (none is needed in normal use; every option selects another kernel or plan for the SAME
- * result — DESIGN.md §8b lists them).  `name` is the name of the environment variable that sets the option's default when a context
+ * result — DESIGN.md §10 lists them).  `name` is the name of the environment variable that sets the option's default when a context
  * is created, e.g. "FRIEDA_TAIL_RUN_LOG", "FRIEDA_NO_ENCODE_TREE_FUSION", "FRIEDA_HOST_DECOMMIT"; a context never re-reads the
  * environment after creation and no option is process-wide.  FRIEDA_ERR_ARG: unknown name or value out of range. */
 int frieda_ctx_set_option(frieda_ctx* ctx, const char* name, int64_t value);
