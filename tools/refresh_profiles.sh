@@ -35,5 +35,11 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 be
 cp $(ls $OUT/stats/*/*kernel_stats.csv | head -1) $OUT/${TAG}_prove24_kernel_stats.csv
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats22 -- python3 bench.py --log-domain 22 --steps 10 --warmup 3 $ONE > $OUT/stats22_run.json 2> $OUT/stats22_err.txt
 cp $(ls $OUT/stats22/*/*kernel_stats.csv | head -1) $OUT/${TAG}_prove22_kernel_stats.csv
-rm -rf $OUT/stats $OUT/stats22 $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_fetch_b $OUT/pmc_write_b
+# the measured loop's own mode (4 blobs per call, 2 calls in flight): what the narrow launches cost while another batch's wide ones run
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_b -- python3 bench.py --only-measured-loop --steps 24 --warmup 0 > /dev/null 2> $OUT/stats_b_err.txt
+cp $(ls $OUT/stats_b/*/*kernel_stats.csv | head -1) $OUT/${TAG}_prove24_batched_kernel_stats.csv
+# VALU utilisation of the wide kernels: SQ counters (their own pass: counters + kernel trace only), tools/valu_util.py
+rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAVES GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_sq -- python3 bench.py --steps 4 --warmup 1 $ONE > /dev/null 2> $OUT/pmc_sq_err.txt
+python tools/valu_util.py $OUT/pmc_sq > $OUT/${TAG}_valu_util_prove24.txt 2>> $OUT/pmc_sq_err.txt
+rm -rf $OUT/stats $OUT/stats22 $OUT/stats_b $OUT/pmc_sq $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_fetch_b $OUT/pmc_write_b
 ls -la $OUT
