@@ -255,7 +255,7 @@ void tree_first_layer(const Launch& L, const uint32_t* cols, size_t stride, uint
 // (circle_evaluate_into_tree), then the rest of the tree.  d_layers non-null: every level above the leaf hashes is kept and the
 // evaluation is written (generate_proof); null: only the root survives, d_scratch must hold merkle_root_scratch_bytes(n) and
 // d_root receives it (commit).  tr / tr_init as tree_first_layer.
-// small domains (2^8 .. 2^13 points, <= 2^9 coefficients per column: the reference's 1 KiB - 4 KiB bench inputs): unpack + encode +
+// small domains (2^8 .. 2^15 points, <= 2^11 coefficients per column: the reference's 1 KiB - 16 KiB bench inputs): unpack + encode +
 // first tree as ONE launch + the top kernel, straight from the blob's bytes (device or page-locked host memory)
 bool small_domain_shape(const Tuning& tn, uint32_t Lc, uint32_t n);
 void small_encode_and_first_tree(const Launch& L, const uint8_t* d_data, size_t len, size_t data_stride, uint32_t Lc, uint32_t n,

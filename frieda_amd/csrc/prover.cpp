@@ -42,7 +42,7 @@ int ensure_pinned(Ctx* ctx, size_t bytes) {
 
 // Small host blobs (the fused small-domain kernel, tree.hip) are not copied to the device at all: they are placed in a page-locked
 // block that the kernel reads directly (one PCIe read per workgroup instead of a copy command in front of the first launch).
-constexpr size_t SMALL_HOST_IN_BYTES = 16384;  // >= 15 << SMALL_MAX_LOG_COEF
+constexpr size_t SMALL_HOST_IN_BYTES = 7680;  // 15 << 9: up to 32 workgroups read the block over PCIe; larger small blobs are copied to the device first
 int ensure_pinned_in(Ctx* ctx) {
     if (ctx->pinned_in) return FRIEDA_OK;
     FR_HIP(ctx, hipHostMalloc(&ctx->pinned_in, SMALL_HOST_IN_BYTES, hipHostMallocDefault));

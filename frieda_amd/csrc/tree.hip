@@ -616,13 +616,14 @@ __global__ __launch_bounds__(256) void tree9_kernel(TreeArgs a) {
 // ------------------------------------------------------------------------------------------------
 // The reference's own bench inputs are 1 KiB .. 64 KiB (benches/commit.rs:6-10, benches/proof.rs:14-21): a 1 KiB blob is 2^7
 // coefficients per column on a 2^11 domain, and `commit` on it was four dependent launches of kernels shaped for megabytes (unpack 8.7
-// us, transform 15.4, tree 14.9, top 7.6).  For domains of 2^8 .. 2^13 points and polynomials of <= 2^9 coefficients a workgroup here
-// owns 256 consecutive evaluations of the bit-reversed domain and does everything for them: it stages the blob (<= 7.5 KB) in LDS,
-// unpacks the 30-bit felts (src/utils.rs:10-33), runs the circle FFT of its block — a block of 2^L consecutive outputs is an
-// independent size-2^L transform of the coefficient vector with that block's twiddles (ntt.hip, "Structure"); for L = 9 the one layer
-// that crosses workgroups is computed in its one-output form, c[j] +- T c[j + 256] —, hashes its 256 leaves and reduces them to one
-// hash exactly as tree9_kernel does.  The top kernel finishes the <= 32 hashes.  Same results, word for word, as the general path.
-constexpr uint32_t SMALL_MAX_LOG_COEF = 9, SMALL_MIN_LOG_DOMAIN = 8, SMALL_MAX_LOG_DOMAIN = 13;
+// us, transform 15.4, tree 14.9, top 7.6).  For domains of 2^8 .. 2^15 points and polynomials of <= 2^11 coefficients (blobs of <= 30 KB)
+// a workgroup here owns 256 consecutive evaluations of the bit-reversed domain and does everything for them: it stages the blob in
+// LDS, unpacks the 30-bit felts (src/utils.rs:10-33), runs the circle FFT of its block — a block of 2^L consecutive outputs is an
+// independent size-2^L transform of the coefficient vector with that block's twiddles (ntt.hip, "Structure"); for L > 8 the L - 8
+// layers that cross workgroups are computed in their one-output form (of each butterfly only the branch this workgroup's position
+// selects: 2^(L-8) coefficients and one workgroup-uniform twiddle per layer and element) —, hashes its 256 leaves and reduces them to
+// one hash exactly as tree9_kernel does.  The top kernel finishes the <= 128 hashes.  Same results, word for word, as the general path.
+constexpr uint32_t SMALL_MAX_LOG_COEF = 11, SMALL_MIN_LOG_DOMAIN = 8, SMALL_MAX_LOG_DOMAIN = 15;
 
 struct SmallFirstArgs {
     const uint8_t* data;  // blob bytes: device memory or page-locked host memory (read once per workgroup)
@@ -642,8 +643,9 @@ __device__ __forceinline__ uint32_t circle_twiddle_fwd(const uint32_t* __restric
 }
 
 __global__ __launch_bounds__(256) void small_first_kernel(SmallFirstArgs a) {
-    __shared__ __attribute__((aligned(16))) uint32_t BL[(15u << SMALL_MAX_LOG_COEF) / 4 + 4];  // the blob, zero beyond len, + a spare word
-    __shared__ __attribute__((aligned(16))) uint32_t CO[4u << SMALL_MAX_LOG_COEF];             // coefficients, column c at c << L
+    extern __shared__ __attribute__((aligned(16))) uint32_t SL[];  // small_first_lds_words(L): the blob, then the coefficients
+    uint32_t* const BL = SL;                                        // the blob, zero beyond len, + a spare word: (15 << L) / 4 + 4 words
+    uint32_t* const CO = SL + (((15u << a.L) + 3) / 4 + 4);         // coefficients, column c at c << L
     __shared__ __attribute__((aligned(16))) uint32_t V[4][256];
     __shared__ __attribute__((aligned(16))) uint32_t RA[8 * (256 + 4)];
     __shared__ __attribute__((aligned(16))) uint32_t QQ[2 * QBUF_WORDS];
@@ -677,7 +679,7 @@ __global__ __launch_bounds__(256) void small_first_kernel(SmallFirstArgs a) {
     const uint32_t top = L < 8 ? L : 8;  // layers 7 .. top of the block are replication (the coefficient vector is zero above 2^L)
     const uint32_t p = t & 127, cb = t >> 7;
     const uint32_t e = 256 * w + t;
-    uint32_t twd[8], t9 = 0;
+    uint32_t twd[8], tup[3] = {0, 0, 0};  // tup[i - 8]: the (workgroup-uniform) twiddle of a layer i >= 8
 #pragma unroll
     for (int i = 0; i < 8; i++) {
         twd[i] = 0;
@@ -687,7 +689,9 @@ __global__ __launch_bounds__(256) void small_first_kernel(SmallFirstArgs a) {
             twd[i] = i >= 1 ? a.tw[tw_level_offset_dev(n, (uint32_t)i - 1) + h] : circle_twiddle_fwd(a.tw, h);
         }
     }
-    if (L == 9) t9 = a.tw[tw_level_offset_dev(n, 7) + (e >> 9)];
+#pragma unroll
+    for (int i = 8; i < 11; i++)
+        if ((uint32_t)i < L) tup[i - 8] = a.tw[tw_level_offset_dev(n, (uint32_t)i - 1) + (e >> (i + 1))];
     __syncthreads();
     // ---- bytes_to_felt_le: felt k = bits [30 k, 30 k + 30) ----
     for (uint32_t k = t; k < (4u << L); k += 256) {
@@ -703,9 +707,26 @@ __global__ __launch_bounds__(256) void small_first_kernel(SmallFirstArgs a) {
         uint32_t v;
         if (L <= 8) {
             v = cc[t & ((1u << L) - 1)];
-        } else {  // L == 9: layer 8 pairs e with e ^ 256, which another workgroup owns: our output of that butterfly alone
-            const uint32_t tt = m31_mul(cc[t + 256], t9);
-            v = (w & 1u) ? m31_sub(cc[t], tt) : m31_add(cc[t], tt);
+        } else {
+            // layers L - 1 .. 8 pair e with positions other workgroups own.  Entering them, position p holds coefficient p mod 2^L; the
+            // values our element depends on are those at e with its bits 8 .. L - 1 replaced by u: cc[t + 256 u].  Layer i keeps, of the
+            // pair (u, u + 2^(i-8)), the branch bit i of e selects; its twiddle index e >> (i + 1) has only workgroup bits.
+            uint32_t arr[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) arr[u] = (uint32_t)u < (1u << (L - 8)) ? cc[t + 256u * (uint32_t)u] : 0u;
+#pragma unroll
+            for (int i = 10; i >= 8; i--) {
+                if ((uint32_t)i < L) {
+                    const int half = 1 << (i - 8);
+                    const bool hi = (w >> (i - 8)) & 1u;
+#pragma unroll
+                    for (int u = 0; u < half; u++) {
+                        const uint32_t tt = m31_mul(arr[u + half], tup[i - 8]);
+                        arr[u] = hi ? m31_sub(arr[u], tt) : m31_add(arr[u], tt);
+                    }
+                }
+            }
+            v = arr[0];
         }
         V[c][t] = v;
     }
@@ -1324,7 +1345,8 @@ void small_encode_and_first_tree(const Launch& L, const uint8_t* d_data, size_t 
     {
         // algorithmic bytes: the blob + the encode (16 N (1 + 2^-B)) + leaves (16 B in, 32 B out) + 8 node levels
         Scope scope(L, "small_first", (double)len + 4.0 * 4.0 * (N + (double)((size_t)1 << Lc)) + 48.0 * N + node_levels_bytes(n - 1, T9_LEVELS - 1));
-        small_first_kernel<<<dim3(1u << (n - 8), L.batch), 256, 0, L.stream>>>(a);
+        const size_t lds_words = (((size_t)15 << Lc) + 3) / 4 + 4 + ((size_t)4 << Lc);  // blob + spare word, coefficients: <= 62 KB
+        small_first_kernel<<<dim3(1u << (n - 8), L.batch), 256, lds_words * sizeof(uint32_t), L.stream>>>(a);
     }
     const uint32_t cur = n - (T9_LEVELS - 1);
     finish_tree(L, a.tree, n, cur, d_layers ? d_layers + merkle_layer_offset(n, cur) : s0, s0, s1, d_root, tr, tr_init, tr_init_pitch);

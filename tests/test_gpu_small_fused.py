@@ -1,5 +1,5 @@
-"""GPU: the fused small-domain path (tree.hip small_first_kernel: unpack + encode + first tree in one launch for domains of 2^8 .. 2^13
-points and polynomials of <= 2^9 coefficients per column — the reference's own 1 KiB .. 4 KiB bench inputs, /root/reference/benches/
+"""GPU: the fused small-domain path (tree.hip small_first_kernel: unpack + encode + first tree in one launch for domains of 2^8 .. 2^15
+points and polynomials of <= 2^11 coefficients per column — the reference's own 1 KiB .. 16 KiB bench inputs, /root/reference/benches/
 commit.rs:6-10, benches/proof.rs:14-21) against the oracle, bit-exact, at every (L, n) it takes and at the shapes just outside it.
 
 Host blobs of that size are not copied to the device (the kernel reads page-locked host memory), device blobs may be unaligned."""
@@ -14,16 +14,16 @@ pytestmark = pytest.mark.gpu
 
 def small_path(L, n):
     """mirror of k::small_domain_shape (ids only)"""
-    return 8 <= n <= 13 and L <= 9
+    return 8 <= n <= 15 and L <= 11
 
 
 CASES = []
-for _L in range(0, 11):
-    for _n in range(max(_L, 1), 15):
+for _L in range(0, 13):
+    for _n in range(max(_L, 1), 17):
         if _n - _L > 9:
             continue
         # inside the fused path: everything; outside: only its border
-        if small_path(_L, _n) or _n in (7, 14) or _L == 10:
+        if small_path(_L, _n) or _n in (7, 16) or _L == 12:
             CASES.append(pytest.param(_L, _n - _L, id=f"L{_L}-n{_n}-{'fused' if small_path(_L, _n) else 'general'}"))
 
 
@@ -58,7 +58,7 @@ def test_small_commit_and_proof(gpu_ctx, oracle, L, B, kind):
         assert g_root == o_root and g_proof.serialize() == o_proof.serialize(), (last, nq)
 
 
-@pytest.mark.parametrize("L,B", [(7, 4), (9, 4), (9, 0), (8, 5), (3, 8), (9, 3)])
+@pytest.mark.parametrize("L,B", [(7, 4), (9, 4), (9, 0), (8, 5), (3, 8), (9, 3), (11, 4), (10, 0), (11, 1)])
 def test_small_device_blobs_unaligned_and_batched(gpu_ctx, oracle, L, B):
     """Device-resident blobs at an odd address (byte loads), and batches of equal-length blobs (one launch for all): equal to the oracle."""
     import torch
