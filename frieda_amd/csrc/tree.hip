@@ -1293,7 +1293,11 @@ void build_tree(const Launch& L, int mode, TreeArgs a, uint32_t m, uint8_t* laye
 void encode_and_first_tree(const Launch& L, const uint32_t* d_coef, size_t coef_stride, uint32_t Lc, uint32_t n, const uint32_t* d_tw,
                            DomainScalars ds, uint32_t* d_eval, size_t eval_stride, uint8_t* d_layers, uint8_t* d_scratch, uint8_t* d_root,
                            DevTranscript* tr, const DevTranscript* tr_init, size_t tr_init_pitch) {
-    const bool no_fuse = L.tune->no_encode_tree_fusion;  // A/B knob
+    // The fused last pass hashes a whole 4096-leaf subtree per workgroup: with fewer tiles than CUs (a lone blob of <= 256 KB) most of
+    // the chip idles while 32 - 128 workgroups each run ~32 compressions per thread; the separate transform + 256-leaf tree launches
+    // spread the same work over 16 times the workgroups (commit of 64 KiB: 123 -> 76 us, of 256 KiB: 133 -> 121; from 256 tiles on the
+    // fused launch is ahead again: 120 vs 136 us at 2^20).  Batches count: 64 blobs of 64 KiB are 2048 tiles.
+    const bool no_fuse = L.tune->no_encode_tree_fusion /* A/B knob */ || (((size_t)1 << (n > 12 ? n - 12 : 0)) * L.batch < 256);
     uint8_t* s0 = d_scratch;
     uint8_t* s1 = d_scratch ? d_scratch + ((size_t)32 << (n > 4 ? n - 4 : 0)) : nullptr;
     EncodeTreeSink sink{d_layers, s0};
