@@ -118,6 +118,9 @@ class Context {
     Context& operator=(const Context&) = delete;
     ~Context() { frieda_ctx_destroy(h_); }
 
+    // a tuning / A-B option of this context alone, named like the environment variable that sets its default ("FRIEDA_HOST_DECOMMIT", ...)
+    void set_option(const char* name, int64_t value) { check(frieda_ctx_set_option(h_, name, value), h_); }
+
     Commitment commit(const uint8_t* data, size_t len, uint32_t log_blowup_factor) {
         Commitment root;
         check(frieda_commit(h_, data, len, log_blowup_factor, root.data()), h_);

@@ -255,6 +255,24 @@ int main(int argc, char** argv) {
             }
         got.clear();  // frees 24 proofs whose contexts were destroyed with their threads
     }
+    {  // options are per context: the general path for a small blob and the host-planned openings give the same bytes as the defaults
+        std::vector<uint8_t> d(1024);
+        for (size_t j = 0; j < d.size(); j++) d[j] = (uint8_t)(j % 256);  // benches/commit.rs:6-8
+        auto want = proof::commit_and_generate_proof(d, (uint64_t)d.size(), PCS_CONFIG);
+        Context other(0);
+        other.set_option("FRIEDA_NO_SMALL_FUSED", 1);
+        other.set_option("FRIEDA_HOST_DECOMMIT", 1);
+        auto got = other.commit_and_generate_proof(d.data(), d.size(), (uint64_t)d.size(), PCS_CONFIG);
+        CHECK(got.first == want.first && got.second.serialize() == want.second.serialize());
+        CHECK(other.commit(d.data(), d.size(), 4) == api::commit(d, 4));
+        bool refused = false;
+        try {
+            other.set_option("FRIEDA_NO_SUCH_OPTION", 1);
+        } catch (const Error&) {
+            refused = true;
+        }
+        CHECK(refused);
+    }
     std::printf("%s (%d failures)\n", failures ? "FAILED" : "ok", failures);
     return failures ? 1 : 0;
 }
