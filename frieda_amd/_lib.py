@@ -48,6 +48,14 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
+    # PyTorch-ROCm bundles its own HIP runtime.  When this library (linked against /opt/rocm's) is loaded BEFORE torch, the runtime that
+    # initialises second fails (torch.cuda.is_available() turns False, or frieda_ctx_create returns FRIEDA_ERR_HIP); with torch loaded
+    # first both work.  So a process that has torch gets it imported here, before the library; one without torch is not affected.
+    import importlib.util
+    import sys
+
+    if "torch" not in sys.modules and importlib.util.find_spec("torch") is not None:
+        import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
