@@ -8,8 +8,9 @@ configuration): unpack -> 4 x circle NTT -> first Merkle tree -> every FRI fold 
 interpolation -> grind (pow_bits 20) -> 20 query openings.  value = M31 field elements committed per second =
 n_gpus * 4 * 2^n * steps / wall time, inputs already resident in HBM when the timed region starts.
 
-The K timed steps process K DISTINCT blobs per GPU (a stream of blobs, as a data-availability node sees them), `--batch`
-consecutive blobs per call through the batched entry points (default 4: every kernel is launched once per batch, so the
+The K timed steps process K DISTINCT blobs per GPU (a stream of blobs, as a data-availability node sees them), about `--batch`
+consecutive blobs per call (the K blobs are cut into a multiple of `--in-flight` calls of equal size to within one) through the
+batched entry points (default 4: every kernel is launched once per batch, so the
 Fiat-Shamir latency chain is paid once per batch) with `--in-flight` calls in flight (default 2: one context = stream +
 workspace each, so that chain also runs under the chip-filling kernels of the other batch).  Results are those of K separate
 calls (tests/test_gpu_parity.py).  Every one of the K timed proofs is verified after the timed region and the K roots must be
