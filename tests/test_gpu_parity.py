@@ -230,7 +230,7 @@ def test_config2_ntt_plus_fold_round(gpu_ctx, oracle):
     assert np.array_equal(d_2.to_array(np.uint32, (4, 1 << (n - 2))), l2)
 
 
-@pytest.mark.parametrize("L,n", [(16, 20), (12, 14), (12, 16), (13, 17), (17, 18), (18, 18), (11, 15), (5, 9), (1, 2), (0, 2)],
+@pytest.mark.parametrize("L,n", [(16, 20), (12, 14), (12, 16), (13, 17), (17, 18), (18, 18), (17, 21), (11, 15), (5, 9), (1, 2), (0, 2)],
                          ids=lambda v: str(v))
 @pytest.mark.parametrize("accumulate", [0, 1])
 def test_circle_evaluate_fold2_matches_the_three_calls(gpu_ctx, oracle, L, n, accumulate):
