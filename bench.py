@@ -737,7 +737,7 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-multi-child", action="store_true", help="internal: the many-core legs of the CPU baseline (forked workers, no GPU), one JSON line")
     ap.add_argument("--spm-child", action="store_true", help="internal: the single-process multi-GPU leg (frieda_prove_many over --gpus devices), one JSON line")
     ap.add_argument("--spm-devices", default=None, help="device list of the single-process leg, e.g. 0,0 (a device listed twice needs the RCCL test double)")
-    ap.add_argument("--spm-blobs-per-gpu", type=int, default=4, help="headline-size blobs per device in the single-process leg")
+    ap.add_argument("--spm-blobs-per-gpu", type=int, default=8, help="headline-size blobs per device in the single-process leg (units of 1 + 4 + 3 per device, two in flight)")
     ap.add_argument("--spm-timeout", type=float, default=150.0, help="seconds the single-process leg may take (it needs ~20 s on 8 GPUs; a hung RCCL bring-up must not cost the line)")
     ap.add_argument("--no-single-process-multi", action="store_true", help="skip the single_process_multi block of an N > 1 line")
     args = ap.parse_args(argv)
