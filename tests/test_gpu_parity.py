@@ -198,8 +198,10 @@ def test_dev_at(gpu_ctx):
     assert gpu_ctx._L.frieda_dev_at(gpu_ctx._h, None, 0, C.byref(one)) == 1
 
 
-@pytest.mark.parametrize("pow_bits,seed", [(0, 1), (5, 2), (12, 3), (20, 4), (22, 5)])
+@pytest.mark.parametrize("pow_bits,seed", [(0, 1), (5, 2), (12, 3), (20, 4), (22, 5), (26, 11), (28, 11)])
 def test_grind_returns_minimum_nonce(gpu_ctx, oracle, pow_bits, seed):
+    """GrindOps::grind (src/proof.rs:58): the MINIMUM qualifying nonce, as the reference's sequential scan finds it.  The last two cases
+    lie beyond 2^25 (nonces 49 847 113 and 59 792 498: 8 - 10 s of the oracle's scan each), i.e. tens of thousands of claimed windows."""
     ch = oracle.Channel()
     oracle.lib().fo_channel_init(C.byref(ch))
     oracle.lib().fo_channel_mix_u64(C.byref(ch), seed)
@@ -1216,6 +1218,18 @@ def test_sharded_batch_helpers_use_the_batched_kernels(oracle):
     for (root, proof), b, sd in zip(got, ragged, [7, 8, 9]):
         o_root, o_proof = oracle.commit_and_generate_proof(b, sd, ocfg)
         assert root == o_root and proof.serialize() == o_proof.serialize()
+
+
+def test_whole_proof_with_26_bit_proof_of_work(gpu_ctx, oracle):
+    """pow_bits above the 24 the other cases stop at (PcsConfig::pow_bits is a free u32, src/proof.rs:108-116): the reference's 1 KiB bench
+    input with a 26-bit proof of work — nonce 36 547 975, six seconds of the oracle's sequential scan — whole proof byte-identical."""
+    import frieda_amd
+
+    data = pattern_bytes(1024).tobytes()
+    o_root, o_proof = oracle.commit_and_generate_proof(data, 1, oracle.make_config(26, 4, 0, 20))
+    assert o_proof.c.proof_of_work == 36547975
+    r, p = gpu_ctx.commit_and_generate_proof(data, 1, _cfg(frieda_amd, 26, 4, 0, 20))
+    assert r == o_root and p.serialize() == o_proof.serialize() and frieda_amd.verify(p, 1)
 
 
 def test_grind_retry_loop(gpu_ctx, oracle, monkeypatch):
