@@ -89,6 +89,20 @@ def test_small_device_blobs_unaligned_and_batched(gpu_ctx, oracle, L, B):
         assert g_root == o_root and g_proof.serialize() == o_proof.serialize()
 
 
+@pytest.mark.parametrize("B", [8, 9, 12])
+def test_empty_and_one_byte_blobs_on_the_fused_path(gpu_ctx, oracle, B):
+    """len = 0 and len = 1 (L = 0: four zero / one non-zero felt) at blow-ups that put the domain inside the fused path: commit() root equal
+    to the oracle's; the prover panics as the reference does (L - 1 < last)."""
+    import frieda_amd
+
+    for data in (b"", b"\x5a"):
+        assert gpu_ctx.commit(data, B) == oracle.commit(data, B)
+        with pytest.raises(frieda_amd.FriedaPanic):
+            gpu_ctx.commit_and_generate_proof(data, 1, frieda_amd.PcsConfig(frieda_amd.FriConfig(B, 0, 20), 4))
+        with pytest.raises(RuntimeError):
+            oracle.commit_and_generate_proof(data, 1, oracle.make_config(4, B, 0, 20))
+
+
 def test_reference_bench_inputs_fused_and_general_path(gpu_ctx):
     """The reference's bench inputs (i % 256 for 1024 / 4096 bytes) through the fused path and, on a context with FRIEDA_NO_SMALL_FUSED
     set, through the general one: the same known roots (tests/golden/vectors.json) and the same proof bytes."""
