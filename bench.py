@@ -8,11 +8,12 @@ configuration): unpack -> 4 x circle NTT -> first Merkle tree -> every FRI fold 
 interpolation -> grind (pow_bits 20) -> 20 query openings.  value = M31 field elements committed per second =
 n_gpus * 4 * 2^n * steps / wall time, inputs already resident in HBM when the timed region starts.
 
-The K timed steps process K DISTINCT blobs per GPU (a stream of blobs, as a data-availability node sees them), about `--batch`
-consecutive blobs per call (the K blobs are cut into a multiple of `--in-flight` calls of equal size to within one) through the
-batched entry points (default 4: every kernel is launched once per batch, so the
-Fiat-Shamir latency chain is paid once per batch) with `--in-flight` calls in flight (default 2: one context = stream +
-workspace each, so that chain also runs under the chip-filling kernels of the other batch).  Results are those of K separate
+The K timed steps process K DISTINCT blobs per GPU (a stream of blobs, as a data-availability node sees them) through the batched
+entry points (every kernel is launched once per call, so the Fiat-Shamir latency chain is paid once per call), cut into calls by
+the library's own batch policy (`frieda_batch_plan`, include/frieda_hip.h: workspace bytes in flight — 5 blobs per call at the 2^24
+domain, 16+ at 2^22 and below; the number of calls a multiple of `--in-flight`, sizes equal to within one; `--batch B` forces about
+B per call instead, as rounds 1-4 did with B = 4) with `--in-flight` calls in flight (default 2: one context = stream +
+workspace each, so that chain also runs under the chip-filling kernels of the other call).  Results are those of K separate
 calls (tests/test_gpu_parity.py).  Every one of the K timed proofs is verified after the timed region and the K roots must be
 distinct; `sequential` in the JSON line is the one-proof-at-a-time figure (`--batch 1 --in-flight 1` makes it the headline;
 `--batch 1` is two single proofs in flight).
@@ -294,7 +295,7 @@ def reference_bench_sizes(ctx, frieda_amd, torch):
 def measure_config(frieda_amd, torch, device, n, workload, K, BSZ, D, cfg):
     """The measured loop of main() on another BASELINE configuration (benches/commit.rs:6-13,
     benches/proof.rs:30-44): K distinct device-resident blobs of a 2^n domain (generator seeds 100 + i) through
-    `commit_and_generate_proof` (BSZ per call, D calls in flight) or `commit`, every proof verified; then the lone-call latency and the
+    `commit_and_generate_proof` (BSZ per call — 0: the library's batch policy —, D calls in flight) or `commit`, every proof verified; then the lone-call latency and the
     dominant kernel of an instrumented replay.  Fractions are algorithmic bytes / time against the 8 TB/s HBM peak."""
     blob_len = blob_len_for(n)
     seed = blob_len
@@ -309,9 +310,12 @@ def measure_config(frieda_amd, torch, device, n, workload, K, BSZ, D, cfg):
     out = {"log_domain": n, "workload": "commit_and_generate_proof" if workload == "prove" else "commit", "blob_bytes": blob_len, "blobs": K}
     if workload == "prove":
         def stream(bsz):
-            pipe = frieda_amd.BatchPipeline(device, D) if bsz > 1 else frieda_amd.ProofPipeline(device, D)
+            """bsz 0: the library's batch policy cuts the K blobs into calls (BatchPipeline.run_stream_device); else bsz per call"""
+            pipe = frieda_amd.BatchPipeline(device, D) if bsz != 1 else frieda_amd.ProofPipeline(device, D)
 
             def run():
+                if bsz == 0:
+                    return pipe.run_stream_device(blobs[0].data_ptr(), blob_len, blob_len, K, [seed] * K, cfg)
                 res = []
                 for i in range(0, K, bsz):
                     cnt = min(bsz, K - i)
@@ -336,19 +340,20 @@ def measure_config(frieda_amd, torch, device, n, workload, K, BSZ, D, cfg):
             assert len(res) == K and len({r for r, _ in res}) == K
             for r, p in res:
                 assert p.commitment == r and frieda_amd.verify(p, seed), "a timed proof does not verify"
+            cut = pipe.plan(blob_len, K, cfg) if bsz == 0 else None
             pipe.close()
-            return dt_, [r for r, _ in res]
+            return dt_, [r for r, _ in res], cut
 
-        dt, roots = stream(BSZ)
-        out["measured_loop"] = f"{BSZ} blobs per call, {D} calls in flight"
+        dt, roots, cut = stream(BSZ)
+        out["measured_loop"] = (f"library batch policy (frieda_batch_plan): {len(cut)} calls of {max(cut)} / {min(cut)} blobs, {D} calls in flight" if BSZ == 0 else
+                                f"{BSZ} blobs per call, {D} calls in flight")
         out["verified_proofs"] = K
         root0 = roots[0]
-        big = min(32, BSZ << max(0, 24 - n), K // D)
-        if big > BSZ:  # smaller blobs want more of them per call: the same bytes in flight as 4 blobs of the 2^24 domain (at most 32)
-            dtb, roots_b = stream(big)
-            assert roots_b == roots
-            out["larger_batch"] = {"measured_loop": f"{big} blobs per call, {D} calls in flight", "ms_per_blob": 1e3 * dtb, "value": elems / dtb,
-                                   "frac_of_hbm_peak_wall": path_bytes / dtb / 1e9 / HBM_PEAK_GBS, "verified_proofs": K}
+        if BSZ == 0:  # for continuity with rounds 1-4, whose loop handed 4 blobs to every call whatever their size
+            dt4, roots4, _ = stream(4)
+            assert roots4 == roots
+            out["fixed_batch4"] = {"measured_loop": f"4 blobs per call, {D} calls in flight (the cut of rounds 1-4)", "ms_per_blob": 1e3 * dt4, "value": elems / dt4,
+                                   "frac_of_hbm_peak_wall": path_bytes / dt4 / 1e9 / HBM_PEAK_GBS, "verified_proofs": K}
 
         def lone():
             return ctx.commit_and_generate_proof_device(blobs[0].data_ptr(), blob_len, seed, cfg)
@@ -720,8 +725,9 @@ def parse_args(argv=None):
     ap.add_argument("--batch-extra", type=int, default=4, help="blobs per call for the extra 'batched' figure (0 = skip)")
     ap.add_argument("--in-flight", type=int, default=2,
                     help="proofs (or batches) in flight in the measured loop (one context each); 1 = one at a time")
-    ap.add_argument("--batch", type=int, default=4,
-                    help="blobs per call in the measured loop: > 1 uses the batched entry points (every kernel launched once per batch); 1 = one blob per call")
+    ap.add_argument("--batch", type=int, default=0,
+                    help="blobs per call in the measured loop: 0 (default) = the library's batch policy (frieda_batch_plan: workspace bytes in flight); "
+                         "> 1 = about that many per call through the batched entry points; 1 = one blob per call")
     ap.add_argument("--pipeline-depth", type=int, default=None, help="deprecated alias: 0 means --in-flight 1")
     ap.add_argument("--sequential-extra", type=int, default=20, help="proofs for the extra one-at-a-time figure (0 = skip)")
     ap.add_argument("--stagger", type=int, default=0, help="experiment: 1 = the second context's first batch has half the blobs")
@@ -910,7 +916,7 @@ def main():
     blob_len = blob_len_for(n)
     K = args.steps
     D = max(1, args.in_flight) if args.workload == "prove" else 1
-    BSZ = max(1, args.batch) if args.workload == "prove" else 1
+    BSZ = max(0, args.batch) if args.workload == "prove" else 1  # 0: the library's batch policy decides the cut
     # K DISTINCT blobs per rank, resident in HBM before the timed region (generator: splitmix64, seeds 100 + rank * K + i; the
     # first blob of rank 0 is the seed-100 blob the CPU baseline proves, so the two roots can be compared).  One contiguous
     # [K, blob_len] array: a batch is `batch` consecutive rows.
@@ -936,7 +942,7 @@ def main():
     # batch: the chain is paid once per batch), `D` batches in flight.
     if args.workload != "prove":
         pipe = None
-    elif BSZ > 1:
+    elif BSZ != 1:
         pipe = frieda_amd.BatchPipeline(local_rank, D)
     else:
         pipe = frieda_amd.ProofPipeline(local_rank, D)
@@ -957,6 +963,8 @@ def main():
         launches' ramps un-overlapped (20 blobs: 4 x 5 instead of 5 x 4, ~1 % at the driver's step count; 60 blobs: 14 calls of 4 - 5)."""
         if n_blobs <= 0:
             return []
+        if BSZ == 0:  # the library's policy (include/frieda_hip.h "batch policy"): the same call frieda_prove_many makes per device
+            return pipe.plan(blob_len, n_blobs, cfg)
         calls = D * max(1, n_blobs // (BSZ * D))
         calls = min(calls, n_blobs)
         base, extra = divmod(n_blobs, calls)
@@ -969,7 +977,7 @@ def main():
                 step(i)
             return []
         out = []
-        if BSZ > 1:
+        if BSZ != 1:
             i = 0
             for nb, cnt in enumerate(batch_cut(n_blobs)):
                 if args.stagger and nb == 1 and D == 2 and cnt >= 2:
@@ -1237,8 +1245,9 @@ def main():
             "parallelism": f"{world} independent blobs per step, one per GPU; one all_gather of the K x 32-byte roots per rank after the last step",
             "blobs": f"{K} distinct blobs per GPU (splitmix64 seeds 100 + rank * K + i), resident in HBM; every timed proof verified after the timed region" if args.workload == "prove" else f"{K} distinct blobs per GPU",
             "in_flight": D,
-            "batch": BSZ,
-            "measured_loop": (f"about {BSZ} consecutive blobs per call — the {K} blobs in {len(batch_cut(K))} calls of {max(batch_cut(K))} / {min(batch_cut(K))}, a multiple of the calls in flight — (frieda_prove_batch_begin_device / _finish), {D} calls in flight" if BSZ > 1 else
+            "batch": BSZ if BSZ else "library policy (frieda_batch_plan)",
+            "measured_loop": ((f"the library's batch policy (frieda_batch_plan: workspace bytes in flight) — " if BSZ == 0 else f"about {BSZ} consecutive blobs per call — ") +
+                              f"the {K} blobs in {len(batch_cut(K))} calls of {max(batch_cut(K))} / {min(batch_cut(K))}, a multiple of the calls in flight — (frieda_prove_batch_begin_device / _finish), {D} calls in flight" if BSZ != 1 else
                               f"one blob per call (frieda_prove_begin_device / _finish), {D} in flight") if args.workload == "prove" else "commit_device per blob, asynchronous",
             "twiddles": "regenerated per call" if args.no_twiddle_cache else "cached per context",
         },
@@ -1252,7 +1261,7 @@ def main():
             "frac_of_hbm_peak_wall": path_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS,
             "gpu_kernel_ms_per_step": gpu_ms,
             "launches_per_lone_proof": sum(k["launches"] for k in kern) / args.steps,
-            "launches_per_blob_in_measured_loop": sum(k["launches"] for k in kern) / args.steps / BSZ,
+            "launches_per_blob_in_measured_loop": sum(k["launches"] for k in kern) / args.steps / (max(batch_cut(K)) if BSZ != 1 else 1),
             "host_phase_marks_ms_last_step": host_phases,
             "frac_of_hbm_peak_kernels": (path_bytes / (gpu_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if gpu_ms > 0 else None,
             "kernels": [
@@ -1287,11 +1296,11 @@ def main():
         rows = []
         try:
             for (cn, cw) in ((20, "prove"), (22, "prove"), (24, "prove"), (22, "commit"), (24, "commit")):
-                if cn == n and cw == args.workload and BSZ == 4 and D == 2:
+                if cn == n and cw == args.workload and BSZ == 0 and D == 2:
                     continue  # that is `value` itself
                 if cn > n:
                     continue  # (small test runs: nothing above the headline size)
-                rows.append(measure_config(frieda_amd, torch, local_rank, cn, cw, 64 if cn <= 22 else 20, 4 if cw == "prove" else 1, 2 if cw == "prove" else 1, cfg))
+                rows.append(measure_config(frieda_amd, torch, local_rank, cn, cw, 64 if cn <= 22 else 20, 0 if cw == "prove" else 1, 2 if cw == "prove" else 1, cfg))
             if n >= 20:
                 rows.insert(0, measure_config2(frieda_amd, torch, local_rank, 20))
         except AssertionError:

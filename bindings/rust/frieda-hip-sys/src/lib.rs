@@ -51,6 +51,11 @@ extern "C" {
     pub fn frieda_ctx_set_option(ctx: *mut frieda_ctx, name: *const c_char, value: i64) -> c_int;
     /// test hook (include/frieda_hip_testing.h), not part of the boundary
     pub fn frieda_ctx_test_set_draw_bound(ctx: *mut frieda_ctx, bound: u32) -> c_int;
+    pub fn frieda_ctx_test_set_grind_first_log(ctx: *mut frieda_ctx, log_first: u32) -> c_int;
+    pub fn frieda_test_parse_cpulist(text: *const c_char, out_cpus: *mut c_int, cap: usize, n: *mut usize) -> c_int;
+    /// batch policy: device workspace one blob adds to a batched call; the cut of `count` equal-length blobs into calls
+    pub fn frieda_workspace_bytes(len: usize, log_blowup_factor: u32, log_last_layer_degree_bound: u32, prove: c_int) -> usize;
+    pub fn frieda_batch_plan(ctx: *const frieda_ctx, len: usize, log_blowup_factor: u32, log_last_layer_degree_bound: u32, prove: c_int, count: u32, in_flight: u32, out_calls: *mut u32, cap: usize, n_calls: *mut u32) -> c_int;
     pub fn frieda_ctx_set_kernel_timing(ctx: *mut frieda_ctx, enabled: c_int) -> c_int;
     pub fn frieda_ctx_last_prove_phases(ctx: *const frieda_ctx, out_ms: *mut f64) -> c_int;
     /// measurement aid: pure-compute Blake2s compression rate of this device (leaf-shaped, node-shaped), compressions per second
@@ -84,6 +89,7 @@ extern "C" {
     pub fn frieda_multi_uses_rccl(m: *const frieda_multi) -> c_int;
     pub fn frieda_multi_gather_count(m: *const frieda_multi) -> u64;
     pub fn frieda_multi_ctx(m: *mut frieda_multi, device_slot: u32) -> *mut frieda_ctx;
+    pub fn frieda_multi_near_cpus(m: *const frieda_multi, device_slot: u32, out_cpus: *mut c_int, cap: usize) -> u32;
     pub fn frieda_commit_many(m: *mut frieda_multi, blobs: *const *const u8, lens: *const usize, count: u32, log_blowup_factor: u32, out_roots: *mut u8) -> c_int;
     pub fn frieda_prove_many(m: *mut frieda_multi, blobs: *const *const u8, lens: *const usize, count: u32, seeds: *const u64, cfg: frieda_pcs_config, out_commitments: *mut u8, out_proofs: *mut *mut frieda_proof) -> c_int;
     pub fn frieda_verify(proof: *const frieda_proof, seed: *const u64, ok: *mut c_int) -> c_int;

@@ -13,12 +13,14 @@ from .api import (  # noqa: F401
     PcsConfig,
     Proof,
     ProofPipeline,
+    batch_plan,
     commit,
     commit_and_generate_proof,
     default_context,
     generate_proof,
     verify,
     verify_samples,
+    workspace_bytes,
 )
 
 __all__ = [
@@ -31,10 +33,12 @@ __all__ = [
     "PcsConfig",
     "Proof",
     "ProofPipeline",
+    "batch_plan",
     "commit",
     "commit_and_generate_proof",
     "default_context",
     "generate_proof",
     "verify",
     "verify_samples",
+    "workspace_bytes",
 ]

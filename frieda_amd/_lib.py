@@ -54,8 +54,12 @@ def lib():
     import importlib.util
     import sys
 
-    if "torch" not in sys.modules and importlib.util.find_spec("torch") is not None:
-        import torch  # noqa: F401
+    # (best effort: a broken or half-imported torch must not keep a CPU-only user — declared_symbols, the host verifier — from the library)
+    try:
+        if "torch" not in sys.modules and importlib.util.find_spec("torch") is not None:
+            import torch  # noqa: F401
+    except Exception:
+        pass
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
@@ -77,6 +81,9 @@ def lib():
         "frieda_ctx_set_host_channel": (C.c_int, [vp, C.c_int]),
         "frieda_ctx_set_option": (C.c_int, [vp, C.c_char_p, C.c_int64]),
         "frieda_ctx_test_set_draw_bound": (C.c_int, [vp, u32]),
+        "frieda_ctx_test_set_grind_first_log": (C.c_int, [vp, u32]),
+        "frieda_workspace_bytes": (sz, [sz, u32, u32, C.c_int]),
+        "frieda_batch_plan": (C.c_int, [vp, sz, u32, u32, C.c_int, u32, u32, C.POINTER(u32), sz, C.POINTER(u32)]),
         "frieda_ctx_set_kernel_timing": (C.c_int, [vp, C.c_int]),
         "frieda_ctx_last_prove_phases": (C.c_int, [vp, C.POINTER(C.c_double)]),
         "frieda_ctx_blake2s_ceiling": (C.c_int, [vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
@@ -105,6 +112,8 @@ def lib():
         "frieda_multi_uses_rccl": (C.c_int, [vp]),
         "frieda_multi_gather_count": (u64, [vp]),
         "frieda_multi_ctx": (vp, [vp, u32]),
+        "frieda_multi_near_cpus": (u32, [vp, u32, C.POINTER(C.c_int), sz]),
+        "frieda_test_parse_cpulist": (C.c_int, [C.c_char_p, C.POINTER(C.c_int), sz, C.POINTER(sz)]),
         "frieda_commit_many": (C.c_int, [vp, pp, C.POINTER(sz), u32, u32, vp]),
         "frieda_prove_many": (C.c_int, [vp, pp, C.POINTER(sz), u32, u64p, PcsConfigC, vp, pp]),
         "frieda_verify": (C.c_int, [vp, u64p, C.POINTER(C.c_int)]),

@@ -530,6 +530,25 @@ class BatchPipeline:
         self.inflight = []  # (ctx, count), oldest first
         self.free = list(self.ctxs)
 
+    def plan(self, length, count, pcs_config, prove=True):
+        """The library's cut of `count` equal-length blobs into calls for this pipeline's depth (frieda_batch_plan: workspace bytes in
+        flight; the options FRIEDA_BATCH_BUDGET_MB / FRIEDA_BATCH_CALLS_PER_CTX of the first context apply)."""
+        return batch_plan(length, count, pcs_config, in_flight=len(self.ctxs), prove=prove, ctx=self.ctxs[0])
+
+    def run_stream_device(self, d_ptr, stride, length, count, seeds, pcs_config):
+        """`count` device-resident blobs of one length (blob i at d_ptr + i * stride) through the pipeline, cut into calls by the library's
+        batch policy; returns [(commitment, proof)] in blob order (the caller loop of benches/proof.rs:30-44 over many blobs)."""
+        out = []
+        i = 0
+        for cnt in self.plan(length, count, pcs_config):
+            sd = None if seeds is None else seeds[i : i + cnt]
+            r = self.submit_device(d_ptr + i * stride, stride, length, cnt, sd, pcs_config)
+            if r is not None:
+                out.extend(r)
+            i += cnt
+        out.extend(self.drain())
+        return out
+
     def submit_device(self, d_ptr, stride, length, count, seeds, pcs_config):
         done = None
         if not self.free:
@@ -553,6 +572,27 @@ class BatchPipeline:
         self.drain()
         for c in self.ctxs:
             c.close()
+
+
+def workspace_bytes(length, log_blowup_factor, log_last_layer_degree_bound=0, prove=True):
+    """Device workspace one blob of `length` bytes adds to a batched call (frieda_workspace_bytes); 0: shape out of range."""
+    return int(_lib.lib().frieda_workspace_bytes(length, log_blowup_factor, log_last_layer_degree_bound, int(bool(prove))))
+
+
+def batch_plan(length, count, pcs_config=None, in_flight=2, prove=True, ctx=None, log_blowup_factor=None):
+    """The library's batch policy (frieda_batch_plan, include/frieda_hip.h "batch policy"): the blob count of each call, in order, for
+    `count` equal-length blobs and `in_flight` contexts taking turns.  pcs_config for proofs, log_blowup_factor for commits."""
+    L = _lib.lib()
+    if pcs_config is not None:
+        B, last = pcs_config.fri_config.log_blowup_factor, pcs_config.fri_config.log_last_layer_degree_bound
+    else:
+        B, last = int(log_blowup_factor), 0
+    n = C.c_uint32(0)
+    h = ctx._h if ctx is not None else None
+    _check(L.frieda_batch_plan(h, length, B, last, int(bool(prove)), count, in_flight, None, 0, C.byref(n)))
+    out = (C.c_uint32 * max(1, n.value))()
+    _check(L.frieda_batch_plan(h, length, B, last, int(bool(prove)), count, in_flight, out, n.value, C.byref(n)))
+    return [int(out[i]) for i in range(n.value)]
 
 
 # ---- module-level API with an implicit per-thread default context (frieda's free functions) ----

@@ -94,11 +94,142 @@ FR_HD void b2_compress(const uint32_t (&h)[8], const uint32_t (&m)[16], uint32_t
     out[7] = h[7] ^ v7 ^ v15;
 }
 
+#if defined(__HIP_DEVICE_COMPILE__)
+// ---- throughput form for the chip-filling kernels (round 5; profiles/r05_issue_pattern.txt, r05_blake2s_runs.txt,
+// r05_blake2s_idle_sweep.txt) ----
+// What a gfx950 SIMD sustains on this instruction stream depends on HOW the stream is laid out, not only on its instruction count:
+//  * a fine interleave of fast-class (v_xor / v_add) and slow-class (v_alignbit / v_add3) instructions — what the scheduler emits when
+//    left alone (average run 2.1) — costs 3975 SIMD cycles per wave-compression (node shape, 8 waves per SIMD);
+//  * the same instructions as RUNS of one class (the four columns / diagonals advance one G step at a time): 3860;
+//  * and with a few IDLE issue states (s_nop) between the runs: 3380 - 3480 (node), 3220 - 3260 (leaf, from 3810) — 12 - 15 % fewer
+//    cycles for ~350 extra (scalar) instructions.  The waves of a SIMD hand the vector pipe to each other at the run boundaries
+//    instead of contending instruction by instruction; the optimum is occupancy-dependent (nothing to gain at 2 waves per SIMD).
+// The runs are pinned by data flow: one volatile asm statement takes the four values a step has just written as read-write
+// operands, so the step's instructions lie between two such statements at every level of the compiler (a scheduling barrier is not
+// enough: IR passes move pure arithmetic across it).  The statement's text is the s_nop; the compiler adds an s_nop 0 of its own in
+// front of the next VALU instruction after any inline asm, so N idle states = "s_nop N-2" (N = 1: empty text; N = 0: no statement).
+// IDLE = 0xABC: idle states at the boundaries slow -> fast (A), fast -> slow (B), slow -> slow (C: rotr 7 -> the next add3).
+template <int N>
+__device__ __forceinline__ void b2_pin(uint32_t& a, uint32_t& b, uint32_t& c, uint32_t& d) {
+    static_assert(N >= 0 && N <= 6, "idle states 0 .. 6");
+    if constexpr (N == 1) asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+    if constexpr (N == 2) asm volatile("s_nop 0" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+    if constexpr (N == 3) asm volatile("s_nop 1" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+    if constexpr (N == 4) asm volatile("s_nop 2" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+    if constexpr (N == 5) asm volatile("s_nop 3" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+    if constexpr (N == 6) asm volatile("s_nop 4" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+}
+// one half-round (R: round, H: 0 = columns, 1 = diagonals); the four G functions are written out (no loops: the unroller gives up on
+// loops that carry inline asm once a kernel holds a few dozen compressions)
+template <int IDLE, int R, int H>
+__device__ __forceinline__ void b2_half_round_runs(uint32_t (&v)[16], const uint32_t (&m)[16]) {
+    using b2detail::SIGMA;
+    constexpr int NA = (IDLE >> 8) & 15, NB = (IDLE >> 4) & 15, NC = IDLE & 15;
+    constexpr int a0 = 0, a1 = 1, a2 = 2, a3 = 3;
+    constexpr int b0 = H ? 5 : 4, b1 = H ? 6 : 5, b2 = H ? 7 : 6, b3 = H ? 4 : 7;
+    constexpr int c0 = H ? 10 : 8, c1 = H ? 11 : 9, c2 = H ? 8 : 10, c3 = H ? 9 : 11;
+    constexpr int d0 = H ? 15 : 12, d1 = H ? 12 : 13, d2 = H ? 13 : 14, d3 = H ? 14 : 15;
+    constexpr int o = 8 * H;
+#define FR_B2_4(X) X(0) X(1) X(2) X(3)
+#define FR_B2_AX(q) v[a##q] = v[a##q] + v[b##q] + m[SIGMA[R][o + 2 * q]];
+#define FR_B2_AY(q) v[a##q] = v[a##q] + v[b##q] + m[SIGMA[R][o + 2 * q + 1]];
+#define FR_B2_DX(q) v[d##q] ^= v[a##q];
+#define FR_B2_CD(q) v[c##q] += v[d##q];
+#define FR_B2_BX(q) v[b##q] ^= v[c##q];
+#define FR_B2_RD16(q) v[d##q] = b2detail::rotr(v[d##q], 16);
+#define FR_B2_RD8(q) v[d##q] = b2detail::rotr(v[d##q], 8);
+#define FR_B2_RB12(q) v[b##q] = b2detail::rotr(v[b##q], 12);
+#define FR_B2_RB7(q) v[b##q] = b2detail::rotr(v[b##q], 7);
+    FR_B2_4(FR_B2_AX)
+    b2_pin<NA>(v[a0], v[a1], v[a2], v[a3]);
+    FR_B2_4(FR_B2_DX)
+    b2_pin<NB>(v[d0], v[d1], v[d2], v[d3]);
+    FR_B2_4(FR_B2_RD16)
+    b2_pin<NA>(v[d0], v[d1], v[d2], v[d3]);
+    FR_B2_4(FR_B2_CD)
+    FR_B2_4(FR_B2_BX)
+    b2_pin<NB>(v[b0], v[b1], v[b2], v[b3]);
+    FR_B2_4(FR_B2_RB12)
+    FR_B2_4(FR_B2_AY)
+    b2_pin<NA>(v[a0], v[a1], v[a2], v[a3]);
+    FR_B2_4(FR_B2_DX)
+    b2_pin<NB>(v[d0], v[d1], v[d2], v[d3]);
+    FR_B2_4(FR_B2_RD8)
+    b2_pin<NA>(v[d0], v[d1], v[d2], v[d3]);
+    FR_B2_4(FR_B2_CD)
+    FR_B2_4(FR_B2_BX)
+    b2_pin<NB>(v[b0], v[b1], v[b2], v[b3]);
+    FR_B2_4(FR_B2_RB7)
+    b2_pin<NC>(v[b0], v[b1], v[b2], v[b3]);
+#undef FR_B2_4
+#undef FR_B2_AX
+#undef FR_B2_AY
+#undef FR_B2_DX
+#undef FR_B2_CD
+#undef FR_B2_BX
+#undef FR_B2_RD16
+#undef FR_B2_RD8
+#undef FR_B2_RB12
+#undef FR_B2_RB7
+}
+template <int IDLE, int R>
+__device__ __forceinline__ void b2_round_runs(uint32_t (&v)[16], const uint32_t (&m)[16]) {
+    b2_half_round_runs<IDLE, R, 0>(v, m);
+    b2_half_round_runs<IDLE, R, 1>(v, m);
+}
+// out = F(0, m, 0, 0) in the run-structured form; message words that are compile-time zeros (a leaf) fold as in the plain form
+template <int IDLE>
+__device__ __forceinline__ void b2_merkle_block_runs(const uint32_t (&m)[16], uint32_t (&out)[8]) {
+    using b2detail::IV;
+    uint32_t v[16] = {0, 0, 0, 0, 0, 0, 0, 0, IV[0], IV[1], IV[2], IV[3], IV[4], IV[5], IV[6], IV[7]};
+    b2_round_runs<IDLE, 0>(v, m);
+    b2_round_runs<IDLE, 1>(v, m);
+    b2_round_runs<IDLE, 2>(v, m);
+    b2_round_runs<IDLE, 3>(v, m);
+    b2_round_runs<IDLE, 4>(v, m);
+    b2_round_runs<IDLE, 5>(v, m);
+    b2_round_runs<IDLE, 6>(v, m);
+    b2_round_runs<IDLE, 7>(v, m);
+    b2_round_runs<IDLE, 8>(v, m);
+    b2_round_runs<IDLE, 9>(v, m);
+    out[0] = v[0] ^ v[8];
+    out[1] = v[1] ^ v[9];
+    out[2] = v[2] ^ v[10];
+    out[3] = v[3] ^ v[11];
+    out[4] = v[4] ^ v[12];
+    out[5] = v[5] ^ v[13];
+    out[6] = v[6] ^ v[14];
+    out[7] = v[7] ^ v[15];
+}
+#endif
+// idle states of the throughput form, per message shape (A/B knobs of the build: tools/build_variant.sh <name> -DFRIEDA_B2_IDLE_NODE=0x...)
+#ifndef FRIEDA_B2_IDLE_NODE
+#define FRIEDA_B2_IDLE_NODE 0x333
+#endif
+#ifndef FRIEDA_B2_IDLE_LEAF
+#define FRIEDA_B2_IDLE_LEAF 0x333
+#endif
+
 // Blake2sMerkleHasher::hash_node for one 16-word block from the zero state: the shape of every node of
 // frieda's trees (leaf = 4 column words + 12 zero words; inner node = left || right).
-FR_HD void b2_merkle_block(const uint32_t (&m)[16], uint32_t (&out)[8]) {
+FR_HD void b2_merkle_block_lat(const uint32_t (&m)[16], uint32_t (&out)[8]) {  // plain form: host code and the latency-bound (one-workgroup) kernels
     const uint32_t z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     b2_compress(z, m, 0, 0, 0, 0, out);
+}
+// the same for the chip-filling kernels: the throughput form on the device (IDLE: see above), the plain form on the host
+// IDLE = B2_LAT selects the plain form (call sites of the latency-bound kernels: one workgroup, or few waves per SIMD, where an idle
+// state is pure delay)
+constexpr int B2_LAT = -1;
+template <int IDLE = FRIEDA_B2_IDLE_NODE>
+FR_HD void b2_merkle_block(const uint32_t (&m)[16], uint32_t (&out)[8]) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(FRIEDA_B2_NO_RUNS)
+    if constexpr (IDLE >= 0)
+        b2_merkle_block_runs<IDLE>(m, out);
+    else
+        b2_merkle_block_lat(m, out);
+#else
+    b2_merkle_block_lat(m, out);
+#endif
 }
 
 // Standard unkeyed Blake2s-256 of a message given as little-endian words, at most one... any number of

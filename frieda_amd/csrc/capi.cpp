@@ -172,6 +172,36 @@ int frieda_ctx_test_set_draw_bound(frieda_ctx* ctx, uint32_t bound) {
     return FRIEDA_OK;
 }
 
+int frieda_ctx_test_set_grind_first_log(frieda_ctx* ctx, uint32_t log_first) {
+    if (!ctx || (log_first != 0 && (log_first < 8 || log_first > 40))) return FRIEDA_ERR_ARG;
+    ctx->c.tuning.test_grind_first_log = log_first;
+    return FRIEDA_OK;
+}
+
+size_t frieda_workspace_bytes(size_t len, uint32_t log_blowup_factor, uint32_t log_last_layer_degree_bound, int prove) {
+    return workspace_bytes_per_blob(len, log_blowup_factor, log_last_layer_degree_bound, prove != 0, true);
+}
+
+int frieda_batch_plan(const frieda_ctx* ctx, size_t len, uint32_t log_blowup_factor, uint32_t log_last_layer_degree_bound, int prove,
+                      uint32_t count, uint32_t in_flight, uint32_t* out_calls, size_t cap, uint32_t* n_calls) {
+    if (!n_calls || in_flight == 0 || in_flight > 64) return FRIEDA_ERR_ARG;
+    *n_calls = 0;
+    try {
+        const size_t ws = workspace_bytes_per_blob(len, log_blowup_factor, log_last_layer_degree_bound, prove != 0, true);
+        if (!ws) return FRIEDA_ERR_ARG;
+        const k::Tuning& t = ctx ? ctx->c.tuning : k::tuning_defaults();
+        std::vector<uint32_t> calls;
+        batch_cut(count, batch_per_call(t, ws, count, in_flight), in_flight, calls);
+        *n_calls = (uint32_t)calls.size();
+        if (calls.size() > cap) return out_calls ? FRIEDA_ERR_ARG : FRIEDA_OK;  // out_calls == NULL: a query for the count
+        if (out_calls)
+            for (size_t i = 0; i < calls.size(); i++) out_calls[i] = calls[i];
+        return FRIEDA_OK;
+    } catch (...) {
+        return FRIEDA_ERR_NOMEM;
+    }
+}
+
 int frieda_ctx_set_kernel_timing(frieda_ctx* ctx, int enabled) {
     if (!ctx) return FRIEDA_ERR_ARG;
     FR_GUARD_BEGIN

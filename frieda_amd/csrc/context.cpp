@@ -5,6 +5,8 @@
 
 #include <cstdio>
 
+#include <algorithm>
+
 #include "host.h"
 
 namespace frieda {
@@ -109,27 +111,32 @@ namespace {
 struct KnobDesc {
     const char* name;
     long lo, hi;
-    void (*set)(Tuning&, long);
+    bool (*set)(Tuning&, long);  // false: a value inside [lo, hi] that the knob does not support (nothing is changed)
 };
 const KnobDesc KNOBS[] = {
-    {"FRIEDA_T5_WIDE_LOG", 16, 24, [](Tuning& t, long v) { t.t5_wide_log = (uint32_t)v; }},
-    {"FRIEDA_T5_REG3_LOG", 0, 30, [](Tuning& t, long v) { t.t5_reg3_log = (uint32_t)v; }},
-    {"FRIEDA_T9_MAX_LOG", 8, 19, [](Tuning& t, long v) { t.t9_max_log = (uint32_t)v; }},
-    {"FRIEDA_TOP_MAX_LOG", 9, 11, [](Tuning& t, long v) { t.top_max_log = (uint32_t)v; }},
-    {"FRIEDA_NTT_CPW", 1, 4, [](Tuning& t, long v) { t.ntt_cpw = (uint32_t)v; }},
-    {"FRIEDA_NTT_CPW_SMALL", 1, 4, [](Tuning& t, long v) { t.ntt_cpw_small = (uint32_t)v; }},
-    {"FRIEDA_NTT_REP", 0, 1, [](Tuning& t, long v) { t.ntt_rep = v != 0; }},
-    {"FRIEDA_NTT_NO_PAD8", 0, 1, [](Tuning& t, long v) { t.ntt_no_pad8 = v != 0; }},
-    {"FRIEDA_NTT_TREE_REG_ONLY", 0, 1, [](Tuning& t, long v) { t.ntt_tree_reg_only = v != 0; }},
-    {"FRIEDA_NO_ENCODE_TREE_FUSION", 0, 1, [](Tuning& t, long v) { t.no_encode_tree_fusion = v != 0; }},
-    {"FRIEDA_NO_SMALL_FUSED", 0, 1, [](Tuning& t, long v) { t.no_small_fused = v != 0; }},
-    {"FRIEDA_UNPACK_TILES", 1, 8, [](Tuning& t, long v) { if (v == 1 || v == 2 || v == 4 || v == 8) t.unpack_tiles = (uint32_t)v; }},
-    {"FRIEDA_INTT_GENERIC", 0, 1, [](Tuning& t, long v) { t.intt_generic = v != 0; }},
-    {"FRIEDA_ERASURE_TREE_MIN_LOG", 6, 32, [](Tuning& t, long v) { t.erasure_tree_min_log = (uint32_t)v; }},
-    {"FRIEDA_TAIL_RUN_LOG", 4, 11, [](Tuning& t, long v) { t.tail_run_log = (uint32_t)v; }},
-    {"FRIEDA_HOST_DECOMMIT", 0, 1, [](Tuning& t, long v) { t.host_decommit = v != 0; }},
-    {"FRIEDA_GATHER_COPY", 0, 1, [](Tuning& t, long v) { t.gather_copy = v != 0; }},
-    {"FRIEDA_TEST_GRIND_FIRST_LOG", 0, 40, [](Tuning& t, long v) { t.test_grind_first_log = (v >= 8) ? (uint32_t)v : 0u; }},
+    {"FRIEDA_T5_WIDE_LOG", 16, 24, [](Tuning& t, long v) { t.t5_wide_log = (uint32_t)v; return true; }},
+    {"FRIEDA_T5_REG3_LOG", 0, 30, [](Tuning& t, long v) { t.t5_reg3_log = (uint32_t)v; return true; }},
+    {"FRIEDA_T9_MAX_LOG", 8, 19, [](Tuning& t, long v) { t.t9_max_log = (uint32_t)v; return true; }},
+    {"FRIEDA_TOP_MAX_LOG", 9, 11, [](Tuning& t, long v) { t.top_max_log = (uint32_t)v; return true; }},
+    {"FRIEDA_NTT_CPW", 1, 4, [](Tuning& t, long v) { t.ntt_cpw = (uint32_t)v; return true; }},
+    {"FRIEDA_NTT_CPW_SMALL", 1, 4, [](Tuning& t, long v) { t.ntt_cpw_small = (uint32_t)v; return true; }},
+    {"FRIEDA_NTT_REP", 0, 1, [](Tuning& t, long v) { t.ntt_rep = v != 0; return true; }},
+    {"FRIEDA_NTT_NO_PAD8", 0, 1, [](Tuning& t, long v) { t.ntt_no_pad8 = v != 0; return true; }},
+    {"FRIEDA_NTT_TREE_REG_ONLY", 0, 1, [](Tuning& t, long v) { t.ntt_tree_reg_only = v != 0; return true; }},
+    {"FRIEDA_NO_ENCODE_TREE_FUSION", 0, 1, [](Tuning& t, long v) { t.no_encode_tree_fusion = v != 0; return true; }},
+    {"FRIEDA_NO_SMALL_FUSED", 0, 1, [](Tuning& t, long v) { t.no_small_fused = v != 0; return true; }},
+    {"FRIEDA_UNPACK_TILES", 1, 8, [](Tuning& t, long v) {
+         if (v != 1 && v != 2 && v != 4 && v != 8) return false;
+         t.unpack_tiles = (uint32_t)v;
+         return true;
+     }},
+    {"FRIEDA_INTT_GENERIC", 0, 1, [](Tuning& t, long v) { t.intt_generic = v != 0; return true; }},
+    {"FRIEDA_ERASURE_TREE_MIN_LOG", 6, 32, [](Tuning& t, long v) { t.erasure_tree_min_log = (uint32_t)v; return true; }},
+    {"FRIEDA_TAIL_RUN_LOG", 4, 11, [](Tuning& t, long v) { t.tail_run_log = (uint32_t)v; return true; }},
+    {"FRIEDA_HOST_DECOMMIT", 0, 1, [](Tuning& t, long v) { t.host_decommit = v != 0; return true; }},
+    {"FRIEDA_GATHER_COPY", 0, 1, [](Tuning& t, long v) { t.gather_copy = v != 0; return true; }},
+    {"FRIEDA_BATCH_BUDGET_MB", 0, 262144, [](Tuning& t, long v) { t.batch_budget_mb = (uint32_t)v; return true; }},
+    {"FRIEDA_BATCH_CALLS_PER_CTX", 1, 64, [](Tuning& t, long v) { t.batch_calls_per_ctx = (uint32_t)v; return true; }},
 };
 }  // namespace
 
@@ -138,8 +145,7 @@ bool tuning_set(Tuning& t, const char* name, long value) {
     for (const KnobDesc& k : KNOBS) {
         if (strcmp(k.name, name) == 0) {
             if (value < k.lo || value > k.hi) return false;
-            k.set(t, value);
-            return true;
+            return k.set(t, value);
         }
     }
     return false;
@@ -164,6 +170,41 @@ const Tuning& tuning_defaults() {
     return d;
 }
 }  // namespace k
+
+// ---- batch policy (host.h) ----
+uint64_t batch_budget_bytes(const k::Tuning& t) {
+    if (t.batch_budget_mb) return (uint64_t)t.batch_budget_mb << 20;
+    // the measured optimum of the headline size, stated in workspace bytes so that it carries over to every other size: five proofs
+    // of a 2^24 domain per call (15 MiB blobs: 2^22 felts -> 2^20 coefficients per column, blowup 2^4), ~13.6 GB
+    static const uint64_t five_headline = 5 * (uint64_t)workspace_bytes_per_blob((size_t)15 << 20, 4, 0, true, true);
+    return five_headline;
+}
+
+uint32_t batch_per_call(const k::Tuning& t, size_t ws_per_blob, uint32_t count, uint32_t in_flight) {
+    if (count == 0) return 1;
+    if (in_flight == 0) in_flight = 1;
+    uint64_t per = ws_per_blob ? batch_budget_bytes(t) / ws_per_blob : 1;
+    const uint64_t ways = (uint64_t)std::max<uint32_t>(1, t.batch_calls_per_ctx) * in_flight;
+    const uint64_t spread = (count + ways - 1) / ways;  // every context gets its calls
+    per = std::min<uint64_t>(per, spread);
+    per = std::min<uint64_t>(per, 65535);  // the batched entry points' own limit
+    return (uint32_t)std::max<uint64_t>(per, 1);
+}
+
+void batch_cut(uint32_t count, uint32_t per_call, uint32_t in_flight, std::vector<uint32_t>& calls) {
+    calls.clear();
+    if (count == 0) return;
+    if (per_call == 0) per_call = 1;
+    if (in_flight == 0) in_flight = 1;
+    // the number of calls is a multiple of the calls in flight: an odd call out would run alone on the chip, its latency chain and
+    // its launches' ramps un-overlapped (20 blobs: 4 x 5, not 5 x 4); no call exceeds per_call (the budget is a ceiling)
+    const uint64_t round = (uint64_t)per_call * in_flight;
+    uint64_t n = (uint64_t)in_flight * ((count + round - 1) / round);
+    n = std::min<uint64_t>(n, count);
+    const uint32_t base = (uint32_t)(count / n), extra = (uint32_t)(count % n);
+    calls.assign((size_t)n, base);
+    for (uint32_t i = 0; i < extra; i++) calls[i] = base + 1;
+}
 
 int Ctx::set_kernel_timing(bool enabled) {
     if (enabled && !timer) timer = new KernelTimerImpl();

@@ -167,6 +167,20 @@ int commit_batch(Ctx* ctx, const uint8_t* data, size_t data_stride, size_t len, 
 int commit_batch_begin(Ctx* ctx, const uint8_t* data, size_t data_stride, size_t len, uint32_t count, bool data_on_device, uint32_t log_blowup,
                        const uint8_t* const* host_ptrs = nullptr);
 int commit_batch_finish(Ctx* ctx, uint8_t* out_roots);
+// ---- batch policy: how a run of equal-length blobs is cut into batched calls ("bytes in flight") ----
+// Every kernel of a batched call covers all its blobs, so the launch / Fiat-Shamir latency chain is paid once per call: small blobs
+// want many per call, large ones few (the workspace grows with the count).  Measured on MI355X (profiles/r04 larger_batch rows, r05):
+// what matters is the bytes of workspace a call keeps in flight, not the blob count.
+//   per_call = clamp(budget / workspace_bytes_per_blob, 1, ceil(count / (calls_per_ctx * in_flight))),
+//   calls    = the smallest multiple of in_flight (no context idles while the last call runs alone) with no call above per_call,
+//              sizes equal to within one.
+// One implementation for frieda_prove_many / frieda_commit_many (multi.cpp), frieda_batch_plan (callers that drive _begin / _finish
+// themselves: frieda_amd.BatchPipeline, bench.py) and the tests.
+size_t workspace_bytes_per_blob(size_t len, uint32_t log_blowup, uint32_t log_last_layer, bool prove, bool data_on_device);
+uint64_t batch_budget_bytes(const k::Tuning& t);  // FRIEDA_BATCH_BUDGET_MB, or the default: five proofs of a 2^24 domain (blowup 2^4), ~13.6 GB
+uint32_t batch_per_call(const k::Tuning& t, size_t ws_per_blob, uint32_t count, uint32_t in_flight);
+void batch_cut(uint32_t count, uint32_t per_call, uint32_t in_flight, std::vector<uint32_t>& calls);
+
 // returns FRIEDA_OK with *ok set, or FRIEDA_ERR_INVARIANT where the reference panics
 // out_queries (optional): on acceptance, the sorted distinct query positions the transcript sampled — evaluations[i] of the proof is
 // the value of the 4 columns at position out_queries[i] of the bit-reversed codeword (src/proof.rs:62-66)

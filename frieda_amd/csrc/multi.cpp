@@ -4,7 +4,8 @@
 // (/root/reference/src/lib.rs:31-38; the bench loops of benches/commit.rs:11-15, benches/proof.rs:30-44).  The blobs are
 // independent, so the path shards at blob granularity: blob i -> device i mod n, one host thread and two
 // contexts per device (two calls in flight: the latency chain of one runs under the wide kernels of the other; runs of
-// equal-length blobs go through the batched kernels MULTI_UNIT at a time, so the chain is also paid once per unit), no data-path
+// equal-length blobs go through the batched kernels, as many per call as the batch policy's workspace budget allows, so the chain is also
+// paid once per unit), no data-path
 // collective.  The only exchange is the gather of the 32-byte commitment roots: one `ncclAllGather` per device on a
 // single-process communicator (`ncclCommInitAll`) — RCCL over xGMI — after which every device holds every root (slot layout:
 // rank-major, blob i at rank i mod n, slot i div n); the host reads device 0's copy.  With one device there is nothing to
@@ -14,9 +15,12 @@
 // bundles its own librccl.so.1) must share that instance, and single-GPU users of libfrieda_hip.so should not load a 570 MB
 // library.  FRIEDA_RCCL_PATH overrides the library (the tests substitute a recording stub).
 #include <dlfcn.h>
+#include <pthread.h>
+#include <sched.h>
 #include <string.h>
 
 #include <algorithm>
+#include <cctype>
 #include <atomic>
 #include <cstdio>
 #include <cstdlib>
@@ -75,6 +79,88 @@ struct RcclApi {
 
 }  // namespace
 
+// ---- NUMA placement of the per-device host threads ----
+// On a two-socket 8-GPU node each device hangs off one socket; its worker thread feeds it with hipMemcpyAsync from pageable
+// memory (a staging copy by the runtime on the calling thread's CPU) and assembles its proofs.  Each worker is therefore pinned to
+// the CPUs of its GPU's NUMA node: /sys/bus/pci/devices/<hipDeviceGetPCIBusId>/numa_node -> /sys/devices/system/node/node<k>/cpulist,
+// intersected with the affinity the process was given.  Anything missing (no sysfs entry, node -1, empty intersection,
+// FRIEDA_MULTI_NO_NUMA_PIN=1) leaves the thread where the scheduler puts it.
+namespace frieda {
+// "0-3,8,10-11\n" -> {0,1,2,3,8,10,11}; false on malformed text (nothing is pinned then)
+bool parse_cpulist(const char* text, std::vector<int>& cpus) {
+    cpus.clear();
+    if (!text) return false;
+    const char* p = text;
+    while (*p == ' ' || *p == '\t') p++;
+    if (*p == '\0' || *p == '\n') return true;  // an empty list is valid (a memory-only node)
+    for (;;) {
+        char* end = nullptr;
+        const long a = strtol(p, &end, 10);
+        if (end == p || a < 0 || a > 65535) return false;
+        long b = a;
+        p = end;
+        if (*p == '-') {
+            p++;
+            b = strtol(p, &end, 10);
+            if (end == p || b < a || b > 65535) return false;
+            p = end;
+        }
+        for (long c = a; c <= b; c++) cpus.push_back((int)c);
+        if (*p == ',') {
+            p++;
+            continue;
+        }
+        while (*p == ' ' || *p == '\t' || *p == '\n') p++;
+        return *p == '\0';
+    }
+}
+}  // namespace frieda
+
+namespace {
+bool read_small_file(const std::string& path, std::string& out) {
+    FILE* f = fopen(path.c_str(), "r");
+    if (!f) return false;
+    char buf[4096];
+    const size_t n = fread(buf, 1, sizeof(buf) - 1, f);
+    fclose(f);
+    buf[n] = 0;
+    out = buf;
+    return true;
+}
+// the CPUs near HIP device `dev`, restricted to the process's affinity; empty: unknown / nothing to do
+std::vector<int> cpus_near_device(int dev) {
+    std::vector<int> out;
+    const char* off = getenv("FRIEDA_MULTI_NO_NUMA_PIN");
+    if (off && *off == '1') return out;
+    char bus[64] = {0};
+    if (hipDeviceGetPCIBusId(bus, (int)sizeof(bus), dev) != hipSuccess) {
+        (void)hipGetLastError();
+        return out;
+    }
+    for (char* c = bus; *c; c++) *c = (char)tolower(*c);
+    std::string node_s, list_s;
+    if (!read_small_file(std::string("/sys/bus/pci/devices/") + bus + "/numa_node", node_s)) return out;
+    const long node = strtol(node_s.c_str(), nullptr, 10);
+    if (node < 0) return out;  // -1: the platform reports no affinity
+    if (!read_small_file("/sys/devices/system/node/node" + std::to_string(node) + "/cpulist", list_s)) return out;
+    std::vector<int> near;
+    if (!frieda::parse_cpulist(list_s.c_str(), near)) return out;
+    cpu_set_t have;
+    CPU_ZERO(&have);
+    if (sched_getaffinity(0, sizeof(have), &have) != 0) return out;
+    for (int c : near)
+        if (c < CPU_SETSIZE && CPU_ISSET(c, &have)) out.push_back(c);
+    return out;
+}
+void pin_this_thread(const std::vector<int>& cpus) {
+    if (cpus.empty()) return;
+    cpu_set_t set;
+    CPU_ZERO(&set);
+    for (int c : cpus) CPU_SET(c, &set);
+    (void)pthread_setaffinity_np(pthread_self(), sizeof(set), &set);  // best effort
+}
+}  // namespace
+
 // joins whatever was started, on every exit path (a std::thread destroyed while joinable terminates the process)
 struct JoinAll {
     std::vector<std::thread>& w;
@@ -96,7 +182,39 @@ static void drain_ctx(frieda_ctx* c) {
     }
 }
 
-constexpr uint32_t MULTI_UNIT = 4;  // equal-length blobs handed to a device per call (the batched kernels)
+inline size_t ring_stride(size_t len) { return (len + 255) & ~(size_t)255; }
+
+// A device's share of the blobs (blob d, d + n, ...) cut into units = calls of the batched kernels.  A run of equal-length blobs is
+// cut by the library's batch policy (host.h: workspace bytes in flight, two calls in flight per device), anything else is a single
+// blob.  With host blobs travelling ahead of their kernels, the very first unit is a single blob when more follow: the chip starts
+// after one upload instead of a whole unit's.
+struct Unit {
+    uint32_t slot, cnt;
+};
+static void cut_device_units(const size_t* lens, uint32_t d, uint32_t n, uint32_t mine, bool batchable, bool prove, uint32_t log_blowup,
+                             uint32_t log_last, const k::Tuning& tune, bool first_single, std::vector<Unit>& units, size_t& ring_need) {
+    units.clear();
+    ring_need = 0;
+    std::vector<uint32_t> calls;
+    for (uint32_t slot = 0; slot < mine;) {
+        const uint32_t i0 = d + slot * n;
+        uint32_t run = 1;
+        while (batchable && slot + run < mine && lens[i0 + run * n] == lens[i0]) run++;
+        if (first_single && slot == 0 && mine > 1 && run > 1) {
+            units.push_back(Unit{0, 1});
+            ring_need = std::max(ring_need, ring_stride(lens[i0]));
+            slot = 1;
+            continue;
+        }
+        const size_t ws = workspace_bytes_per_blob(lens[i0], log_blowup, log_last, prove, true);  // 0: the call itself reports the shape error
+        batch_cut(run, ws ? batch_per_call(tune, ws, run, 2) : 1u, 2, calls);
+        for (uint32_t c : calls) {
+            units.push_back(Unit{slot, c});
+            ring_need = std::max(ring_need, ring_stride(lens[i0]) * c);
+            slot += c;
+        }
+    }
+}
 
 // Host blobs travel ahead of their kernels.  The two contexts of a device finish their units at about the same time (two launches
 // of the same kernel share the chip evenly), so an upload enqueued on a context's own stream at `begin` would run with the chip
@@ -110,12 +228,12 @@ struct UploadRing {
     uint8_t* slot[RING_SLOTS] = {};
     size_t cap = 0;  // bytes per slot
 };
-inline size_t ring_stride(size_t len) { return (len + 255) & ~(size_t)255; }
 
 struct frieda_multi {
     std::vector<int> devices;
     std::vector<frieda_ctx*> ctx;        // 2 per device: [2 d], [2 d + 1]
     std::vector<UploadRing> ring;        // per device
+    std::vector<std::vector<int>> near_cpus;  // per device: the CPUs of its NUMA node (empty: unknown, the worker is not pinned)
     bool prefetch = true;                // FRIEDA_MULTI_NO_PREFETCH=1: uploads on the contexts' own streams at begin (round 2's path; A/B knob)
     std::vector<hipStream_t> gstream;    // per device: the stream the gather runs on
     std::vector<uint8_t*> d_send, d_recv;
@@ -262,6 +380,8 @@ int frieda_multi_create(const int* devices, uint32_t n_devices, frieda_multi** o
         m->d_send.assign(n_devices, nullptr);
         m->d_recv.assign(n_devices, nullptr);
         m->ring.assign(n_devices, UploadRing{});
+        m->near_cpus.resize(n_devices);
+        for (uint32_t d = 0; d < n_devices; d++) m->near_cpus[d] = cpus_near_device(devices[d]);
         {
             const char* np = getenv("FRIEDA_MULTI_NO_PREFETCH");
             m->prefetch = !(np && *np == '1');
@@ -339,6 +459,26 @@ uint32_t frieda_multi_device_count(const frieda_multi* m) { return m ? (uint32_t
 const char* frieda_multi_last_error(const frieda_multi* m) { return m ? m->err.c_str() : "null handle"; }
 int frieda_multi_uses_rccl(const frieda_multi* m) { return m && m->use_rccl ? 1 : 0; }
 uint64_t frieda_multi_gather_count(const frieda_multi* m) { return m ? m->gathers : 0; }
+uint32_t frieda_multi_near_cpus(const frieda_multi* m, uint32_t device_slot, int* out_cpus, size_t cap) {
+    if (!m || device_slot >= m->near_cpus.size()) return 0;
+    const std::vector<int>& v = m->near_cpus[device_slot];
+    for (size_t i = 0; i < v.size() && i < cap && out_cpus; i++) out_cpus[i] = v[i];
+    return (uint32_t)v.size();
+}
+int frieda_test_parse_cpulist(const char* text, int* out_cpus, size_t cap, size_t* n) {
+    if (!n) return FRIEDA_ERR_ARG;
+    *n = 0;
+    try {
+        std::vector<int> v;
+        if (!parse_cpulist(text, v)) return FRIEDA_ERR_FORMAT;
+        *n = v.size();
+        if (v.size() > cap) return FRIEDA_ERR_ARG;
+        for (size_t i = 0; i < v.size() && out_cpus; i++) out_cpus[i] = v[i];
+        return FRIEDA_OK;
+    } catch (...) {
+        return FRIEDA_ERR_NOMEM;
+    }
+}
 frieda_ctx* frieda_multi_ctx(frieda_multi* m, uint32_t device_slot) {
     return m && device_slot < m->devices.size() ? m->ctx[2 * (size_t)device_slot] : nullptr;
 }
@@ -361,6 +501,7 @@ int frieda_commit_many(frieda_multi* m, const uint8_t* const* blobs, const size_
         for (size_t d = 0; d < n; d++) local[d].resize((count + n - 1 - d) / n);
         for (size_t d = 0; d < n; d++) {
             workers.emplace_back([&, d] {
+                pin_this_thread(m->near_cpus[d]);
                 frieda_ctx* cx[2] = {m->ctx[2 * d], m->ctx[2 * d + 1]};
                 const bool pf = m->prefetch;
                 struct DrainUploads {  // no upload may still be reading the caller's blobs when the worker returns
@@ -372,25 +513,13 @@ int frieda_commit_many(frieda_multi* m, const uint8_t* const* blobs, const size_
                     }
                 } drain_uploads{m, d, pf};
                 try {
-                    // This device's blobs in order, cut into units (a run of up to MULTI_UNIT blobs of one length = one call of the
-                    // batched kernels); two units in flight on the two contexts, the blobs of the unit after them being uploaded
+                    // This device's blobs in order, cut into units (cut_device_units: a run of blobs of one length = calls of the
+                    // batched kernels, sized by the batch policy); two units in flight on the two contexts, the blobs of the unit after them being uploaded
                     // meanwhile on the copy stream.
                     const uint32_t mine = (uint32_t)local[d].size();
-                    struct Unit {
-                        uint32_t slot, cnt;
-                    };
                     std::vector<Unit> units;
                     size_t ring_need = 0;
-                    for (uint32_t slot = 0; slot < mine;) {
-                        const uint32_t i0 = (uint32_t)d + slot * (uint32_t)n;
-                        uint32_t cnt = 1;
-                        // (the very first unit is a single blob when more follow: the chip starts after one upload instead of four)
-                        const uint32_t cap = (slot == 0 && mine > MULTI_UNIT) ? 1u : MULTI_UNIT;
-                        while (cnt < cap && slot + cnt < mine && lens[i0 + cnt * n] == lens[i0]) cnt++;
-                        units.push_back(Unit{slot, cnt});
-                        ring_need = std::max(ring_need, ring_stride(lens[i0]) * cnt);
-                        slot += cnt;
-                    }
+                    cut_device_units(lens, (uint32_t)d, (uint32_t)n, mine, true, false, log_blowup_factor, 0, cx[0]->c.tuning, pf, units, ring_need);
                     auto bail_msg = [&](int rc, const std::string& msg) {
                         if (status[d] == FRIEDA_OK) {
                             status[d] = rc;
@@ -408,9 +537,9 @@ int frieda_commit_many(frieda_multi* m, const uint8_t* const* blobs, const size_
                     }
                     auto upload = [&](size_t u) {
                         const uint32_t i0 = (uint32_t)d + units[u].slot * (uint32_t)n;
-                        const uint8_t* ptrs[MULTI_UNIT];
+                        std::vector<const uint8_t*> ptrs(units[u].cnt);
                         for (uint32_t k = 0; k < units[u].cnt; k++) ptrs[k] = blobs[i0 + k * n];
-                        return m->upload(d, (uint32_t)(u % RING_SLOTS), ptrs, lens[i0], units[u].cnt, uw);
+                        return m->upload(d, (uint32_t)(u % RING_SLOTS), ptrs.data(), lens[i0], units[u].cnt, uw);
                     };
                     auto begin = [&](size_t u) {
                         const uint32_t i0 = (uint32_t)d + units[u].slot * (uint32_t)n;
@@ -421,9 +550,9 @@ int frieda_commit_many(frieda_multi* m, const uint8_t* const* blobs, const size_
                             return commit_batch_begin(c, m->ring[d].slot[u % RING_SLOTS], ring_stride(lens[i0]), lens[i0], units[u].cnt, true,
                                                       log_blowup_factor, nullptr);
                         }
-                        const uint8_t* ptrs[MULTI_UNIT];
+                        std::vector<const uint8_t*> ptrs(units[u].cnt);
                         for (uint32_t k = 0; k < units[u].cnt; k++) ptrs[k] = blobs[i0 + k * n];
-                        return commit_batch_begin(c, ptrs[0], lens[i0], lens[i0], units[u].cnt, false, log_blowup_factor, ptrs);
+                        return commit_batch_begin(c, ptrs[0], lens[i0], lens[i0], units[u].cnt, false, log_blowup_factor, ptrs.data());
                     };
                     int rc = FRIEDA_OK;
                     for (size_t u = 0; pf && u < 2 && u < units.size() && rc == FRIEDA_OK; u++) rc = upload(u);
@@ -494,6 +623,7 @@ int frieda_prove_many(frieda_multi* m, const uint8_t* const* blobs, const size_t
         for (size_t d = 0; d < n; d++) local[d].resize((count + n - 1 - d) / n);
         for (size_t d = 0; d < n; d++) {
             workers.emplace_back([&, d] {
+              pin_this_thread(m->near_cpus[d]);
               const bool pf = m->prefetch;
               struct DrainUploads {  // no upload may still be reading the caller's blobs when the worker returns
                   frieda_multi* m;
@@ -504,8 +634,9 @@ int frieda_prove_many(frieda_multi* m, const uint8_t* const* blobs, const size_t
                   }
               } drain_uploads{m, d, pf};
               try {
-                // This device's blobs in order, cut into units: a run of up to MULTI_UNIT blobs of one length is one call of the
-                // batched kernels (the Fiat-Shamir chain is paid once per unit), anything else a single proof.  Two units in
+                // This device's blobs in order, cut into units (cut_device_units: a run of blobs of one length goes through the
+                // batched kernels, as many per call as the batch policy's workspace budget allows — the Fiat-Shamir chain is paid
+                // once per unit —, anything else is a single proof).  Two units in
                 // flight: begin(u + 1) is enqueued on the other context before finish(u) waits; the blobs of unit u + 2 are
                 // uploaded on the copy stream meanwhile.
                 frieda_ctx* cx[2] = {m->ctx[2 * d], m->ctx[2 * d + 1]};
@@ -516,21 +647,10 @@ int frieda_prove_many(frieda_multi* m, const uint8_t* const* blobs, const size_t
                 const bool batchable = cfg.log_last_layer_degree_bound <= 11 && cfg.log_blowup_factor <= 11 &&
                                        cfg.log_last_layer_degree_bound + cfg.log_blowup_factor <= 11 && !cx[0]->c.host_channel &&
                                        !cx[1]->c.host_channel;
-                struct Unit {
-                    uint32_t slot, cnt;
-                };
                 std::vector<Unit> units;
                 size_t ring_need = 0;
-                for (uint32_t slot = 0; slot < mine;) {
-                    const uint32_t i0 = (uint32_t)d + slot * (uint32_t)n;
-                    uint32_t cnt = 1;
-                    // (the very first unit is a single blob when more follow: the chip starts after one upload instead of four)
-                    const uint32_t cap = (slot == 0 && mine > MULTI_UNIT) ? 1u : MULTI_UNIT;
-                    while (batchable && cnt < cap && slot + cnt < mine && lens[i0 + cnt * n] == lens[i0]) cnt++;
-                    units.push_back(Unit{slot, cnt});
-                    ring_need = std::max(ring_need, ring_stride(lens[i0]) * cnt);
-                    slot += cnt;
-                }
+                cut_device_units(lens, (uint32_t)d, (uint32_t)n, mine, batchable, true, cfg.log_blowup_factor, cfg.log_last_layer_degree_bound,
+                                 cx[0]->c.tuning, pf, units, ring_need);
                 auto bail_msg = [&](int rc, const std::string& msg) {
                     if (status[d] == FRIEDA_OK) {
                         status[d] = rc;
@@ -547,16 +667,18 @@ int frieda_prove_many(frieda_multi* m, const uint8_t* const* blobs, const size_t
                 }
                 auto upload = [&](size_t u) {
                     const uint32_t i0 = (uint32_t)d + units[u].slot * (uint32_t)n;
-                    const uint8_t* ptrs[MULTI_UNIT];
+                    std::vector<const uint8_t*> ptrs(units[u].cnt);
                     for (uint32_t k = 0; k < units[u].cnt; k++) ptrs[k] = blobs[i0 + k * n];
-                    return m->upload(d, (uint32_t)(u % RING_SLOTS), ptrs, lens[i0], units[u].cnt, uw);
+                    return m->upload(d, (uint32_t)(u % RING_SLOTS), ptrs.data(), lens[i0], units[u].cnt, uw);
                 };
                 auto begin = [&](size_t u) {
                     const Unit& un = units[u];
                     const uint32_t i0 = (uint32_t)d + un.slot * (uint32_t)n;
                     Ctx* c = &cx[u & 1]->c;
-                    const uint8_t* ptrs[MULTI_UNIT];
-                    uint64_t sd[MULTI_UNIT];
+                    std::vector<const uint8_t*> ptrs_v(un.cnt);
+                    std::vector<uint64_t> sd_v(un.cnt);
+                    const uint8_t** ptrs = ptrs_v.data();
+                    uint64_t* sd = sd_v.data();
                     for (uint32_t k = 0; k < un.cnt; k++) {
                         ptrs[k] = blobs[i0 + k * n];
                         sd[k] = seeds ? seeds[i0 + k * n] : 0;

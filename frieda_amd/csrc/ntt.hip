@@ -27,6 +27,8 @@
 // twice its HBM time.
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include <cstdlib>
 
 #include "clock_stamps.h"
@@ -590,8 +592,9 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_last_tree_kernel(NttTreeArgs 
     for (int it = 0; it < 4; it++) {
         const size_t l0 = leaf0 + 4u * (uint32_t)it;
         uint32_t hb[2][8];
-#pragma unroll
-        for (int half = 0; half < 2; half++) {
+        // (written out through a lambda: the unroller refuses loops whose body carries the compressions' inline asm)
+        auto half_ab = [&](auto half_c) {
+            constexpr int half = decltype(half_c)::value;
             uint32_t ha[2][8];
             leaf_hash(v[0][2 * half], v[1][2 * half], v[2][2 * half], v[3][2 * half], ha[0]);
             leaf_hash(v[0][2 * half + 1], v[1][2 * half + 1], v[2][2 * half + 1], v[3][2 * half + 1], ha[1]);
@@ -599,7 +602,9 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_last_tree_kernel(NttTreeArgs 
 #pragma unroll
             for (int w = 0; w < 8; w++) mm[w] = ha[0][w], mm[8 + w] = ha[1][w];
             b2_merkle_block(mm, hb[half]);
-        }
+        };
+        half_ab(std::integral_constant<int, 0>{});
+        half_ab(std::integral_constant<int, 1>{});
         if (STORE_ALL) {
             store_hash(out_b, l0 >> 1, hb[0]);
             store_hash(out_b, (l0 >> 1) + 1, hb[1]);

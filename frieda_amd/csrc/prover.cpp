@@ -371,6 +371,55 @@ struct ProveJob {
 
 void ProveJobDeleter::operator()(ProveJob* j) const { delete j; }
 
+namespace {
+// the per-blob part of a proof's workspace (one plan for the prover and for the batch policy, which divides its budget by plan.off)
+void plan_prove_blob(ArenaPlan& plan, const Shape& sh, uint32_t last_log, size_t host_len, size_t& o_data, size_t& o_coef, FriLayerDev& first,
+                     std::vector<FriLayerDev>& inner, size_t& o_lastv, size_t& o_nonce) {
+    const uint32_t n = sh.n, n_inner = (n - 1) - last_log;
+    o_data = plan.take(host_len);
+    o_coef = plan.take(sizeof(uint32_t) * sh.cs.n_padded);
+    first = FriLayerDev{plan.take(sizeof(uint32_t) * 4 * sh.N), 0, n};
+    first.o_tree = plan.take(k::merkle_layer_offset(n, 0) + 32);
+    inner.resize(n_inner);
+    for (uint32_t kx = 0; kx < n_inner; kx++) {
+        uint32_t lg = n - 1 - kx;
+        inner[kx].log = lg;
+        inner[kx].o_vals = plan.take(sizeof(uint32_t) * 4 << lg);
+        inner[kx].o_tree = plan.take(k::merkle_layer_offset(lg, 0) + 32);
+    }
+    o_lastv = plan.take(sizeof(uint32_t) * 4 << last_log);
+    o_nonce = plan.take(8);
+}
+}  // namespace
+
+// Device workspace one blob of `len` bytes adds to a batched call (what ensure_arena is asked for, per blob): the figure the batch
+// policy (batch_plan below) divides its budget by.  0: the shape is outside what the prover accepts.
+size_t workspace_bytes_per_blob(size_t len, uint32_t log_blowup, uint32_t log_last_layer, bool prove, bool data_on_device) {
+    if (log_blowup > FRIEDA_MAX_LOG_DOMAIN || len > ((size_t)1 << 40)) return 0;
+    Shape sh;
+    sh.cs = codec_shape(len);
+    sh.L = sh.cs.log_size;
+    sh.B = log_blowup;
+    if ((uint64_t)sh.L + log_blowup < 1 || (uint64_t)sh.L + log_blowup > FRIEDA_MAX_LOG_DOMAIN) return 0;
+    sh.n = sh.L + log_blowup;
+    sh.N = (size_t)1 << sh.n;
+    ArenaPlan plan;
+    if (!prove) {  // commit_batch_begin's plan
+        plan.take(data_on_device ? 0 : len);
+        plan.take(sizeof(uint32_t) * sh.cs.n_padded);
+        plan.take(sizeof(uint32_t) * 4 * sh.N);
+        plan.take(k::merkle_root_scratch_bytes(sh.n));
+        plan.take(32);
+        return plan.off;
+    }
+    if (log_last_layer > 10 || sh.n < 2 || sh.L < 1 + log_last_layer || log_last_layer + log_blowup > sh.n - 1) return 0;
+    size_t a, b, c, d;
+    FriLayerDev first;
+    std::vector<FriLayerDev> inner;
+    plan_prove_blob(plan, sh, log_last_layer + log_blowup, data_on_device ? 0 : len, a, b, first, inner, c, d);
+    return plan.off;
+}
+
 static double ms_since(std::chrono::steady_clock::time_point t0) {
     return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
 }
@@ -455,21 +504,11 @@ int prove_begin_batch(Ctx* ctx, const uint8_t* data, size_t data_stride, size_t 
 
     // ---- workspace plan ----
     ArenaPlan plan;
-    size_t o_data = plan.take(data_on_device ? 0 : len);
-    size_t o_coef = plan.take(sizeof(uint32_t) * sh.cs.n_padded);
+    size_t o_data = 0, o_coef = 0;
     FriLayerDev& first = J.first;
-    first = FriLayerDev{plan.take(sizeof(uint32_t) * 4 * N), 0, n};
-    first.o_tree = plan.take(k::merkle_layer_offset(n, 0) + 32);
     std::vector<FriLayerDev>& inner = J.inner;
-    inner.resize(n_inner);
-    for (uint32_t kx = 0; kx < n_inner; kx++) {
-        uint32_t lg = n - 1 - kx;
-        inner[kx].log = lg;
-        inner[kx].o_vals = plan.take(sizeof(uint32_t) * 4 << lg);
-        inner[kx].o_tree = plan.take(k::merkle_layer_offset(lg, 0) + 32);
-    }
-    const size_t o_lastv = J.o_lastv = plan.take(sizeof(uint32_t) * 4 << last_log);
-    const size_t o_nonce = J.o_nonce = plan.take(8);
+    plan_prove_blob(plan, sh, last_log, data_on_device ? 0 : len, o_data, o_coef, first, inner, J.o_lastv, J.o_nonce);
+    const size_t o_lastv = J.o_lastv, o_nonce = J.o_nonce;
     // everything above is per blob; what follows is shared by the batch
     const size_t bstride = J.bstride = plan.off;  // a multiple of 256
     plan.off = bstride * count;

@@ -30,6 +30,8 @@
 // bound by the integer VALU pipe (~38 G compressions/s chip-wide), not by HBM.
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include <cstdlib>
 
 #include "clock_stamps.h"
@@ -243,16 +245,21 @@ __global__ __launch_bounds__(T5_THREADS) void tree5r_kernel(TreeArgs a) {
         *reinterpret_cast<uint4*>(a.out_vals + 3 * a.out_stride + g0) = lc3;
     }
     uint32_t hb[2][8];
-#pragma unroll
-    for (int half = 0; half < 2; half++) {
+    // (the two halves are written out through a lambda: the unroller refuses loops whose body carries the compressions' inline asm)
+    auto half_ab = [&](auto half_c) {
+        constexpr int half = decltype(half_c)::value;
         uint32_t ha[2][8];
         const size_t g = g0 + 2 * half;  // level-A nodes g, g + 1
         if (MODE == T_NODE) {
-#pragma unroll
-            for (int k = 0; k < 2; k++) {
+            {
                 uint32_t m[16];
-                load_children(a.children, g + k, m);
-                b2_merkle_block(m, ha[k]);
+                load_children(a.children, g, m);
+                b2_merkle_block(m, ha[0]);
+            }
+            {
+                uint32_t m[16];
+                load_children(a.children, g + 1, m);
+                b2_merkle_block(m, ha[1]);
             }
         } else if (half == 0) {
             leaf_hash(lc0.x, lc1.x, lc2.x, lc3.x, ha[0]);
@@ -269,7 +276,9 @@ __global__ __launch_bounds__(T5_THREADS) void tree5r_kernel(TreeArgs a) {
 #pragma unroll
         for (int w = 0; w < 8; w++) m[w] = ha[0][w], m[8 + w] = ha[1][w];
         b2_merkle_block(m, hb[half]);
-    }
+    };
+    half_ab(std::integral_constant<int, 0>{});
+    half_ab(std::integral_constant<int, 1>{});
     if (out_b) {
         store_hash(out_b, (g0 >> 1), hb[0]);
         store_hash(out_b, (g0 >> 1) + 1, hb[1]);
@@ -446,7 +455,7 @@ __device__ const uint32_t* wg_reduce(uint32_t* s_cur, uint32_t* s_other, uint32_
         for (uint32_t j = t; j < cnt; j += WG1_THREADS) {
             uint32_t m[16], h[8];
             lds_children(s_cur, 2 * cnt + 4, j, m);
-            b2_merkle_block(m, h);
+            b2_merkle_block<B2_LAT>(m, h);
             if (gout) store_hash(gout, j, h);
             if (cnt >= 512)
                 lds_put(s_other, cnt + 4, j, h);
@@ -554,7 +563,7 @@ __device__ __forceinline__ void tree9_upper(const TreeArgs& a, const uint32_t* R
     if (t < 128) {
         uint32_t m[16], h[8];
         lds_children(RA, 256 + 4, t, m);
-        b2_merkle_block(m, h);
+        b2_merkle_block<B2_LAT>(m, h);
         if (a.store_all) store_hash(a.layers + layer_off(a.tree_log, a.level_a - 1), (wg_base >> 1) + t, h);
         q_put_hash(QQ, t, h);
     }
@@ -755,7 +764,7 @@ __global__ __launch_bounds__(256) void small_first_kernel(SmallFirstArgs a) {
     }
     {
         uint32_t h[8];
-        leaf_hash(v0, v1, v2, v3, h);
+        leaf_hash<B2_LAT>(v0, v1, v2, v3, h);
         if (ta.store_all && !ta.skip_a) store_hash(ta.layers + layer_off(ta.tree_log, ta.level_a), e, h);
         lds_put(RA, 256 + 4, t, h);
     }
@@ -860,7 +869,7 @@ __global__ __launch_bounds__(WG1_THREADS) void top_kernel(TopArgs a) {
             for (uint32_t j = t; j < cnt; j += WG1_THREADS) {
                 uint32_t m[16], h[8];
                 load_children(a.in, j, m);
-                b2_merkle_block(m, h);
+                b2_merkle_block<B2_LAT>(m, h);
                 if (gout) store_hash(gout, j, h);
                 if (cnt >= 512)
                     lds_put(S0, cnt + 4, j, h);
@@ -952,7 +961,7 @@ __global__ __launch_bounds__(WG1_THREADS) void tail_kernel(TailArgs a) {
             dstv[3 * cnt + j] = r.d;
             if (!is_last) {
                 uint32_t h[8];
-                leaf_hash(r.a, r.b, r.c, r.d, h);
+                leaf_hash<B2_LAT>(r.a, r.b, r.c, r.d, h);
                 store_hash(a.trees[kx] + boff, j, h);  // leaf layer sits at offset 0
                 if (cnt >= 512)
                     lds_put(S0, cnt + 4, j, h);

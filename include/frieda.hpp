@@ -194,6 +194,19 @@ class MultiContext {
 
     bool uses_rccl() const { return frieda_multi_uses_rccl(h_) != 0; }
     uint64_t gather_count() const { return frieda_multi_gather_count(h_); }
+    uint32_t device_count() const { return frieda_multi_device_count(h_); }
+    // a tuning option (frieda_ctx_set_option) on device slot d, e.g. the batch policy's "FRIEDA_BATCH_BUDGET_MB"
+    void set_option(uint32_t device_slot, const char* name, int64_t value) {
+        frieda_ctx* c = frieda_multi_ctx(h_, device_slot);
+        if (!c) throw Error(FRIEDA_ERR_ARG, "no such device slot");
+        check(frieda_ctx_set_option(c, name, value));
+    }
+    // the CPUs the worker thread of device slot d is pinned to (its GPU's NUMA node); empty: not pinned
+    std::vector<int> near_cpus(uint32_t device_slot) const {
+        std::vector<int> v(frieda_multi_near_cpus(h_, device_slot, nullptr, 0));
+        if (!v.empty()) frieda_multi_near_cpus(h_, device_slot, v.data(), v.size());
+        return v;
+    }
     std::vector<Commitment> commit_many(const std::vector<std::vector<uint8_t>>& blobs, uint32_t log_blowup_factor) {
         std::vector<const uint8_t*> ptrs;
         std::vector<size_t> lens;

@@ -177,11 +177,31 @@ int frieda_verify(const frieda_proof* proof, const uint64_t* seed, int* ok);
  * the count (0 when the proof is rejected); FRIEDA_ERR_ARG when cap is smaller than that. */
 int frieda_verify_samples(const frieda_proof* proof, const uint64_t* seed, int* ok, uint32_t* out_positions, size_t cap, size_t* n_positions);
 
+/* ---- batch policy: how a stream of equal-length blobs is cut into batched calls ("bytes in flight") -------------------------
+ * Every kernel of a batched call covers all its blobs, so the launch / Fiat-Shamir latency chain is paid once per call: small
+ * blobs want many per call, large blobs few (the device workspace grows with the count).  The library's rule — what
+ * frieda_prove_many / frieda_commit_many apply per device, offered here to callers that drive _begin / _finish themselves (the
+ * caller loop of benches/proof.rs:30-44 over many blobs):
+ *     per_call = clamp(budget / frieda_workspace_bytes(blob), 1, ceil(count / (calls_per_ctx * in_flight)))
+ *     calls    = the smallest multiple of in_flight with no call above per_call, sizes equal to within one
+ * budget: context option "FRIEDA_BATCH_BUDGET_MB" (0 = default: the workspace of five proofs on a 2^24 domain, ~13.6 GB);
+ * calls_per_ctx: option "FRIEDA_BATCH_CALLS_PER_CTX" (default 1: one call per context when the budget allows — measured equal to
+ * two at the 2^22 / 2^24 domains and faster below, where a call is mostly its latency chain; raise it to bound a call's latency).
+ * in_flight = the contexts taking turns (frieda_prove_many uses 2 per device).
+ * frieda_workspace_bytes: device workspace one blob of `len` bytes adds to a batched call (prove != 0: commit_and_generate_proof,
+ * else commit); 0 when the shape is outside what the entry points accept.
+ * frieda_batch_plan: out_calls[0 .. *n_calls) receive the blob count of each call, in order (sum = count); ctx == NULL uses the
+ * default options; out_calls == NULL only counts; FRIEDA_ERR_ARG when cap is too small or the shape is invalid. */
+size_t frieda_workspace_bytes(size_t len, uint32_t log_blowup_factor, uint32_t log_last_layer_degree_bound, int prove);
+int frieda_batch_plan(const frieda_ctx* ctx, size_t len, uint32_t log_blowup_factor, uint32_t log_last_layer_degree_bound, int prove,
+                      uint32_t count, uint32_t in_flight, uint32_t* out_calls, size_t cap, uint32_t* n_calls);
+
 /* ---- multi-GPU: a batch of independent blobs across the GPUs of one node ---------------------------------------------
  * What a caller looping api::commit / commit_and_generate_proof over blobs gets on an 8 x MI355X node
  * (src/lib.rs:31-38; benches/commit.rs:11-15, benches/proof.rs:30-44).  The path shards at blob granularity: blob i runs
  * on devices[i mod n], one host thread and two contexts per device (two calls in flight; a run of equal-length blobs on a
- * device goes through the batched kernels four blobs per call), no data-path collective.  The
+ * device goes through the batched kernels, cut into calls by the batch policy above — options set on frieda_multi_ctx(m, d)
+ * apply to device slot d), no data-path collective.  The
  * only exchange is the gather of the 32-byte commitment roots: one ncclAllGather per device on a single-process
  * communicator (ncclCommInitAll; RCCL over xGMI), after which every device holds every root; the host reads device 0's
  * copy.  n == 1 needs no exchange and does not touch RCCL.  RCCL is bound at frieda_multi_create by dlopen("librccl.so.1")
@@ -198,6 +218,10 @@ const char* frieda_multi_last_error(const frieda_multi* m);
 /* 1 when root gathers go through RCCL (n > 1, or FRIEDA_MULTI_FORCE_RCCL=1); collectives issued so far */
 int frieda_multi_uses_rccl(const frieda_multi* m);
 uint64_t frieda_multi_gather_count(const frieda_multi* m);
+/* Each device's worker thread is pinned to the CPUs of that GPU's NUMA node (sysfs numa_node of its PCI function, intersected with
+ * the process's affinity; FRIEDA_MULTI_NO_NUMA_PIN=1 or a platform that reports none: not pinned).  Returns how many CPUs slot d's
+ * worker is pinned to (0: not pinned) and writes up to cap of them. */
+uint32_t frieda_multi_near_cpus(const frieda_multi* m, uint32_t device_slot, int* out_cpus, size_t cap);
 /* the first context of device slot d (e.g. to set a policy on it); owned by the handle */
 frieda_ctx* frieda_multi_ctx(frieda_multi* m, uint32_t device_slot);
 int frieda_commit_many(frieda_multi* m, const uint8_t* const* blobs, const size_t* lens, uint32_t count, uint32_t log_blowup_factor,

@@ -14,6 +14,15 @@ extern "C" {
  * made with a non-default bound do not verify.  0 restores 2P. */
 int frieda_ctx_test_set_draw_bound(frieda_ctx* ctx, uint32_t bound);
 
+/* The proof-of-work search scans ordered nonce windows (2^20 nonces first, then doubling).  log_first in 8 .. 40 makes the first
+ * window 2^log_first nonces, so that a test reaches the window-growth branch at a few bits of work; 0 restores the default.  The
+ * nonce found is the minimum either way. */
+int frieda_ctx_test_set_grind_first_log(frieda_ctx* ctx, uint32_t log_first);
+
+/* The parser of sysfs CPU lists ("0-3,8,10-11\n") behind frieda_multi's NUMA placement, for the CPU tests: *n receives the count,
+ * out_cpus (cap entries) the CPUs in order.  FRIEDA_ERR_FORMAT for malformed text, FRIEDA_ERR_ARG when cap is too small. */
+int frieda_test_parse_cpulist(const char* text, int* out_cpus, size_t cap, size_t* n);
+
 #ifdef __cplusplus
 }
 #endif

@@ -10,6 +10,8 @@
 #include <thread>
 #include <vector>
 
+#include <sched.h>
+
 #include "frieda.hpp"
 
 using namespace frieda;
@@ -36,7 +38,10 @@ static int multi_mode(const std::vector<uint8_t>& blob, int n_slots, bool distin
         for (size_t j = 0; j < d.size(); j++) d[j] = (uint8_t)(j * 29 + i * 5 + (j >> 5));
         blobs.push_back(d);
     }
-    for (int i = 0; i < 11; i++) {  // a run of equal lengths: the devices take these through the batched kernels, four per call
+    // a run of equal lengths: each device takes its share through the batched kernels, cut into calls by the library's batch policy
+    // (11 blobs on 1 - 3 slots; 8 slots get 8 x 9 + 3 so that every slot sees a multi-call run, one slot a longer one)
+    const int run_len = n_slots >= 4 ? 9 * n_slots + 3 : 11;
+    for (int i = 0; i < run_len; i++) {
         std::vector<uint8_t> d(3000);
         for (size_t j = 0; j < d.size(); j++) d[j] = (uint8_t)(j * 13 + i * 31 + (j >> 7));
         blobs.push_back(d);
@@ -80,6 +85,32 @@ static int multi_mode(const std::vector<uint8_t>& blob, int n_slots, bool distin
     CHECK(mc.commit_many({}, 4).empty());
     // and the handle is usable afterwards
     CHECK(mc.commit_many(blobs, 4) == roots);
+    {  // the batch policy is a performance knob, never a result: a 1 MB budget (one blob per call) and three calls per context
+       // on every slot give the same roots and proofs
+        CHECK(mc.device_count() == (uint32_t)n_slots);
+        for (int d = 0; d < n_slots; d++) mc.set_option(d, "FRIEDA_BATCH_BUDGET_MB", 1);
+        CHECK(mc.commit_many(blobs, 4) == roots);
+        auto again = mc.prove_many(provable, seeds.data(), PCS_CONFIG);
+        for (size_t i = 0; i < again.size(); i++) CHECK(again[i].first == proofs[i].first && again[i].second.serialize() == proofs[i].second.serialize());
+        for (int d = 0; d < n_slots; d++) mc.set_option(d, "FRIEDA_BATCH_BUDGET_MB", 0), mc.set_option(d, "FRIEDA_BATCH_CALLS_PER_CTX", 3);
+        CHECK(mc.commit_many(blobs, 4) == roots);
+        again = mc.prove_many(provable, seeds.data(), PCS_CONFIG);
+        for (size_t i = 0; i < again.size(); i++) CHECK(again[i].first == proofs[i].first && again[i].second.serialize() == proofs[i].second.serialize());
+        bool refused = false;
+        try {
+            mc.set_option(0, "FRIEDA_BATCH_CALLS_PER_CTX", 0);
+        } catch (const Error&) {
+            refused = true;
+        }
+        CHECK(refused);
+        // NUMA placement: whatever the platform reports, the list is a subset of the CPUs this process may run on
+        cpu_set_t have;
+        CPU_ZERO(&have);
+        CHECK(sched_getaffinity(0, sizeof(have), &have) == 0);
+        for (int d = 0; d < n_slots; d++)
+            for (int c : mc.near_cpus(d)) CHECK(c >= 0 && c < CPU_SETSIZE && CPU_ISSET(c, &have));
+        std::printf("near_cpus(slot 0): %zu\n", mc.near_cpus(0).size());
+    }
     std::printf("multi n_slots=%d rccl=%d gathers=%llu: %s (%d failures)\n", n_slots, (int)mc.uses_rccl(), (unsigned long long)mc.gather_count(),
                 failures ? "FAILED" : "ok", failures);
     return failures ? 1 : 0;

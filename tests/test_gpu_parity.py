@@ -533,11 +533,13 @@ def test_cpp_bench_harness(gpu_ctx):
     assert sum("time:" in ln for ln in r.stdout.splitlines()) == 20
 
 
-@pytest.mark.parametrize("n_slots,mode", [(1, "plain"), (1, "rccl"), (2, "stub"), (3, "stub")])
+@pytest.mark.parametrize("n_slots,mode", [(1, "plain"), (1, "rccl"), (2, "stub"), (3, "stub"), (8, "stub")])
 def test_cpp_multi_gpu_entry_points(gpu_ctx, n_slots, mode):
     """frieda_multi_create / frieda_commit_many / frieda_prove_many from C++ (tests/cpp/test_api.cpp multi_mode): the no-exchange
     path, the real one-rank RCCL collective (FRIEDA_MULTI_FORCE_RCCL=1), and the N > 1 gather layout against the RCCL test
-    double (this box has one GPU and real RCCL refuses a device listed twice)."""
+    double (this box has one GPU and real RCCL refuses a device listed twice).  8 slots = the target node's shape: 16 contexts,
+    8 worker threads, an 8-way rank-major gather, every slot with a multi-call run of equal-length blobs; each mode also re-runs
+    with the batch policy's options changed (results must not move) and checks the NUMA placement list."""
     import subprocess
 
     from conftest import GOLDEN, ROOT
@@ -1195,6 +1197,55 @@ def test_two_batches_in_flight(gpu_ctx):
     other.close()
 
 
+@pytest.mark.parametrize("length,count", [(2048, 37), (61440, 9), (700, 3)])
+def test_batch_policy_stream_equals_separate_calls(gpu_ctx, oracle, length, count):
+    """BatchPipeline.run_stream_device: a stream of equal-length device blobs cut into calls by the library's batch policy
+    (frieda_batch_plan) — whatever the cut (default budget, a 1 MB budget = one blob per call, four calls per context), the roots and
+    proofs are those of separate calls and the oracle's."""
+    import torch
+
+    import frieda_amd
+
+    cfg = _cfg(frieda_amd, 8, 4, 0, 12)
+    ocfg = oracle.make_config(8, 4, 0, 12)
+    blobs = [splitmix64_bytes(9700 + i, length) for i in range(count)]
+    dev = torch.from_numpy(np.concatenate(blobs)).cuda()
+    torch.cuda.synchronize()
+    seeds = [None if count < 4 else 40 + i for i in range(count)]
+    seeds = None if count < 4 else seeds
+    expect = [oracle.commit_and_generate_proof(b.tobytes(), None if seeds is None else seeds[i], ocfg) for i, b in enumerate(blobs)]
+    want = [(bytes(r), p.serialize()) for r, p in expect]
+    pipe = frieda_amd.BatchPipeline(0, 2)
+    try:
+        cuts = []
+        for opts in ({}, {"FRIEDA_BATCH_BUDGET_MB": 1}, {"FRIEDA_BATCH_BUDGET_MB": 0, "FRIEDA_BATCH_CALLS_PER_CTX": 4}):
+            for k, v in opts.items():
+                pipe.ctxs[0].set_option(k, v)
+            cut = pipe.plan(length, count, cfg)
+            assert sum(cut) == count
+            cuts.append(cut)
+            got = pipe.run_stream_device(dev.data_ptr(), length, length, count, seeds, cfg)
+            assert [(r, p.serialize()) for r, p in got] == want
+        if count >= 8:
+            assert max(cuts[1]) < max(cuts[0]) and len(cuts[0]) == 2 and len(cuts[2]) > 2  # the options did change the cut
+        if 2 * frieda_amd.workspace_bytes(length, 4) > (1 << 20) and count >= 4:
+            assert max(cuts[1]) == 1  # 1 MB of workspace: one blob per call
+    finally:
+        pipe.close()
+
+
+def test_batch_budget_option_range(gpu_ctx):
+    import frieda_amd
+
+    for name, bad in (("FRIEDA_BATCH_BUDGET_MB", -1), ("FRIEDA_BATCH_CALLS_PER_CTX", 0), ("FRIEDA_BATCH_CALLS_PER_CTX", 65), ("FRIEDA_UNPACK_TILES", 3),
+                      ("FRIEDA_UNPACK_TILES", 7), ("FRIEDA_TEST_GRIND_FIRST_LOG", 10)):
+        with pytest.raises(frieda_amd.FriedaError):
+            gpu_ctx.set_option(name, bad)  # in-range-but-unsupported values are refused too; the grind hook is no longer an option
+    gpu_ctx.set_option("FRIEDA_UNPACK_TILES", 4)
+    assert gpu_ctx._L.frieda_ctx_test_set_grind_first_log(gpu_ctx._h, 5) != 0  # below the smallest window
+    assert gpu_ctx._L.frieda_ctx_test_set_grind_first_log(gpu_ctx._h, 0) == 0
+
+
 def test_sharded_batch_helpers_use_the_batched_kernels(oracle):
     """frieda_amd.batch (the multi-GPU sharding layer) on one rank: equal-length shards go through the batched kernels, ragged
     ones through the C ABI's multi entry (frieda_commit_many / frieda_prove_many, two proofs in flight); both give the oracle's
@@ -1241,7 +1292,7 @@ def test_grind_retry_loop(gpu_ctx, oracle, monkeypatch):
     blobs = [splitmix64_bytes(9500 + i, 900).tobytes() for i in range(6)]
     expect = [oracle.commit_and_generate_proof(b, i, oracle.make_config(18, 4, 0, 8)) for i, b in enumerate(blobs)]
     assert len({p.c.proof_of_work for _, p in expect}) > 1
-    gpu_ctx.set_option("FRIEDA_TEST_GRIND_FIRST_LOG", 10)  # 1024 nonces, then 2048, 4096, ... (this context only)
+    _check(gpu_ctx, gpu_ctx._L.frieda_ctx_test_set_grind_first_log(gpu_ctx._h, 10))  # 1024 nonces, then 2048, 4096, ... (this context only)
     try:
         got = gpu_ctx.commit_and_generate_proof_batch(blobs, list(range(len(blobs))), cfg)
         for (er, ep), (gr, gp) in zip(expect, got):
@@ -1249,7 +1300,7 @@ def test_grind_retry_loop(gpu_ctx, oracle, monkeypatch):
         r, p = gpu_ctx.commit_and_generate_proof(blobs[0], 0, cfg)
         assert r == expect[0][0] and p.serialize() == expect[0][1].serialize()
     finally:
-        gpu_ctx.set_option("FRIEDA_TEST_GRIND_FIRST_LOG", 0)
+        gpu_ctx._L.frieda_ctx_test_set_grind_first_log(gpu_ctx._h, 0)
 
 
 def test_release_workspace(gpu_ctx):

@@ -160,7 +160,7 @@ def _run_bench(argv, env_extra=None, timeout=300):
     return r, [json.loads(ln) for ln in lines if ln.startswith("{")]
 
 
-@pytest.mark.parametrize("gpus", [2, 3])
+@pytest.mark.parametrize("gpus", [2, 3, 8])
 def test_bench_self_launches_its_ranks(gpus):
     """`python bench.py --gpus N` (no torch.distributed.run, no WORLD_SIZE) spawns its N ranks itself and relays rank 0's single
     JSON line.  `--dry-collective gloo` keeps the launcher, rendezvous, barriers, root all_gather and max-reduce and stubs the GPU."""
