@@ -177,11 +177,12 @@ __device__ __forceinline__ void b2_round_runs(uint32_t (&v)[16], const uint32_t 
     b2_half_round_runs<IDLE, R, 0>(v, m);
     b2_half_round_runs<IDLE, R, 1>(v, m);
 }
-// out = F(0, m, 0, 0) in the run-structured form; message words that are compile-time zeros (a leaf) fold as in the plain form
+// out = F(h, m, t, f) in the run-structured form
 template <int IDLE>
-__device__ __forceinline__ void b2_merkle_block_runs(const uint32_t (&m)[16], uint32_t (&out)[8]) {
+__device__ __forceinline__ void b2_compress_runs(const uint32_t (&h)[8], const uint32_t (&m)[16], uint32_t t0, uint32_t t1, uint32_t f0, uint32_t f1,
+                                                 uint32_t (&out)[8]) {
     using b2detail::IV;
-    uint32_t v[16] = {0, 0, 0, 0, 0, 0, 0, 0, IV[0], IV[1], IV[2], IV[3], IV[4], IV[5], IV[6], IV[7]};
+    uint32_t v[16] = {h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7], IV[0], IV[1], IV[2], IV[3], IV[4] ^ t0, IV[5] ^ t1, IV[6] ^ f0, IV[7] ^ f1};
     b2_round_runs<IDLE, 0>(v, m);
     b2_round_runs<IDLE, 1>(v, m);
     b2_round_runs<IDLE, 2>(v, m);
@@ -192,14 +193,20 @@ __device__ __forceinline__ void b2_merkle_block_runs(const uint32_t (&m)[16], ui
     b2_round_runs<IDLE, 7>(v, m);
     b2_round_runs<IDLE, 8>(v, m);
     b2_round_runs<IDLE, 9>(v, m);
-    out[0] = v[0] ^ v[8];
-    out[1] = v[1] ^ v[9];
-    out[2] = v[2] ^ v[10];
-    out[3] = v[3] ^ v[11];
-    out[4] = v[4] ^ v[12];
-    out[5] = v[5] ^ v[13];
-    out[6] = v[6] ^ v[14];
-    out[7] = v[7] ^ v[15];
+    out[0] = h[0] ^ v[0] ^ v[8];
+    out[1] = h[1] ^ v[1] ^ v[9];
+    out[2] = h[2] ^ v[2] ^ v[10];
+    out[3] = h[3] ^ v[3] ^ v[11];
+    out[4] = h[4] ^ v[4] ^ v[12];
+    out[5] = h[5] ^ v[5] ^ v[13];
+    out[6] = h[6] ^ v[6] ^ v[14];
+    out[7] = h[7] ^ v[7] ^ v[15];
+}
+// out = F(0, m, 0, 0) (the Merkle shape); message words that are compile-time zeros (a leaf) fold as in the plain form
+template <int IDLE>
+__device__ __forceinline__ void b2_merkle_block_runs(const uint32_t (&m)[16], uint32_t (&out)[8]) {
+    const uint32_t z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    b2_compress_runs<IDLE>(z, m, 0, 0, 0, 0, out);
 }
 #endif
 // idle states of the throughput form, per message shape (A/B knobs of the build: tools/build_variant.sh <name> -DFRIEDA_B2_IDLE_NODE=0x...)
@@ -209,6 +216,18 @@ __device__ __forceinline__ void b2_merkle_block_runs(const uint32_t (&m)[16], ui
 #ifndef FRIEDA_B2_IDLE_LEAF
 #define FRIEDA_B2_IDLE_LEAF 0x333
 #endif
+// the fused last transform pass + tree launch (ntt.hip) runs at 4 waves per SIMD (120 VGPRs), where the optimum differs
+#ifndef FRIEDA_B2_IDLE_NTT_NODE
+#define FRIEDA_B2_IDLE_NTT_NODE FRIEDA_B2_IDLE_NODE
+#endif
+#ifndef FRIEDA_B2_IDLE_NTT_LEAF
+#define FRIEDA_B2_IDLE_NTT_LEAF FRIEDA_B2_IDLE_LEAF
+#endif
+// tree5r in NODE mode (every compression node-shaped, children loaded from memory): the plain form is ahead there (92 vs 100 us for
+// the 2^24 proof's node launches, profiles/r05_idle_states_product_ab.txt); -1 = B2_LAT
+#ifndef FRIEDA_B2_IDLE_T5_NODE
+#define FRIEDA_B2_IDLE_T5_NODE -1
+#endif
 
 // Blake2sMerkleHasher::hash_node for one 16-word block from the zero state: the shape of every node of
 // frieda's trees (leaf = 4 column words + 12 zero words; inner node = left || right).
@@ -217,6 +236,15 @@ FR_HD void b2_merkle_block_lat(const uint32_t (&m)[16], uint32_t (&out)[8]) {  /
     b2_compress(z, m, 0, 0, 0, 0, out);
 }
 // the same for the chip-filling kernels: the throughput form on the device (IDLE: see above), the plain form on the host
+// F(h, m, t, f) for chip-filling launches with a chaining value (the grind): throughput form on the device, plain form on the host
+template <int IDLE>
+FR_HD void b2_compress_tp(const uint32_t (&h)[8], const uint32_t (&m)[16], uint32_t t0, uint32_t t1, uint32_t f0, uint32_t f1, uint32_t (&out)[8]) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(FRIEDA_B2_NO_RUNS)
+    b2_compress_runs<IDLE>(h, m, t0, t1, f0, f1, out);
+#else
+    b2_compress(h, m, t0, t1, f0, f1, out);
+#endif
+}
 // IDLE = B2_LAT selects the plain form (call sites of the latency-bound kernels: one workgroup, or few waves per SIMD, where an idle
 // state is pure delay)
 constexpr int B2_LAT = -1;

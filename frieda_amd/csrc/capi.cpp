@@ -55,10 +55,16 @@ int frieda_ctx_create(int device, void* stream, frieda_ctx** out) {
         }
         ctx->c.own_stream = true;
     }
+    // Two kernels want more LDS than the 64 KB default.  A device (or build) that refuses either keeps every other path: the generic
+    // transform kernel then takes 3 columns per workgroup (51 KB) and small domains take the general path.
     if (k::ntt_opt_in_dynamic_lds() != hipSuccess) {
         (void)hipGetLastError();
-        frieda_ctx_destroy(ctx);
-        return FRIEDA_ERR_HIP;
+        if (ctx->c.tuning.ntt_cpw > 3) ctx->c.tuning.ntt_cpw = 3;
+        ctx->c.err = "note: 68 KB of dynamic LDS refused for the generic transform kernel; 3 columns per workgroup";
+    }
+    if (!k::small_first_opt_in()) {
+        ctx->c.tuning.no_small_fused = true;
+        ctx->c.err = "note: the fused small-domain kernel does not fit this device's LDS; general path for small domains";
     }
     *out = ctx;
     return FRIEDA_OK;
@@ -758,6 +764,14 @@ int frieda_circle_evaluate_fold2(frieda_ctx* ctx, const uint32_t* d_coeffs, uint
     FR_GUARD_BEGIN
     for (int i = 0; i < 4; i++)
         if (alpha0[i] >= P31 || alpha1[i] >= P31) return ctx->c.fail(FRIEDA_ERR_ARG, "alpha coordinates must be canonical M31 values");
+    {  // the fused pass writes the lines while other workgroups still write the evaluation: no two of the four buffers may overlap
+        const uintptr_t b[4] = {reinterpret_cast<uintptr_t>(d_coeffs), reinterpret_cast<uintptr_t>(d_evals), reinterpret_cast<uintptr_t>(d_line1),
+                                reinterpret_cast<uintptr_t>(d_line2)};
+        const size_t len[4] = {(size_t)16 << log_size, (size_t)16 << log_domain, (size_t)16 << (log_domain - 1), (size_t)16 << (log_domain - 2)};
+        for (int i = 0; i < 4; i++)
+            for (int j = i + 1; j < 4; j++)
+                if (b[i] < b[j] + len[j] && b[j] < b[i] + len[i]) return ctx->c.fail(FRIEDA_ERR_ARG, "coefficient, evaluation and line buffers must not overlap");
+    }
     FR_HIP(&ctx->c, hipSetDevice(ctx->c.device));
     TwiddleSet ts;
     int rc = ctx->c.get_twiddles(log_domain, ts);
@@ -768,8 +782,10 @@ int frieda_circle_evaluate_fold2(frieda_ctx* ctx, const uint32_t* d_coeffs, uint
     fs.accumulate = accumulate_line1 != 0;
     fs.line1 = d_line1;
     fs.line2 = d_line2;
+    hipError_t fe = hipSuccess;
     (void)k::circle_evaluate_fold2(ctx->c.launch(), d_coeffs, (size_t)1 << log_size, log_size, log_domain, ts.d_tw, ts.ds, d_evals,
-                                   (size_t)1 << log_domain, fs);
+                                   (size_t)1 << log_domain, fs, &fe);
+    FR_HIP(&ctx->c, fe);
     FR_HIP(&ctx->c, hipGetLastError());
     return FRIEDA_OK;
     FR_GUARD_END(ctx)

@@ -3,7 +3,8 @@
 // The commit / prove path is bound by the integer VALU rate of Blake2s.  bench.py measures that ceiling in the same
 // process, on the same device, right after the timed run, instead of quoting a number taken on another box (devices differ by a few
 // per cent), and reads the clock inside the kernel with it: the chip holds ~2.39 GHz under this load (MI355X), so the ceiling is the
-// instruction mix (~3950 SIMD cycles per wave-compression), not a lowered clock: every lane chains compressions on register-resident data
+// instruction stream (~3250 / ~3480 SIMD cycles per leaf / node wave-compression in the throughput form of blake2s.h, which is what this
+// kernel runs — the same code as the tree kernels), not a lowered clock: every lane chains compressions on register-resident data
 // (no memory traffic), 8 workgroups per CU, once with the 4-word message of a leaf (12 zero words constant-folded) and once with
 // the full 16-word message of an inner node.  (tools/blake2s_rate.hip is the stand-alone sweep over occupancies.)
 #include <hip/hip_runtime.h>

@@ -141,7 +141,7 @@ struct EncodeFoldSink {
     uint32_t* line2;
 };
 bool circle_evaluate_fold2(const Launch& L_, const uint32_t* d_coef, size_t coef_stride, uint32_t L, uint32_t n, const uint32_t* d_tw,
-                           DomainScalars ds, uint32_t* d_out, size_t out_stride, const EncodeFoldSink& fs);
+                           DomainScalars ds, uint32_t* d_out, size_t out_stride, const EncodeFoldSink& fs, hipError_t* err);
 uint32_t circle_evaluate_into_tree(const Launch& L_, const uint32_t* d_coef, size_t coef_stride, uint32_t ncols, uint32_t L, uint32_t n,
                                const uint32_t* d_tw, DomainScalars ds, uint32_t* d_out, size_t out_stride, const EncodeTreeSink* sink);
 
@@ -262,6 +262,9 @@ void tree_first_layer(const Launch& L, const uint32_t* cols, size_t stride, uint
 // small domains (2^8 .. 2^15 points, <= 2^11 coefficients per column: the reference's 1 KiB - 16 KiB bench inputs): unpack + encode +
 // first tree as ONE launch + the top kernel, straight from the blob's bytes (device or page-locked host memory)
 bool small_domain_shape(const Tuning& tn, uint32_t Lc, uint32_t n);
+// per context at creation: checks the device's LDS against the fused small-domain kernel's need (~94 KB per workgroup) and opts the
+// function object in; false = use the general path on this device (Tuning::no_small_fused)
+bool small_first_opt_in();
 void small_encode_and_first_tree(const Launch& L, const uint8_t* d_data, size_t len, size_t data_stride, uint32_t Lc, uint32_t n,
                                  const uint32_t* d_tw, DomainScalars ds, uint32_t* d_eval, size_t eval_stride, uint8_t* d_layers,
                                  uint8_t* d_scratch, uint8_t* d_root, DevTranscript* tr, const DevTranscript* tr_init, size_t tr_init_pitch);

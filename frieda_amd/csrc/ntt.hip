@@ -49,6 +49,113 @@ constexpr uint32_t MID_LOG_W = 4;  // 64-byte contiguous runs in the strided pas
 
 __device__ __forceinline__ uint32_t pad(uint32_t e) { return e + (e >> 4); }
 
+// ---- the four layers of a radix-16 stage on 16 register-resident values, eight butterflies at a time ----
+// Same idea as the hash kernels' throughput form (blake2s.h): the eight independent butterflies of a layer advance together, one
+// arithmetic step at a time, so that the VALU stream is made of runs of one rate class (v_mad_u64_u32 / v_alignbit / v_min: slow;
+// v_and / v_add / v_sub: fast) with a few idle issue states (s_nop) between the runs, pinned by data flow.  FRIEDA_NTT_IDLE = 0xAB:
+// idle states after a slow run (A) and after a fast run (B); 0 = the plain form (butterfly by butterfly, the scheduler's order).
+#ifndef FRIEDA_NTT_IDLE
+#define FRIEDA_NTT_IDLE 0x33
+#endif
+#ifndef FRIEDA_NTT_GROUP
+#define FRIEDA_NTT_GROUP 8  // butterflies advanced together (8 = a whole layer; 4 halves the temporaries)
+#endif
+#ifndef FRIEDA_NTT_GROUP_FUSED
+#define FRIEDA_NTT_GROUP_FUSED 4  // in the kernels that keep all four columns in registers (120+ VGPRs)
+#endif
+template <int N, int G>
+__device__ __forceinline__ void ntt_pin(uint32_t (&a)[G]) {
+    static_assert(N >= 0 && N <= 5 && (G == 4 || G == 8), "idle states 0 .. 5, groups of 4 or 8");
+#define FR_PIN_OPS4 "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3])
+#define FR_PIN_OPS8 "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7])
+    if constexpr (G == 8) {
+        if constexpr (N == 1) asm volatile("" : FR_PIN_OPS8);
+        if constexpr (N == 2) asm volatile("s_nop 0" : FR_PIN_OPS8);
+        if constexpr (N == 3) asm volatile("s_nop 1" : FR_PIN_OPS8);
+        if constexpr (N == 4) asm volatile("s_nop 2" : FR_PIN_OPS8);
+        if constexpr (N == 5) asm volatile("s_nop 3" : FR_PIN_OPS8);
+    } else {
+        if constexpr (N == 1) asm volatile("" : FR_PIN_OPS4);
+        if constexpr (N == 2) asm volatile("s_nop 0" : FR_PIN_OPS4);
+        if constexpr (N == 3) asm volatile("s_nop 1" : FR_PIN_OPS4);
+        if constexpr (N == 4) asm volatile("s_nop 2" : FR_PIN_OPS4);
+        if constexpr (N == 5) asm volatile("s_nop 3" : FR_PIN_OPS4);
+    }
+#undef FR_PIN_OPS4
+#undef FR_PIN_OPS8
+}
+// G butterflies (k0 .. k0 + G - 1 of the layer's eight) of layer Q (0 = the stage's top bit): x[r], x[r | bit] with twiddle
+// tw[(1 << Q) - 1 + (r >> (bit + 1))]
+template <int IDLE, int Q, int G, int K0, typename TW>
+__device__ __forceinline__ void radix16_group(uint32_t (&x)[16], const TW& tw) {
+    constexpr int bit = 3 - Q, NA = (IDLE >> 4) & 15, NB = IDLE & 15;
+    // the eight (low, high) index pairs of a layer
+    constexpr int LOW[4][8] = {{0, 1, 2, 3, 4, 5, 6, 7}, {0, 1, 2, 3, 8, 9, 10, 11}, {0, 1, 4, 5, 8, 9, 12, 13}, {0, 2, 4, 6, 8, 10, 12, 14}};
+    uint32_t hi[G], lo[G], d[G];
+#pragma unroll
+    for (int k = 0; k < G; k++) {
+        const int r = LOW[Q][K0 + k];
+        const uint64_t p = (uint64_t)x[r | (1 << bit)] * tw[(1 << Q) - 1 + (r >> (bit + 1))];
+        hi[k] = (uint32_t)(p >> 31);
+        lo[k] = (uint32_t)p;
+    }
+    ntt_pin<NA, G>(hi);  // (lo follows from the same multiply: pinning one of the two results orders both)
+#pragma unroll
+    for (int k = 0; k < G; k++) {
+        lo[k] &= P31;
+        lo[k] += hi[k];
+        hi[k] = lo[k] - P31;
+    }
+    ntt_pin<NB, G>(hi);
+#pragma unroll
+    for (int k = 0; k < G; k++) lo[k] = umin32(lo[k], hi[k]);  // t = x_high * tw, canonical
+    ntt_pin<NA, G>(lo);
+#pragma unroll
+    for (int k = 0; k < G; k++) {
+        const int r = LOW[Q][K0 + k];
+        const uint32_t w = x[r];
+        d[k] = w - lo[k];
+        x[r] = w + lo[k];
+        hi[k] = d[k] + P31;
+        lo[k] = x[r] - P31;
+    }
+    ntt_pin<NB, G>(lo);
+#pragma unroll
+    for (int k = 0; k < G; k++) {
+        const int r = LOW[Q][K0 + k];
+        x[r] = umin32(x[r], lo[k]);
+        x[r | (1 << bit)] = umin32(d[k], hi[k]);
+    }
+}
+template <int IDLE, int Q, int G, typename TW>
+__device__ __forceinline__ void radix16_layer(uint32_t (&x)[16], const TW& tw) {
+    radix16_group<IDLE, Q, G, 0>(x, tw);
+    if constexpr (G == 4) radix16_group<IDLE, Q, G, 4>(x, tw);
+}
+template <int G = FRIEDA_NTT_GROUP, typename TW>
+__device__ __forceinline__ void radix16_stage(uint32_t (&x)[16], const TW& tw) {
+    if constexpr (FRIEDA_NTT_IDLE != 0) {
+        radix16_layer<FRIEDA_NTT_IDLE, 0, G>(x, tw);
+        radix16_layer<FRIEDA_NTT_IDLE, 1, G>(x, tw);
+        radix16_layer<FRIEDA_NTT_IDLE, 2, G>(x, tw);
+        radix16_layer<FRIEDA_NTT_IDLE, 3, G>(x, tw);
+    } else {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int bit = 3 - q;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                if (r & (1 << bit)) continue;
+                const int u = r >> (bit + 1);
+                const uint32_t t = m31_mul(x[r | (1 << bit)], tw[(1 << q) - 1 + u]);
+                const uint32_t v = x[r];
+                x[r] = m31_add(v, t);
+                x[r | (1 << bit)] = m31_sub(v, t);
+            }
+        }
+    }
+}
+
 // circle-layer twiddle Y[h] from the first line level: pairs (x, y) -> [y, -y, -x, x]
 __device__ __forceinline__ uint32_t circle_twiddle(const uint32_t* __restrict__ tw, uint32_t n, uint32_t h, uint32_t init_y) {
     if (n < 3) return (h & 1u) ? m31_neg(init_y) : init_y;  // n == 1: [y]; n == 2: [y, -y]
@@ -291,19 +398,7 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_tile12_kernel(NttArgs a) {
             uint32_t* col = lds + pbase[s];
 #pragma unroll
             for (int r = 0; r < 16; r++) x[r] = col[pad((uint32_t)r << lo)];
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const int bit = 3 - q;
-#pragma unroll
-                for (int r = 0; r < 16; r++) {
-                    if (r & (1 << bit)) continue;
-                    const int u = r >> (bit + 1);
-                    const uint32_t t = m31_mul(x[r | (1 << bit)], twd[s][(1 << q) - 1 + u]);
-                    const uint32_t v = x[r];
-                    x[r] = m31_add(v, t);
-                    x[r | (1 << bit)] = m31_sub(v, t);
-                }
-            }
+            radix16_stage(x, twd[s]);
             if (s + 1 < NS || LOG_W != 0) {
 #pragma unroll
                 for (int r = 0; r < 16; r++) col[pad((uint32_t)r << lo)] = x[r];
@@ -418,19 +513,7 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_tile12_rep_kernel(NttArgs a) 
                 uint32_t* col = lds + pbase[s];
 #pragma unroll
                 for (int r = 0; r < 16; r++) x[r] = col[pad((uint32_t)r << lo)];
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    const int bit = 3 - q;
-#pragma unroll
-                    for (int r = 0; r < 16; r++) {
-                        if (r & (1 << bit)) continue;
-                        const int u = r >> (bit + 1);
-                        const uint32_t t = m31_mul(x[r | (1 << bit)], twd[s][(1 << q) - 1 + u]);
-                        const uint32_t v = x[r];
-                        x[r] = m31_add(v, t);
-                        x[r | (1 << bit)] = m31_sub(v, t);
-                    }
-                }
+                radix16_stage(x, twd[s]);
 #pragma unroll
                 for (int r = 0; r < 16; r++) col[pad((uint32_t)r << lo)] = x[r];
                 __syncthreads();
@@ -527,19 +610,7 @@ __device__ __forceinline__ void last_pass_four_columns(const NttArgs& a, uint32_
             uint32_t* x = v[c];
 #pragma unroll
             for (int r = 0; r < 16; r++) x[r] = col[pad((uint32_t)r << lo)];
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const int bit = 3 - q;
-#pragma unroll
-                for (int r = 0; r < 16; r++) {
-                    if (r & (1 << bit)) continue;
-                    const int u = r >> (bit + 1);
-                    const uint32_t t = m31_mul(x[r | (1 << bit)], twd[s][(1 << q) - 1 + u]);
-                    const uint32_t w = x[r];
-                    x[r] = m31_add(w, t);
-                    x[r | (1 << bit)] = m31_sub(w, t);
-                }
-            }
+            radix16_stage<FRIEDA_NTT_GROUP_FUSED>(*reinterpret_cast<uint32_t(*)[16]>(x), twd[s]);
             if (s < 2) {
 #pragma unroll
                 for (int r = 0; r < 16; r++) col[pad((uint32_t)r << lo)] = x[r];
@@ -596,12 +667,12 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_last_tree_kernel(NttTreeArgs 
         auto half_ab = [&](auto half_c) {
             constexpr int half = decltype(half_c)::value;
             uint32_t ha[2][8];
-            leaf_hash(v[0][2 * half], v[1][2 * half], v[2][2 * half], v[3][2 * half], ha[0]);
-            leaf_hash(v[0][2 * half + 1], v[1][2 * half + 1], v[2][2 * half + 1], v[3][2 * half + 1], ha[1]);
+            leaf_hash<FRIEDA_B2_IDLE_NTT_LEAF>(v[0][2 * half], v[1][2 * half], v[2][2 * half], v[3][2 * half], ha[0]);
+            leaf_hash<FRIEDA_B2_IDLE_NTT_LEAF>(v[0][2 * half + 1], v[1][2 * half + 1], v[2][2 * half + 1], v[3][2 * half + 1], ha[1]);
             uint32_t mm[16];
 #pragma unroll
             for (int w = 0; w < 8; w++) mm[w] = ha[0][w], mm[8 + w] = ha[1][w];
-            b2_merkle_block(mm, hb[half]);
+            b2_merkle_block<FRIEDA_B2_IDLE_NTT_NODE>(mm, hb[half]);
         };
         half_ab(std::integral_constant<int, 0>{});
         half_ab(std::integral_constant<int, 1>{});
@@ -614,7 +685,7 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_last_tree_kernel(NttTreeArgs 
             uint32_t mm[16];
 #pragma unroll
             for (int w = 0; w < 8; w++) mm[w] = hb[0][w], mm[8 + w] = hb[1][w];
-            b2_merkle_block(mm, hc);
+            b2_merkle_block<FRIEDA_B2_IDLE_NTT_NODE>(mm, hc);
         }
         if (STORE_ALL) store_hash(out_c, l0 >> 2, hc);
         if ((it & 1) == 0) {
@@ -624,7 +695,7 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_last_tree_kernel(NttTreeArgs 
             uint32_t hd[8], mm[16];
 #pragma unroll
             for (int w = 0; w < 8; w++) mm[w] = hprev[w], mm[8 + w] = hc[w];
-            b2_merkle_block(mm, hd);
+            b2_merkle_block<FRIEDA_B2_IDLE_NTT_NODE>(mm, hd);
             if (STORE_ALL) store_hash(out_d, l0 >> 3, hd);
             if (it == 1) {
 #pragma unroll
@@ -633,7 +704,7 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_last_tree_kernel(NttTreeArgs 
                 uint32_t he[8];
 #pragma unroll
                 for (int w = 0; w < 8; w++) mm[w] = hdprev[w], mm[8 + w] = hd[w];
-                b2_merkle_block(mm, he);
+                b2_merkle_block<FRIEDA_B2_IDLE_NTT_NODE>(mm, he);
                 if (STORE_ALL || REG_ONLY) store_hash(out_e, l0 >> 4, he);
                 if (!REG_ONLY) lds_put(RC, 256 + 4, g, he);
             }
@@ -652,7 +723,7 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_last_tree_kernel(NttTreeArgs 
     if (g < 128) {
         uint32_t mm[16], h[8];
         lds_children(RC, 256 + 4, g, mm);
-        b2_merkle_block(mm, h);
+        b2_merkle_block<FRIEDA_B2_IDLE_NTT_NODE>(mm, h);
         if (STORE_ALL) store_hash(layers + layer_off(m, m - 5), (wg_e >> 1) + g, h);
         lds_put(RD, 128 + 4, g, h);
     }
@@ -660,7 +731,7 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_last_tree_kernel(NttTreeArgs 
     if (g < 64) {
         uint32_t mm[16], h[8];
         lds_children(RD, 128 + 4, g, mm);
-        b2_merkle_block(mm, h);
+        b2_merkle_block<FRIEDA_B2_IDLE_NTT_NODE>(mm, h);
         uint8_t* dst = STORE_ALL ? layers + layer_off(m, m - 6) : A.last_out + blockIdx.z * A.bstride;
         store_hash(dst, (wg_e >> 2) + g, h);
         FR_CLOCK_END(g_clock_ntt_last_tree, h[0])
@@ -793,10 +864,14 @@ hipError_t ntt_opt_in_dynamic_lds() {
 }
 
 bool circle_evaluate_fold2(const Launch& L_, const uint32_t* d_coef, size_t coef_stride, uint32_t L, uint32_t n, const uint32_t* d_tw,
-                           DomainScalars ds, uint32_t* d_out, size_t out_stride, const EncodeFoldSink& fs) {
+                           DomainScalars ds, uint32_t* d_out, size_t out_stride, const EncodeFoldSink& fs, hipError_t* err) {
+    *err = hipSuccess;
     if (evaluate_plan(L_, d_coef, coef_stride, 4, L, n, n, d_tw, ds, d_out, out_stride, nullptr, &fs)) return true;
     // shapes the fused pass does not take: the three operations as they are
-    if (!fs.accumulate) (void)hipMemsetAsync(fs.line1, 0, sizeof(uint32_t) * ((size_t)4 << (n - 1)), L_.stream);
+    if (!fs.accumulate) {  // (a failed memset would have the fold accumulate onto garbage)
+        *err = hipMemsetAsync(fs.line1, 0, sizeof(uint32_t) * ((size_t)4 << (n - 1)), L_.stream);
+        if (*err != hipSuccess) return false;
+    }
     fold_circle_into_line(L_, fs.line1, (size_t)1 << (n - 1), d_out, out_stride, n, fs.itw, ds, Alpha{{fs.alpha0[0], fs.alpha0[1], fs.alpha0[2], fs.alpha0[3]}});
     fold_line(L_, fs.line1, (size_t)1 << (n - 1), n - 1, n, fs.itw, ds, Alpha{{fs.alpha1[0], fs.alpha1[1], fs.alpha1[2], fs.alpha1[3]}}, fs.line2,
               (size_t)1 << (n - 2));

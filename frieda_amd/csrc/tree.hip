@@ -254,12 +254,12 @@ __global__ __launch_bounds__(T5_THREADS) void tree5r_kernel(TreeArgs a) {
             {
                 uint32_t m[16];
                 load_children(a.children, g, m);
-                b2_merkle_block(m, ha[0]);
+                b2_merkle_block<MODE == T_NODE ? FRIEDA_B2_IDLE_T5_NODE : FRIEDA_B2_IDLE_NODE>(m, ha[0]);
             }
             {
                 uint32_t m[16];
                 load_children(a.children, g + 1, m);
-                b2_merkle_block(m, ha[1]);
+                b2_merkle_block<MODE == T_NODE ? FRIEDA_B2_IDLE_T5_NODE : FRIEDA_B2_IDLE_NODE>(m, ha[1]);
             }
         } else if (half == 0) {
             leaf_hash(lc0.x, lc1.x, lc2.x, lc3.x, ha[0]);
@@ -275,7 +275,7 @@ __global__ __launch_bounds__(T5_THREADS) void tree5r_kernel(TreeArgs a) {
         uint32_t m[16];
 #pragma unroll
         for (int w = 0; w < 8; w++) m[w] = ha[0][w], m[8 + w] = ha[1][w];
-        b2_merkle_block(m, hb[half]);
+        b2_merkle_block<MODE == T_NODE ? FRIEDA_B2_IDLE_T5_NODE : FRIEDA_B2_IDLE_NODE>(m, hb[half]);
     };
     half_ab(std::integral_constant<int, 0>{});
     half_ab(std::integral_constant<int, 1>{});
@@ -288,7 +288,7 @@ __global__ __launch_bounds__(T5_THREADS) void tree5r_kernel(TreeArgs a) {
         uint32_t m[16];
 #pragma unroll
         for (int w = 0; w < 8; w++) m[w] = hb[0][w], m[8 + w] = hb[1][w];
-        b2_merkle_block(m, hc);
+        b2_merkle_block<MODE == T_NODE ? FRIEDA_B2_IDLE_T5_NODE : FRIEDA_B2_IDLE_NODE>(m, hc);
     }
     if (out_c) store_hash(out_c, g0 >> 2, hc);
     if (REG_ONLY) return;
@@ -297,7 +297,7 @@ __global__ __launch_bounds__(T5_THREADS) void tree5r_kernel(TreeArgs a) {
     if (t < 128) {
         uint32_t m[16], h[8];
         lds_children(RC, 256 + 4, t, m);
-        b2_merkle_block(m, h);
+        b2_merkle_block<MODE == T_NODE ? FRIEDA_B2_IDLE_T5_NODE : FRIEDA_B2_IDLE_NODE>(m, h);
         if (out_d) store_hash(out_d, (wg_base >> 3) + t, h);
         lds_put(RD, 128 + 4, t, h);
     }
@@ -305,7 +305,7 @@ __global__ __launch_bounds__(T5_THREADS) void tree5r_kernel(TreeArgs a) {
     if (t < 64) {
         uint32_t m[16], h[8];
         lds_children(RD, 128 + 4, t, m);
-        b2_merkle_block(m, h);
+        b2_merkle_block<MODE == T_NODE ? FRIEDA_B2_IDLE_T5_NODE : FRIEDA_B2_IDLE_NODE>(m, h);
         store_hash(out_e, (wg_base >> 4) + t, h);
         FR_CLOCK_END(g_clock_tree5r, h[0])
     }
@@ -1132,7 +1132,7 @@ __global__ __launch_bounds__(256) void grind_dev_kernel(GrindArgs a) {
             if (__hip_atomic_load(&tr->nonce, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < nonce) break;
             const uint32_t m[16] = {(uint32_t)nonce, (uint32_t)(nonce >> 32), 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
             uint32_t r[8];
-            b2_compress(h, m, 0, 0, 0, 0, r);
+            b2_compress_tp<FRIEDA_B2_IDLE_LEAF>(h, m, 0, 0, 0, 0, r);  // (a chip-filling launch: the throughput form, blake2s.h)
             uint32_t tz;
             if (r[0])
                 tz = __ffs(r[0]) - 1;
@@ -1328,6 +1328,30 @@ void encode_and_first_tree(const Launch& L, const uint32_t* d_coef, size_t coef_
     finish_tree(L, a, n, cur, d_layers ? d_layers + merkle_layer_offset(n, cur) : s0, s0, s1, d_root, tr, tr_init, tr_init_pitch);
 }
 
+// The fused small-domain kernel needs more LDS than a 64 KB part has: its dynamic block (blob + spare word + coefficients) is
+// (15 << L) / 4 + 4 + (4 << L) words = 63.5 KB at L = SMALL_MAX_LOG_COEF, on top of ~31 KB of static arrays (V, RA, QQ): ~94 KB per
+// workgroup, one workgroup per CU of a 160 KB gfx950 CU.  Called once per context at creation (the attribute belongs to the current
+// device's function object): false = this device cannot run it, the caller switches the context to the general path.
+bool small_first_opt_in() {
+    int dev = 0, lds_max = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    const size_t dyn = ((((size_t)15 << SMALL_MAX_LOG_COEF) + 3) / 4 + 4 + ((size_t)4 << SMALL_MAX_LOG_COEF)) * sizeof(uint32_t);
+    hipFuncAttributes fa{};
+    if (hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(small_first_kernel)) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    if (fa.sharedSizeBytes + dyn > (size_t)lds_max) return false;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(small_first_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    return true;
+}
+
 bool small_domain_shape(const Tuning& tn, uint32_t Lc, uint32_t n) {
     return !tn.no_small_fused /* A/B knob: the general path for every size */ && n >= SMALL_MIN_LOG_DOMAIN && n <= SMALL_MAX_LOG_DOMAIN && Lc <= SMALL_MAX_LOG_COEF && Lc <= n;
 }
@@ -1358,7 +1382,7 @@ void small_encode_and_first_tree(const Launch& L, const uint8_t* d_data, size_t 
     {
         // algorithmic bytes: the blob + the encode (16 N (1 + 2^-B)) + leaves (16 B in, 32 B out) + 8 node levels
         Scope scope(L, "small_first", (double)len + 4.0 * 4.0 * (N + (double)((size_t)1 << Lc)) + 48.0 * N + node_levels_bytes(n - 1, T9_LEVELS - 1));
-        const size_t lds_words = (((size_t)15 << Lc) + 3) / 4 + 4 + ((size_t)4 << Lc);  // blob + spare word, coefficients: <= 62 KB
+        const size_t lds_words = (((size_t)15 << Lc) + 3) / 4 + 4 + ((size_t)4 << Lc);  // blob + spare word, coefficients: <= 63.5 KB (+ ~31 KB static: small_first_opt_in)
         small_first_kernel<<<dim3(1u << (n - 8), L.batch), 256, lds_words * sizeof(uint32_t), L.stream>>>(a);
     }
     const uint32_t cur = n - (T9_LEVELS - 1);

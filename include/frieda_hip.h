@@ -99,8 +99,9 @@ int frieda_ctx_blake2s_ceiling(frieda_ctx* ctx, double* leaf_per_s, double* node
 /* the same after ~0.25 s of that load per shape (~0.5 s in all), with the clock the chip holds under it read inside the kernel (shader-clock counter against
  * the 100 MHz wall-clock counter, median over the workgroups): out = {leaf compressions/s, node compressions/s, leaf clock GHz,
  * leaf SIMD cycles per wave-compression, node clock GHz, node SIMD cycles per wave-compression}.  On MI355X the clock stays at
- * ~2.4 GHz under this load and a compression costs ~3950 cycles per wave (profiles/r03_clock_probe_mi355x.txt): the ceiling is
- * the instruction mix, not a lowered clock. */
+ * ~2.4 GHz under this load (profiles/r03_clock_probe_mi355x.txt) and a compression costs ~3250 (leaf) / ~3480 (node) cycles per wave
+ * in the library's throughput form (runs of one VALU rate class with idle issue states between them; ~3950 for the scheduler's own
+ * fine interleave, profiles/r05_blake2s_idle_sweep.txt): the ceiling is the instruction stream, not a lowered clock. */
 int frieda_ctx_blake2s_ceiling_ex(frieda_ctx* ctx, double out[6]);
 /* diagnostic: the Fiat-Shamir transcript of the last finished generate_proof on this ctx (blob 0 of a batch) — what
  * FriProver::commit derives between src/proof.rs:52 and :58 and the Proof does not carry: per FRI layer (first, then inner)
@@ -372,7 +373,8 @@ int frieda_fold_line(frieda_ctx* ctx, const uint32_t* d_src, uint32_t line_log, 
  * (log_size >= 12, 16-byte aligned buffers), as the three operations otherwise; the results are those of the three separate calls.
  * For callers that hold both folding challenges: a verifier re-executing a round, FRI with fold_step 2, BASELINE configs[1].  The
  * prover of src/proof.rs draws alpha1 only after committing to line 1 (its fused fold + tree launches are inside
- * frieda_commit_and_generate_proof). */
+ * frieda_commit_and_generate_proof).  The four buffers must not overlap (FRIEDA_ERR_ARG): the one-pass form writes the lines while
+ * other workgroups are still writing the evaluation. */
 int frieda_circle_evaluate_fold2(frieda_ctx* ctx, const uint32_t* d_coeffs, uint32_t log_size, uint32_t log_domain, uint32_t* d_evals,
                                  const uint32_t alpha0[4], int accumulate_line1, uint32_t* d_line1, const uint32_t alpha1[4],
                                  uint32_t* d_line2);

@@ -266,6 +266,16 @@ def test_circle_evaluate_fold2_rejects_bad_arguments(gpu_ctx):
     assert L_.frieda_circle_evaluate_fold2(gpu_ctx._h, d.ptr, 5, 4, d.ptr, good.ctypes.data, 0, d.ptr, good.ctypes.data, d.ptr) == frieda_amd._lib.ERR_ARG
     assert L_.frieda_circle_evaluate_fold2(gpu_ctx._h, d.ptr, 2, 4, d.ptr, bad.ctypes.data, 0, d.ptr, good.ctypes.data, d.ptr) == frieda_amd._lib.ERR_ARG
     assert L_.frieda_circle_evaluate_fold2(gpu_ctx._h, None, 2, 4, d.ptr, good.ctypes.data, 0, d.ptr, good.ctypes.data, d.ptr) == frieda_amd._lib.ERR_ARG
+    # overlapping buffers (the one-pass form writes the lines while the evaluation is still being written): coefficients 4 x 2^2 words
+    # at 0, evaluation 4 x 2^4 words at 64 B, line 1 at 320 B, line 2 at 448 B are disjoint; any shift into a neighbour is refused
+    base = d.ptr.value
+    ok = (base, base + 64, base + 320, base + 448)
+    assert L_.frieda_circle_evaluate_fold2(gpu_ctx._h, ok[0], 2, 4, ok[1], good.ctypes.data, 0, ok[2], good.ctypes.data, ok[3]) == frieda_amd._lib.OK
+    for bad_set in ((base, base + 48, base + 320, base + 448), (base, base + 64, base + 316, base + 448), (base, base + 64, base + 320, base + 444),
+                    (base, base + 64, base + 320, base + 320)):
+        assert L_.frieda_circle_evaluate_fold2(gpu_ctx._h, bad_set[0], 2, 4, bad_set[1], good.ctypes.data, 0, bad_set[2], good.ctypes.data,
+                                               bad_set[3]) == frieda_amd._lib.ERR_ARG
+    gpu_ctx.synchronize()
 
 
 # ------------------------------------------------------------------------------------------------

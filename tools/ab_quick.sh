@@ -8,7 +8,7 @@ try:
     d=json.load(open("gpurun_out/abq_$tag.json"))
     ks={k["name"]:round(k["ms_per_step"]*1e3,1) for k in d["path"]["kernels"]}
     v=d.get("roofline_valu") or []
-    print("$tag", "ms/step", round(d["ms_per_step"],4), ks, [ (x.get("kernel"), round(x.get("frac_of_ceiling",0),3)) for x in v] if isinstance(v,list) else "")
+    print("$tag", "ms/step", round(d["ms_per_step"],4), ks, [ (x.get("kernel"), round(x.get("frac",0),3)) for x in v] if isinstance(v,list) else "")
 except Exception as e:
     print("$tag ERR", e); print(open("gpurun_out/abq_$tag.err").read()[-1500:])
 PY
