@@ -85,10 +85,10 @@ def traffic_from_profiles(kernel, n, workload):
     come from."""
     if n != 24:
         return None, f"none: the committed PMC passes were taken on the 2^24 domain, this run is 2^{n}", None
-    for name in ("r04_prove24_traffic.json", "r03_prove24_traffic.json", "r02_prove24_traffic.json", "r01_prove24_traffic.json"):
-        path = os.path.join(ROOT, "profiles", name)
-        if not os.path.exists(path):
-            continue
+    import glob
+
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_prove24_traffic.json")), reverse=True):  # newest round first
+        name = os.path.basename(path)
         try:
             doc = json.load(open(path))
             val = doc["kernels"][kernel]["traffic_bytes_per_launch"]

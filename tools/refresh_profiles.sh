@@ -14,8 +14,8 @@ export TMPDIR=/tmp
 ONE="--no-cpu-baseline --no-by-config --no-end-to-end --no-reconstruct --batch 1 --in-flight 1 --batch-extra 0 --sequential-extra 0"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 bench.py --steps 2 --warmup 1 $ONE > /dev/null 2> $OUT/pmc_fetch_err.txt
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 bench.py --steps 2 --warmup 1 $ONE > /dev/null 2> $OUT/pmc_write_err.txt
-# the same two passes in the measured loop's own mode (4 blobs per call, 2 calls in flight): launches cover 4 blobs each
-BAT="--only-measured-loop"
+# the same two passes in the measured loop's mode with 4 blobs per call, 2 calls in flight: launches cover 4 blobs each
+BAT="--only-measured-loop --batch 4"  # (4 blobs per launch: what tools/traffic_from_pmc.py divides the batched figures by; the default policy gives 5 at 2^24)
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_b -- python3 bench.py --steps 8 --warmup 0 $BAT > /dev/null 2> $OUT/pmc_fetch_b_err.txt
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_b -- python3 bench.py --steps 8 --warmup 0 $BAT > /dev/null 2> $OUT/pmc_write_b_err.txt
 python tools/traffic_from_pmc.py $OUT/pmc_fetch $OUT/pmc_write $OUT/${TAG}_prove24_traffic.json "$COMMIT" $OUT/pmc_fetch_b $OUT/pmc_write_b

@@ -119,7 +119,7 @@ def main():
     if len(sys.argv) > 6:  # second pair of passes: the measured loop's own mode (4 blobs per launch, 2 calls in flight)
         fb, fbraw, fbc = collect(sys.argv[5], True)
         wb, _, wbc = collect(sys.argv[6], False)
-        res["batched"] = {"mode": "the measured loop (bench.py default: 4 blobs per call, 2 calls in flight): a launch covers 4 blobs",
+        res["batched"] = {"mode": "the measured loop with 4 blobs per call, 2 calls in flight (bench.py --only-measured-loop --batch 4): a launch covers 4 blobs",
                           "blobs_per_launch": 4, "kernels": table(fb, fbraw, fbc, wb, wbc)}
     json.dump(res, open(out, "w"), indent=1)
     for k, v in res["kernels"].items():
