@@ -420,6 +420,42 @@ size_t workspace_bytes_per_blob(size_t len, uint32_t log_blowup, uint32_t log_la
     return plan.off;
 }
 
+// ---- batch policy (host.h) ----
+uint64_t batch_budget_bytes(const k::Tuning& t) {
+    if (t.batch_budget_mb) return (uint64_t)t.batch_budget_mb << 20;
+    // the measured optimum of the headline size, stated in workspace bytes so that it carries over to every other size: five proofs
+    // of a 2^24 domain per call (15 MiB blobs: 2^22 felts -> 2^20 coefficients per column, blowup 2^4), ~13.6 GB
+    static const uint64_t five_headline = 5 * (uint64_t)workspace_bytes_per_blob((size_t)15 << 20, 4, 0, true, true);
+    return five_headline;
+}
+
+uint32_t batch_per_call(const k::Tuning& t, size_t ws_per_blob, uint32_t count, uint32_t in_flight) {
+    if (count == 0) return 1;
+    if (in_flight == 0) in_flight = 1;
+    uint64_t per = ws_per_blob ? batch_budget_bytes(t) / ws_per_blob : 1;
+    const uint64_t ways = (uint64_t)std::max<uint32_t>(1, t.batch_calls_per_ctx) * in_flight;
+    const uint64_t spread = (count + ways - 1) / ways;  // every context gets its calls
+    per = std::min<uint64_t>(per, spread);
+    per = std::min<uint64_t>(per, 65535);  // the batched entry points' own limit
+    return (uint32_t)std::max<uint64_t>(per, 1);
+}
+
+void batch_cut(uint32_t count, uint32_t per_call, uint32_t in_flight, std::vector<uint32_t>& calls) {
+    calls.clear();
+    if (count == 0) return;
+    if (per_call == 0) per_call = 1;
+    if (in_flight == 0) in_flight = 1;
+    // the number of calls is a multiple of the calls in flight: an odd call out would run alone on the chip, its latency chain and
+    // its launches' ramps un-overlapped (20 blobs: 4 x 5, not 5 x 4); no call exceeds per_call (the budget is a ceiling)
+    const uint64_t round = (uint64_t)per_call * in_flight;
+    uint64_t n = (uint64_t)in_flight * ((count + round - 1) / round);
+    n = std::min<uint64_t>(n, count);
+    const uint32_t base = (uint32_t)(count / n), extra = (uint32_t)(count % n);
+    calls.assign((size_t)n, base);
+    for (uint32_t i = 0; i < extra; i++) calls[i] = base + 1;
+}
+
+
 static double ms_since(std::chrono::steady_clock::time_point t0) {
     return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
 }

@@ -34,7 +34,11 @@ def fuzz_binary(tmp_path_factory):
            "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath,/opt/rocm/lib"]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
-        pytest.skip("host sanitizer build unavailable: " + r.stderr[-400:])
+        # only a missing sanitizer runtime is a reason to skip; a source that no longer builds or links on the host is a failure
+        # (round 5: a new cross-file reference in context.cpp silently turned this test into a skip)
+        if "asan" in r.stderr.lower() and ("cannot find" in r.stderr or "No such file" in r.stderr):
+            pytest.skip("host sanitizer runtime unavailable: " + r.stderr[-400:])
+        pytest.fail("host sanitizer build failed: " + r.stderr[-1500:])
     return str(exe)
 
 
