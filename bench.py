@@ -10,8 +10,8 @@ n_gpus * 4 * 2^n * steps / wall time, inputs already resident in HBM when the ti
 
 The K timed steps process K DISTINCT blobs per GPU (a stream of blobs, as a data-availability node sees them) through the batched
 entry points (every kernel is launched once per call, so the Fiat-Shamir latency chain is paid once per call), cut into calls by
-the library's own batch policy (`frieda_batch_plan`, include/frieda_hip.h: workspace bytes in flight — 5 blobs per call at the 2^24
-domain, 16+ at 2^22 and below; the number of calls a multiple of `--in-flight`, sizes equal to within one; `--batch B` forces about
+the library's own batch policy (`frieda_batch_plan`, include/frieda_hip.h: workspace bytes in flight — up to 16 blobs per call at the 2^24
+domain, one call per context at 2^22 and below; the number of calls a multiple of `--in-flight`, sizes equal to within one; `--batch B` forces about
 B per call instead, as rounds 1-4 did with B = 4) with `--in-flight` calls in flight (default 2: one context = stream +
 workspace each, so that chain also runs under the chip-filling kernels of the other call).  Results are those of K separate
 calls (tests/test_gpu_parity.py).  Every one of the K timed proofs is verified after the timed region and the K roots must be
@@ -1063,6 +1063,9 @@ def main():
         proof0_image = proof.serialize()
         timed_roots = [r for r, _ in results]
         del results
+        if pipe is not None:  # the measured loop is over: its workspaces (up to 43 GB per context) go back before the extra figures allocate theirs
+            for c in pipe.ctxs:
+                c.release_workspace()
     else:
         ctx.synchronize()
         root = bytes(roots_all[:32].cpu().numpy())

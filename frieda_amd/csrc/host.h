@@ -177,7 +177,7 @@ int commit_batch_finish(Ctx* ctx, uint8_t* out_roots);
 // One implementation for frieda_prove_many / frieda_commit_many (multi.cpp), frieda_batch_plan (callers that drive _begin / _finish
 // themselves: frieda_amd.BatchPipeline, bench.py) and the tests.
 size_t workspace_bytes_per_blob(size_t len, uint32_t log_blowup, uint32_t log_last_layer, bool prove, bool data_on_device);
-uint64_t batch_budget_bytes(const k::Tuning& t);  // FRIEDA_BATCH_BUDGET_MB, or the default: five proofs of a 2^24 domain (blowup 2^4), ~13.6 GB
+uint64_t batch_budget_bytes(const k::Tuning& t);  // FRIEDA_BATCH_BUDGET_MB, or the default: sixteen proofs of a 2^24 domain (blowup 2^4), ~43 GB
 uint32_t batch_per_call(const k::Tuning& t, size_t ws_per_blob, uint32_t count, uint32_t in_flight);
 void batch_cut(uint32_t count, uint32_t per_call, uint32_t in_flight, std::vector<uint32_t>& calls);
 

