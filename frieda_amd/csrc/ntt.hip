@@ -54,6 +54,7 @@ __device__ __forceinline__ uint32_t pad(uint32_t e) { return e + (e >> 4); }
 // arithmetic step at a time, so that the VALU stream is made of runs of one rate class (v_mad_u64_u32 / v_alignbit / v_min: slow;
 // v_and / v_add / v_sub: fast) with a few idle issue states (s_nop) between the runs, pinned by data flow.  FRIEDA_NTT_IDLE = 0xAB:
 // idle states after a slow run (A) and after a fast run (B); 0 = the plain form (butterfly by butterfly, the scheduler's order).
+// The twiddles of these stages are kept DOUBLED in their registers (2 tw mod 2^32 = 2 tw): one instruction fewer per butterfly.
 #ifndef FRIEDA_NTT_IDLE
 #define FRIEDA_NTT_IDLE 0x33
 #endif
@@ -95,15 +96,17 @@ __device__ __forceinline__ void radix16_group(uint32_t (&x)[16], const TW& tw) {
 #pragma unroll
     for (int k = 0; k < G; k++) {
         const int r = LOW[Q][K0 + k];
+        // the twiddle arrives DOUBLED (2 tw < 2^32): x * 2 tw = (x tw >> 31) * 2^32 + 2 (x tw mod 2^31), so the high dword of the
+        // product IS the high part of the Mersenne fold and the low part is one shift away (no 64-bit shift, no mask)
         const uint64_t p = (uint64_t)x[r | (1 << bit)] * tw[(1 << Q) - 1 + (r >> (bit + 1))];
-        hi[k] = (uint32_t)(p >> 31);
+        hi[k] = (uint32_t)(p >> 32);
         lo[k] = (uint32_t)p;
     }
     ntt_pin<NA, G>(hi);  // (lo follows from the same multiply: pinning one of the two results orders both)
 #pragma unroll
     for (int k = 0; k < G; k++) {
-        lo[k] &= P31;
-        lo[k] += hi[k];
+        lo[k] >>= 1;
+        lo[k] += hi[k];  // <= (P - 1) + P
         hi[k] = lo[k] - P31;
     }
     ntt_pin<NB, G>(hi);
@@ -147,7 +150,7 @@ __device__ __forceinline__ void radix16_stage(uint32_t (&x)[16], const TW& tw) {
             for (int r = 0; r < 16; r++) {
                 if (r & (1 << bit)) continue;
                 const int u = r >> (bit + 1);
-                const uint32_t t = m31_mul(x[r | (1 << bit)], tw[(1 << q) - 1 + u]);
+                const uint32_t t = m31_mul(x[r | (1 << bit)], tw[(1 << q) - 1 + u] >> 1);  // (the callers hand doubled twiddles)
                 const uint32_t v = x[r];
                 x[r] = m31_add(v, t);
                 x[r | (1 << bit)] = m31_sub(v, t);
@@ -347,7 +350,7 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_tile12_kernel(NttArgs a) {
             const uint32_t hbase = (hblk << (a.i_hi - i)) | (base >> (b + 1));
             if (LOG_W == 0 && s == NS - 1 && q == 3) {  // i == 0: the circle layer
 #pragma unroll
-                for (int u = 0; u < 8; u++) twd[s][7 + u] = circle_twiddle(a.tw, a.n, hbase + (uint32_t)u, a.init_y);
+                for (int u = 0; u < 8; u++) twd[s][7 + u] = 2u * circle_twiddle(a.tw, a.n, hbase + (uint32_t)u, a.init_y);
             } else {
                 const uint32_t* lvl = a.tw + tw_level_offset_dev(a.n, i - 1) + hbase;
 #pragma unroll
@@ -356,7 +359,7 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_tile12_kernel(NttArgs a) {
                     // stage 0 acts on tile bits 8..11: its twiddle index has no thread-dependent bits (base >> (b+1) == 0 for
                     // g < 256), so the 15 values are workgroup-uniform and live in scalar registers
                     if (s == 0) v = (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
-                    twd[s][(1 << q) - 1 + u] = v;
+                    twd[s][(1 << q) - 1 + u] = 2u * v;  // doubled: radix16_group
                 }
             }
         }
@@ -491,7 +494,7 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_tile12_rep_kernel(NttArgs a) 
                 for (int u = 0; u < (1 << q); u++) {
                     uint32_t v = lvl[u];
                     if (s == 0) v = (uint32_t)__builtin_amdgcn_readfirstlane((int)v);  // workgroup-uniform (ntt_tile12_kernel)
-                    twd[s][(1 << q) - 1 + u] = v;
+                    twd[s][(1 << q) - 1 + u] = 2u * v;  // doubled: radix16_group
                 }
             }
         }
@@ -569,14 +572,14 @@ __device__ __forceinline__ void last_pass_four_columns(const NttArgs& a, uint32_
             const uint32_t hbase = (hblk << (11 - b)) | (base >> (b + 1));
             if (s == 2 && q == 3) {  // layer 0: the circle layer
 #pragma unroll
-                for (int u = 0; u < 8; u++) twd[s][7 + u] = circle_twiddle(a.tw, a.n, hbase + (uint32_t)u, a.init_y);
+                for (int u = 0; u < 8; u++) twd[s][7 + u] = 2u * circle_twiddle(a.tw, a.n, hbase + (uint32_t)u, a.init_y);
             } else {
                 const uint32_t* lvl = a.tw + tw_level_offset_dev(a.n, b - 1) + hbase;
 #pragma unroll
                 for (int u = 0; u < (1 << q); u++) {
                     uint32_t v = lvl[u];
                     if (s == 0) v = (uint32_t)__builtin_amdgcn_readfirstlane((int)v);  // workgroup-uniform (ntt_tile12_kernel)
-                    twd[s][(1 << q) - 1 + u] = v;
+                    twd[s][(1 << q) - 1 + u] = 2u * v;  // doubled: radix16_group
                 }
             }
         }
