@@ -49,6 +49,7 @@ struct Tuning {
     uint32_t test_grind_first_log = 0;   // test hook (frieda_ctx_test_set_grind_first_log): a short first nonce range (0 = off)
     // batch policy (host.h, "batch policy"): workspace bytes a batched call may keep in flight, and the fewest calls a context gets
     uint32_t batch_budget_mb = 0;        // FRIEDA_BATCH_BUDGET_MB: 0 = the default (sixteen proofs of a 2^24 domain, ~43 GB)
+    uint32_t grind_iters = 0;            // FRIEDA_GRIND_ITERS: nonces per lane and claim in the batched grind (window = 256 x this); 0 = by batch size
     uint32_t batch_calls_per_ctx = 1;    // FRIEDA_BATCH_CALLS_PER_CTX: a stream is cut into at least this many calls per context in flight
                                          // (measured, profiles/r05_batch_policy_sweep.txt: 1 beats 2 by 3 % at 2^20 and 30 % at 1 KiB blobs, equal at 2^22 / 2^24)
 };
@@ -281,7 +282,9 @@ void fri_tail(const Launch& L, const uint32_t* src, size_t src_stride, uint32_t 
               const uint32_t* d_itw, DomainScalars ds, uint32_t last_log, uint32_t last, uint32_t n_layers, uint32_t* const* vals,
               uint8_t* const* trees, DevTranscript* tr, uint32_t* d_gnext = nullptr);
 // proof-of-work scan keyed by tr->ch.digest; atomicMin into tr->nonce
-// d_next: L.batch words of scratch (the per-blob window counters; zeroed here unless next_zeroed: fri_tail did it)
+// d_next: L.batch * GRIND_NEXT_STRIDE words of scratch (the per-blob window counters, one 128-byte line each: 2048 workgroups claim
+// windows with atomics, and counters sharing a line serialise in one L2 channel; zeroed here unless next_zeroed: fri_tail did it)
+constexpr uint32_t GRIND_NEXT_STRIDE = 32;
 void grind_dev(const Launch& L, DevTranscript* tr, uint32_t* d_next, uint32_t pow_bits, uint64_t base, uint64_t count,
                bool next_zeroed = false);
 

@@ -552,7 +552,7 @@ int prove_begin_batch(Ctx* ctx, const uint8_t* data, size_t data_stride, size_t 
     const size_t bstride = J.bstride = plan.off;  // a multiple of 256
     plan.off = bstride * count;
     const size_t o_tr = J.o_tr = plan.take(sizeof(DevTranscript) * count);
-    J.o_gnext = plan.take(sizeof(uint32_t) * count);  // grind window counters
+    J.o_gnext = plan.take(sizeof(uint32_t) * k::GRIND_NEXT_STRIDE * count);  // grind window counters, one cache line per blob
     // decommit gather: per layer <= 2 positions per query; hashes <= 2 * queries * log per layer
     J.max_words = (size_t)cfg.n_queries * 4 * (1 + (n_inner + 1)) * count;
     J.max_hashes = (size_t)cfg.n_queries * 2 * (size_t)(n + 1) * (n_inner + 1) * count;

@@ -937,7 +937,7 @@ __global__ __launch_bounds__(WG1_THREADS) void tail_kernel(TailArgs a) {
         chan_prefetch(cr, tr, q);
         s_alpha[t] = tr->alpha[t];
     }
-    if (t == 4 && a.gnext) a.gnext[blockIdx.y] = 0;
+    if (t == 4 && a.gnext) a.gnext[blockIdx.y * GRIND_NEXT_STRIDE] = 0;
 
     const uint32_t* src = reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(a.src) + boff);
     size_t src_stride = a.src_stride;
@@ -1067,15 +1067,20 @@ __global__ __launch_bounds__(WG1_THREADS) void tail_kernel(TailArgs a) {
 // sequential search; blobs that finish early release their workgroups to the others (in a batch the slowest blob needs
 // several times the mean).  Every loop is bounded: a claim consumes one of n_windows * batch windows, a fruitless walk over
 // all blobs ends the workgroup.
-constexpr uint32_t GRIND_WINDOW = 1024;  // nonces per claim: 4 per lane (256-nonce windows were tried: the claim — an atomic and two
-                                         // barriers — then costs as much as the scan, 47 instead of 19 us on the bench blob)
+constexpr uint32_t GRIND_WINDOW = 1024;  // the unit n_windows counts in: 4 nonces per lane (256-nonce windows were tried: the claim — an atomic
+                                         // and two barriers — then costs as much as the scan, 47 instead of 19 us on the bench blob)
+// A claim takes `iters / 4` consecutive units (GrindArgs::iters nonces per lane): in a batch 2048 workgroups claim ~45 M units per second
+// chip-wide, and with every blob's counter in the same cache line and 4 nonces per lane per claim the launch ran at 36 - 50 % of the
+// compression rate (10 blobs of 2^24: 772 us for 12.9 M nonces; 32 blobs of 2^20: 1089 us for 25.2 M).  Round 5: a cache line per
+// counter (GRIND_NEXT_STRIDE: 637 / 397 us) and 8 nonces per lane and claim for batches of 2 .. 15 blobs (337 us).
 
 struct GrindArgs {
     DevTranscript* tr;  // array over the blobs of the batch
     uint32_t* next;     // [batch] next unclaimed window of each blob
     uint32_t pow_bits, batch;
     unsigned long long base;
-    uint32_t n_windows;  // per blob
+    uint32_t n_windows;  // per blob, in units of GRIND_WINDOW nonces
+    uint32_t units;      // units per claim (a lane scans 4 * units nonces of the claim)
 };
 
 __global__ __launch_bounds__(256) void grind_dev_kernel(GrindArgs a) {
@@ -1089,7 +1094,7 @@ __global__ __launch_bounds__(256) void grind_dev_kernel(GrindArgs a) {
                 uint32_t bb = b + t;
                 if (bb >= a.batch) bb -= a.batch;
                 const bool cand = t < a.batch && __hip_atomic_load(&a.tr[bb].nonce, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ~0ull &&
-                                  __hip_atomic_load(&a.next[bb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < a.n_windows;
+                                  __hip_atomic_load(&a.next[bb * GRIND_NEXT_STRIDE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < a.n_windows;
                 const unsigned long long mask = __ballot(cand);
                 if (mask == 0) {
                     const uint32_t adv = a.batch < 64 ? a.batch : 64;
@@ -1102,7 +1107,7 @@ __global__ __launch_bounds__(256) void grind_dev_kernel(GrindArgs a) {
                 uint32_t tb = b + l;
                 if (tb >= a.batch) tb -= a.batch;
                 uint32_t c = 0;
-                if (t == 0) c = atomicAdd(&a.next[tb], 1u);
+                if (t == 0) c = atomicAdd(&a.next[tb * GRIND_NEXT_STRIDE], a.units);
                 c = (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
                 b = tb + 1 == a.batch ? 0 : tb + 1;
                 if (c < a.n_windows) {
@@ -1126,7 +1131,9 @@ __global__ __launch_bounds__(256) void grind_dev_kernel(GrindArgs a) {
 #pragma unroll
         for (int i = 0; i < 8; i++) h[i] = tr->ch.digest[i];
         const unsigned long long first = a.base + (unsigned long long)cw * GRIND_WINDOW + t;
-        for (uint32_t i = 0; i < GRIND_WINDOW / 256; i++) {
+        // (the claim may reach past the range's last unit: only whole units below n_windows are scanned)
+        const uint32_t my_units = a.n_windows - cw < a.units ? a.n_windows - cw : a.units;
+        for (uint32_t i = 0; i < my_units * (GRIND_WINDOW / 256); i++) {
             const unsigned long long nonce = first + 256ull * i;
             // a smaller qualifying nonce is already known: nothing this lane finds from here on can lower the minimum
             if (__hip_atomic_load(&tr->nonce, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < nonce) break;
@@ -1475,7 +1482,13 @@ void grind_dev(const Launch& L, DevTranscript* tr, uint32_t* d_next, uint32_t po
     a.n_windows = nwin > 0xFFFF0000ull ? 0xFFFF0000u : (uint32_t)nwin;
     if (a.n_windows == 0) return;
     Scope scope(L, "grind", 0.0);
-    if (!next_zeroed) (void)hipMemsetAsync(d_next, 0, sizeof(uint32_t) * L.batch, L.stream);
+    if (!next_zeroed) (void)hipMemsetAsync(d_next, 0, sizeof(uint32_t) * GRIND_NEXT_STRIDE * L.batch, L.stream);
+    // nonces per lane and claim: 4 for a lone blob (the windows in flight when the hit arrives are wasted work: latency) and for big
+    // batches (the counters' lines are then spread enough), 8 in between — measured with the counters on their own cache lines:
+    // 10 blobs of 2^24: 772 (round 4) -> 397 (4) / 337 (8) / 408 (16) us for 12.9 M nonces (279 us at the compression ceiling);
+    // 32 blobs of 2^20: 1089 -> 637 / 702 / 714 us for 25.2 M nonces (548 us)
+    const uint32_t iters = L.tune->grind_iters ? L.tune->grind_iters : ((L.batch >= 2 && L.batch < 16) ? 8u : 4u);
+    a.units = iters < 4 ? 1u : iters / 4;
     // workgroups in flight: the chip holds 2048 (8 per CU); a lone blob gets no more than cover about half the expected search
     // (2^pow_bits nonces), so that the windows in flight when the first hit arrives are not mostly beyond it
     uint64_t want = (((uint64_t)1 << (pow_bits > 40 ? 40 : pow_bits)) / 2 / GRIND_WINDOW) * L.batch;
