@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """stream_ab.py — A/B of per-context options on the measured loop itself: K device-resident blobs of a 2^n domain through
-BatchPipeline.run_stream_device (library batch policy, 2 calls in flight), alternating the option sets, best of 3 each.
+BatchPipeline.run_stream_device (library batch policy, 2 calls in flight), alternating the option sets over several fresh pipeline instances each; best and median.
+(Memory: every instance keeps its workspaces — up to 16 headline proofs per context; add FRIEDA_BATCH_BUDGET_MB to the sets to stay within the HBM.)
 usage: stream_ab.py <log_domain>[,<log_domain>...] NAME=VALUE[,NAME=VALUE...] [more option sets ...]   ("-" = defaults)"""
 import os
 import sys
@@ -26,14 +27,17 @@ def main():
         for i in range(K):
             blobs[i].copy_(torch.from_numpy(splitmix64_bytes(100 + i, blob_len)))
         torch.cuda.synchronize()
+        INST = 2  # fresh pipelines per option set: instances of the SAME options differ by 1 - 3 % (where their arenas land), so every set
+        # gets several and the report is the best and the median over instances x rounds
         pipes = []
         for opts in sets:
-            p = frieda_amd.BatchPipeline(0, 2)
-            for c in p.ctxs:
-                for k, v in opts.items():
-                    c.set_option(k, v)
-            pipes.append(p)
-        best = [1e9] * len(sets)
+            for _ in range(INST):
+                p = frieda_amd.BatchPipeline(0, 2)
+                for c in p.ctxs:
+                    for k, v in opts.items():
+                        c.set_option(k, v)
+                pipes.append(p)
+        times = [[] for _ in sets]
         ref = None
         for rnd in range(4):
             for i, p in enumerate(pipes):
@@ -45,9 +49,10 @@ def main():
                     ref = roots
                 assert roots == ref
                 if rnd:
-                    best[i] = min(best[i], dt)
-        for opts, b in zip(sets, best):
-            print(f"n={n} K={K} {opts or 'defaults'}: {1e3 * b:.4f} ms/blob", flush=True)
+                    times[i // INST].append(dt)
+        for opts, ts in zip(sets, times):
+            ts.sort()
+            print(f"n={n} K={K} {opts or 'defaults'}: best {1e3 * ts[0]:.4f}  median {1e3 * ts[len(ts) // 2]:.4f} ms/blob  ({len(ts)} runs over {INST} instances)", flush=True)
         for p in pipes:
             p.close()
         del blobs
