@@ -248,6 +248,95 @@ __global__ __launch_bounds__(256, WAVES) void chain_n_kernel(uint32_t* out, int 
     out[blockIdx.x * 256 + threadIdx.x] = s;
 }
 
+// ---- the same with TWO compressions in lock step (runs of 8 - 16), idle states per boundary kind as above ----
+template <int N>
+__device__ __forceinline__ void pin_n8(uint32_t& a, uint32_t& b, uint32_t& c, uint32_t& d, uint32_t& e, uint32_t& f, uint32_t& g, uint32_t& h) {
+    if constexpr (N == 1) asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h));
+    if constexpr (N == 2) asm volatile("s_nop 0" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h));
+    if constexpr (N == 3) asm volatile("s_nop 1" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h));
+    if constexpr (N == 4) asm volatile("s_nop 2" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h));
+    if constexpr (N == 5) asm volatile("s_nop 3" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h));
+    if constexpr (N == 6) asm volatile("s_nop 4" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h));
+}
+template <int LEAF, int NA, int NB, int NC>
+__device__ __forceinline__ void half_round_n2(uint32_t (&v)[16][2], const uint32_t (&m)[16][2], const int (&ia)[4], const int (&ib)[4], const int (&ic)[4],
+                                              const int (&id)[4], const uint8_t* sx) {
+#define P(N, ix) pin_n8<N>(v[ix[0]][0], v[ix[1]][0], v[ix[2]][0], v[ix[3]][0], v[ix[0]][1], v[ix[1]][1], v[ix[2]][1], v[ix[3]][1])
+#define FQ for (int q = 0; q < 4; q++) for (int k = 0; k < 2; k++)
+    _Pragma("unroll") FQ {
+        const int x = sx[2 * q];
+        v[ia[q]][k] = v[ia[q]][k] + v[ib[q]][k] + ((LEAF && x >= 4) ? 0u : m[x][k]);
+    }
+    P(NA, ia);
+    _Pragma("unroll") FQ v[id[q]][k] ^= v[ia[q]][k];
+    P(NB, id);
+    _Pragma("unroll") FQ v[id[q]][k] = b2detail::rotr(v[id[q]][k], 16);
+    P(NA, id);
+    _Pragma("unroll") FQ v[ic[q]][k] += v[id[q]][k];
+    _Pragma("unroll") FQ v[ib[q]][k] ^= v[ic[q]][k];
+    P(NB, ib);
+    _Pragma("unroll") FQ v[ib[q]][k] = b2detail::rotr(v[ib[q]][k], 12);
+    _Pragma("unroll") FQ {
+        const int y = sx[2 * q + 1];
+        v[ia[q]][k] = v[ia[q]][k] + v[ib[q]][k] + ((LEAF && y >= 4) ? 0u : m[y][k]);
+    }
+    P(NA, ia);
+    _Pragma("unroll") FQ v[id[q]][k] ^= v[ia[q]][k];
+    P(NB, id);
+    _Pragma("unroll") FQ v[id[q]][k] = b2detail::rotr(v[id[q]][k], 8);
+    P(NA, id);
+    _Pragma("unroll") FQ v[ic[q]][k] += v[id[q]][k];
+    _Pragma("unroll") FQ v[ib[q]][k] ^= v[ic[q]][k];
+    P(NB, ib);
+    _Pragma("unroll") FQ v[ib[q]][k] = b2detail::rotr(v[ib[q]][k], 7);
+    P(NC, ib);
+#undef FQ
+#undef P
+}
+template <int LEAF, int WAVES, int NA, int NB, int NC>
+__global__ __launch_bounds__(256, WAVES) void chain_n2_kernel(uint32_t* out, int iters, Stamp* st) {
+    using b2detail::IV;
+    using b2detail::SIGMA;
+    uint32_t m[16][2], h[8][2];
+    for (int k = 0; k < 2; k++) {
+        for (int i = 0; i < 16; i++) m[i][k] = threadIdx.x * 2654435761u + i * 40503u + blockIdx.x + 977u * k;
+        for (int i = 0; i < 8; i++) h[i][k] = 0;
+    }
+    unsigned long long c0, r0, c1, r1;
+    stamp_pair(c0, r0);
+    asm volatile("" : "+v"(m[0][0]) : "s"(c0));
+    constexpr int ca[4] = {0, 1, 2, 3}, cb[4] = {4, 5, 6, 7}, cc[4] = {8, 9, 10, 11}, cd[4] = {12, 13, 14, 15};
+    constexpr int db[4] = {5, 6, 7, 4}, dc[4] = {10, 11, 8, 9}, dd[4] = {15, 12, 13, 14};
+    for (int it = 0; it < iters; it++) {
+        uint32_t v[16][2];
+        for (int k = 0; k < 2; k++)
+            for (int i = 0; i < 8; i++) v[i][k] = 0u, v[8 + i][k] = IV[i];
+#pragma unroll
+        for (int r = 0; r < 10; r++) {
+            half_round_n2<LEAF, NA, NB, NC>(v, m, ca, cb, cc, cd, &SIGMA[r][0]);
+            half_round_n2<LEAF, NA, NB, NC>(v, m, ca, db, dc, dd, &SIGMA[r][8]);
+        }
+        for (int k = 0; k < 2; k++) {
+            for (int i = 0; i < 8; i++) h[i][k] = v[i][k] ^ v[8 + i][k];
+            if (LEAF) {
+                for (int i = 0; i < 4; i++) m[i][k] = h[i][k] ^ h[4 + i][k];
+            } else {
+                for (int i = 0; i < 8; i++) {
+                    m[i][k] ^= h[i][k];
+                    m[8 + i][k] += h[i][k];
+                }
+            }
+        }
+    }
+    asm volatile("" ::"v"(h[0][0]), "v"(h[7][1]));
+    stamp_pair(c1, r1);
+    if (threadIdx.x == 0) st[blockIdx.x] = Stamp{c0, r0, c1, r1};
+    uint32_t s = 0;
+    for (int k = 0; k < 2; k++)
+        for (int i = 0; i < 8; i++) s += h[i][k];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+
 typedef void (*kern_t)(uint32_t*, int, Stamp*);
 
 static double run(const char* name, kern_t kfn, int K, int waves, double seconds) {
@@ -304,8 +393,22 @@ static double run(const char* name, kern_t kfn, int K, int waves, double seconds
         run(nm, chain_n_kernel<LEAF, WAVES, NA, NB, NC>, 1, WAVES, secs);                                                 \
     } while (0)
 
+#define RUN_N2(LEAF, WAVES, NA, NB, NC)                                                                                   \
+    do {                                                                                                                  \
+        char nm[96];                                                                                                      \
+        snprintf(nm, sizeof nm, "%s K=2 idle states: slow>fast %d, fast>slow %d, slow>slow %d", LEAF ? "leaf" : "node", NA, NB, NC); \
+        run(nm, chain_n2_kernel<LEAF, WAVES, NA, NB, NC>, 2, WAVES, secs);                                                \
+    } while (0)
+
 int main(int argc, char** argv) {
     const double secs = argc > 1 ? atof(argv[1]) : 0.5;
+    if (argc > 2 && argv[2][0] == '2') {  // two compressions in lock step, at 4 and 8 waves per SIMD
+        RUN_N(0, 4, 3, 3, 3); RUN_N(1, 4, 3, 3, 3); RUN_N(0, 4, 0, 0, 0); RUN_N(1, 4, 0, 0, 0);
+        RUN_N2(0, 4, 1, 1, 1); RUN_N2(0, 4, 2, 2, 2); RUN_N2(0, 4, 3, 3, 3); RUN_N2(0, 4, 4, 4, 4); RUN_N2(0, 4, 3, 0, 3); RUN_N2(0, 4, 6, 0, 0);
+        RUN_N2(1, 4, 1, 1, 1); RUN_N2(1, 4, 2, 2, 2); RUN_N2(1, 4, 3, 3, 3); RUN_N2(1, 4, 4, 4, 4); RUN_N2(1, 4, 3, 0, 3); RUN_N2(1, 4, 6, 0, 0);
+        RUN_N2(0, 8, 3, 3, 3); RUN_N2(1, 8, 3, 3, 3); RUN_N2(0, 8, 5, 5, 5); RUN_N2(1, 8, 5, 5, 5);
+        return 0;
+    }
     if (argc > 2) {  // the idle-state sweep only
         for (int leaf = 0; leaf < 2; leaf++) {
             if (leaf == 0) {
