@@ -101,8 +101,8 @@ FR_HD void b2_compress(const uint32_t (&h)[8], const uint32_t (&m)[16], uint32_t
 //  * a fine interleave of fast-class (v_xor / v_add) and slow-class (v_alignbit / v_add3) instructions — what the scheduler emits when
 //    left alone (average run 2.1) — costs 3975 SIMD cycles per wave-compression (node shape, 8 waves per SIMD);
 //  * the same instructions as RUNS of one class (the four columns / diagonals advance one G step at a time): 3860;
-//  * and with a few IDLE issue states (s_nop) between the runs: 3380 - 3480 (node), 3220 - 3260 (leaf, from 3810) — 12 - 15 % fewer
-//    cycles for ~350 extra (scalar) instructions.  The waves of a SIMD hand the vector pipe to each other at the run boundaries
+//  * and with a few IDLE issue states (s_nop) between the runs: 3290 - 3320 (node), 3130 - 3150 (leaf, from 3810) — 17 - 18 % fewer
+//    cycles for ~250 extra (scalar) instructions.  The waves of a SIMD hand the vector pipe to each other at the run boundaries
 //    instead of contending instruction by instruction; the optimum is occupancy-dependent (nothing to gain at 2 waves per SIMD).
 // The runs are pinned by data flow: one volatile asm statement takes the four values a step has just written as read-write
 // operands, so the step's instructions lie between two such statements at every level of the compiler (a scheduling barrier is not
@@ -111,7 +111,7 @@ FR_HD void b2_compress(const uint32_t (&h)[8], const uint32_t (&m)[16], uint32_t
 // IDLE = 0xABC: idle states at the boundaries slow -> fast (A), fast -> slow (B), slow -> slow (C: rotr 7 -> the next add3).
 template <int N>
 __device__ __forceinline__ void b2_pin(uint32_t& a, uint32_t& b, uint32_t& c, uint32_t& d) {
-    static_assert(N >= 0 && N <= 6, "idle states 0 .. 6");
+    static_assert(N >= 0 && N <= 6, "idle states 0 .. 6");  // (more than 6 never paid: profiles/r05_blake2s_idle_sweep.txt)
     if constexpr (N == 1) asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
     if constexpr (N == 2) asm volatile("s_nop 0" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
     if constexpr (N == 3) asm volatile("s_nop 1" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
@@ -210,11 +210,14 @@ __device__ __forceinline__ void b2_merkle_block_runs(const uint32_t (&m)[16], ui
 }
 #endif
 // idle states of the throughput form, per message shape (A/B knobs of the build: tools/build_variant.sh <name> -DFRIEDA_B2_IDLE_NODE=0x...)
+// 0x603: six idle states after every slow run that a fast run follows, none after a fast run, three between the two slow runs at the
+// half-round boundary — a local optimum of the per-position sweep (profiles/r05_blake2s_idle_sweep.txt, last blocks): 3290 - 3320 node /
+// 3130 - 3150 leaf cycles at 8 waves per SIMD (0x333: 3476 - 3506 / 3255), 3606 / 3496 at 4 waves (3808 / 3538)
 #ifndef FRIEDA_B2_IDLE_NODE
-#define FRIEDA_B2_IDLE_NODE 0x333
+#define FRIEDA_B2_IDLE_NODE 0x603
 #endif
 #ifndef FRIEDA_B2_IDLE_LEAF
-#define FRIEDA_B2_IDLE_LEAF 0x333
+#define FRIEDA_B2_IDLE_LEAF 0x603
 #endif
 // the fused last transform pass + tree launch (ntt.hip) runs at 4 waves per SIMD (120 VGPRs), where the optimum differs
 #ifndef FRIEDA_B2_IDLE_NTT_NODE

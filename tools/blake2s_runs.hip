@@ -174,6 +174,11 @@ __device__ __forceinline__ void pin_n(uint32_t& a, uint32_t& b, uint32_t& c, uin
     if constexpr (N == 4) asm volatile("s_nop 2" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
     if constexpr (N == 5) asm volatile("s_nop 3" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
     if constexpr (N == 6) asm volatile("s_nop 4" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+    if constexpr (N == 7) asm volatile("s_nop 5" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+    if constexpr (N == 8) asm volatile("s_nop 6" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+    if constexpr (N == 9) asm volatile("s_nop 7" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+    if constexpr (N == 10) asm volatile("s_nop 8" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+    if constexpr (N == 12) asm volatile("s_nop 10" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
 }
 template <int LEAF, int NA, int NB, int NC>
 __device__ __forceinline__ void half_round_n(uint32_t (&v)[16], const uint32_t (&m)[16], const int (&ia)[4], const int (&ib)[4], const int (&ic)[4],
@@ -337,6 +342,82 @@ __global__ __launch_bounds__(256, WAVES) void chain_n2_kernel(uint32_t* out, int
     out[blockIdx.x * 256 + threadIdx.x] = s;
 }
 
+// ---- K = 1, idle states per boundary POSITION of the half-round (nine of them, in order: after a+=b+x, after d^=a, after rotr16, after
+// c+=d / b^=c, after rotr12 / a+=b+y, after d^=a, after rotr8, after c+=d / b^=c, after rotr7) ----
+template <int LEAF, int... P>
+__device__ __forceinline__ void half_round_p(uint32_t (&v)[16], const uint32_t (&m)[16], const int (&ia)[4], const int (&ib)[4], const int (&ic)[4],
+                                             const int (&id)[4], const uint8_t* sx) {
+    constexpr int N[9] = {P...};
+#define PP(i, ix) pin_n<N[i]>(v[ix[0]], v[ix[1]], v[ix[2]], v[ix[3]])
+#define FQ for (int q = 0; q < 4; q++)
+    _Pragma("unroll") FQ {
+        const int x = sx[2 * q];
+        v[ia[q]] = v[ia[q]] + v[ib[q]] + ((LEAF && x >= 4) ? 0u : m[x]);
+    }
+    PP(0, ia);
+    _Pragma("unroll") FQ v[id[q]] ^= v[ia[q]];
+    PP(1, id);
+    _Pragma("unroll") FQ v[id[q]] = b2detail::rotr(v[id[q]], 16);
+    PP(2, id);
+    _Pragma("unroll") FQ v[ic[q]] += v[id[q]];
+    _Pragma("unroll") FQ v[ib[q]] ^= v[ic[q]];
+    PP(3, ib);
+    _Pragma("unroll") FQ v[ib[q]] = b2detail::rotr(v[ib[q]], 12);
+    _Pragma("unroll") FQ {
+        const int y = sx[2 * q + 1];
+        v[ia[q]] = v[ia[q]] + v[ib[q]] + ((LEAF && y >= 4) ? 0u : m[y]);
+    }
+    PP(4, ia);
+    _Pragma("unroll") FQ v[id[q]] ^= v[ia[q]];
+    PP(5, id);
+    _Pragma("unroll") FQ v[id[q]] = b2detail::rotr(v[id[q]], 8);
+    PP(6, id);
+    _Pragma("unroll") FQ v[ic[q]] += v[id[q]];
+    _Pragma("unroll") FQ v[ib[q]] ^= v[ic[q]];
+    PP(7, ib);
+    _Pragma("unroll") FQ v[ib[q]] = b2detail::rotr(v[ib[q]], 7);
+    PP(8, ib);
+#undef FQ
+#undef PP
+}
+template <int LEAF, int WAVES, int... P>
+__global__ __launch_bounds__(256, WAVES) void chain_p_kernel(uint32_t* out, int iters, Stamp* st) {
+    using b2detail::IV;
+    using b2detail::SIGMA;
+    uint32_t m[16], h[8];
+    for (int i = 0; i < 16; i++) m[i] = threadIdx.x * 2654435761u + i * 40503u + blockIdx.x;
+    for (int i = 0; i < 8; i++) h[i] = 0;
+    unsigned long long c0, r0, c1, r1;
+    stamp_pair(c0, r0);
+    asm volatile("" : "+v"(m[0]) : "s"(c0));
+    constexpr int ca[4] = {0, 1, 2, 3}, cb[4] = {4, 5, 6, 7}, cc[4] = {8, 9, 10, 11}, cd[4] = {12, 13, 14, 15};
+    constexpr int db[4] = {5, 6, 7, 4}, dc[4] = {10, 11, 8, 9}, dd[4] = {15, 12, 13, 14};
+    for (int it = 0; it < iters; it++) {
+        uint32_t v[16];
+        for (int i = 0; i < 8; i++) v[i] = 0u, v[8 + i] = IV[i];
+#pragma unroll
+        for (int r = 0; r < 10; r++) {
+            half_round_p<LEAF, P...>(v, m, ca, cb, cc, cd, &SIGMA[r][0]);
+            half_round_p<LEAF, P...>(v, m, ca, db, dc, dd, &SIGMA[r][8]);
+        }
+        for (int i = 0; i < 8; i++) h[i] = v[i] ^ v[8 + i];
+        if (LEAF) {
+            for (int i = 0; i < 4; i++) m[i] = h[i] ^ h[4 + i];
+        } else {
+            for (int i = 0; i < 8; i++) {
+                m[i] ^= h[i];
+                m[8 + i] += h[i];
+            }
+        }
+    }
+    asm volatile("" ::"v"(h[0]), "v"(h[7]));
+    stamp_pair(c1, r1);
+    if (threadIdx.x == 0) st[blockIdx.x] = Stamp{c0, r0, c1, r1};
+    uint32_t s = 0;
+    for (int i = 0; i < 8; i++) s += h[i];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+
 typedef void (*kern_t)(uint32_t*, int, Stamp*);
 
 static double run(const char* name, kern_t kfn, int K, int waves, double seconds) {
@@ -402,6 +483,38 @@ static double run(const char* name, kern_t kfn, int K, int waves, double seconds
 
 int main(int argc, char** argv) {
     const double secs = argc > 1 ? atof(argv[1]) : 0.5;
+    if (argc > 2 && argv[2][0] == 'p') {  // per-position idle states, one coordinate at a time around 6-0-6-0-6-0-6-0-3
+#define RUN_P(W, ...)                                                                              \
+    do {                                                                                           \
+        run("node K=1 per position " #__VA_ARGS__, chain_p_kernel<0, W, __VA_ARGS__>, 1, W, secs); \
+        run("leaf K=1 per position " #__VA_ARGS__, chain_p_kernel<1, W, __VA_ARGS__>, 1, W, secs); \
+    } while (0)
+        RUN_P(8, 6, 0, 6, 0, 6, 0, 6, 0, 3);
+        RUN_P(8, 4, 0, 6, 0, 6, 0, 6, 0, 3); RUN_P(8, 8, 0, 6, 0, 6, 0, 6, 0, 3); RUN_P(8, 3, 0, 6, 0, 6, 0, 6, 0, 3);
+        RUN_P(8, 6, 0, 4, 0, 6, 0, 6, 0, 3); RUN_P(8, 6, 0, 8, 0, 6, 0, 6, 0, 3); RUN_P(8, 6, 0, 3, 0, 6, 0, 6, 0, 3);
+        RUN_P(8, 6, 0, 6, 0, 4, 0, 6, 0, 3); RUN_P(8, 6, 0, 6, 0, 8, 0, 6, 0, 3); RUN_P(8, 6, 0, 6, 0, 3, 0, 6, 0, 3);
+        RUN_P(8, 6, 0, 6, 0, 6, 0, 4, 0, 3); RUN_P(8, 6, 0, 6, 0, 6, 0, 8, 0, 3); RUN_P(8, 6, 0, 6, 0, 6, 0, 3, 0, 3);
+        RUN_P(8, 6, 1, 6, 0, 6, 0, 6, 0, 3); RUN_P(8, 6, 0, 6, 1, 6, 0, 6, 0, 3); RUN_P(8, 6, 0, 6, 0, 6, 1, 6, 0, 3); RUN_P(8, 6, 0, 6, 0, 6, 0, 6, 1, 3);
+        RUN_P(8, 6, 0, 6, 2, 6, 0, 6, 2, 3); RUN_P(8, 6, 0, 6, 0, 6, 0, 6, 0, 0); RUN_P(8, 0, 0, 6, 0, 6, 0, 6, 0, 3); RUN_P(8, 6, 0, 0, 0, 6, 0, 6, 0, 3);
+        RUN_P(8, 6, 0, 6, 0, 0, 0, 6, 0, 3); RUN_P(8, 6, 0, 6, 0, 6, 0, 0, 0, 3);
+        return 0;
+    }
+    if (argc > 2 && argv[2][0] == 'g') {  // around 6-0-3
+#define BOTH(A, B, C, W) RUN_N(0, W, A, B, C); RUN_N(1, W, A, B, C)
+        BOTH(6, 0, 3, 8); BOTH(6, 0, 2, 8); BOTH(6, 0, 4, 8); BOTH(6, 0, 5, 8); BOTH(5, 0, 3, 8); BOTH(7, 0, 3, 8); BOTH(8, 0, 3, 8); BOTH(8, 0, 4, 8);
+        BOTH(7, 0, 4, 8); BOTH(10, 0, 3, 8); BOTH(10, 0, 5, 8); BOTH(12, 0, 6, 8); BOTH(6, 1, 3, 8); BOTH(7, 1, 3, 8); BOTH(5, 0, 2, 8); BOTH(5, 0, 4, 8);
+        BOTH(6, 0, 3, 4); BOTH(8, 0, 4, 4); BOTH(4, 0, 2, 4); BOTH(3, 3, 3, 4); BOTH(5, 0, 3, 4); BOTH(3, 0, 2, 4);
+        return 0;
+    }
+    if (argc > 2 && argv[2][0] == 'f') {  // finer sweep around the two optima of the first one, 8 waves per SIMD
+        RUN_N(0, 8, 6, 0, 0); RUN_N(0, 8, 5, 0, 0); RUN_N(0, 8, 4, 0, 0); RUN_N(0, 8, 6, 1, 0); RUN_N(0, 8, 6, 0, 1); RUN_N(0, 8, 6, 0, 3); RUN_N(0, 8, 6, 0, 6);
+        RUN_N(0, 8, 5, 1, 1); RUN_N(0, 8, 5, 2, 0); RUN_N(0, 8, 6, 2, 0); RUN_N(0, 8, 4, 2, 0); RUN_N(0, 8, 2, 4, 2); RUN_N(0, 8, 2, 5, 2); RUN_N(0, 8, 2, 6, 2);
+        RUN_N(0, 8, 1, 4, 1); RUN_N(0, 8, 2, 4, 0); RUN_N(0, 8, 0, 4, 2); RUN_N(0, 8, 3, 3, 3); RUN_N(0, 8, 6, 0, 0);
+        RUN_N(1, 8, 6, 0, 0); RUN_N(1, 8, 5, 0, 0); RUN_N(1, 8, 4, 0, 0); RUN_N(1, 8, 6, 1, 0); RUN_N(1, 8, 6, 0, 1); RUN_N(1, 8, 6, 0, 3); RUN_N(1, 8, 6, 0, 6);
+        RUN_N(1, 8, 5, 1, 1); RUN_N(1, 8, 5, 2, 0); RUN_N(1, 8, 6, 2, 0); RUN_N(1, 8, 4, 2, 0); RUN_N(1, 8, 2, 4, 2); RUN_N(1, 8, 2, 5, 2); RUN_N(1, 8, 2, 6, 2);
+        RUN_N(1, 8, 1, 4, 1); RUN_N(1, 8, 2, 4, 0); RUN_N(1, 8, 0, 4, 2); RUN_N(1, 8, 3, 3, 3); RUN_N(1, 8, 2, 4, 2);
+        return 0;
+    }
     if (argc > 2 && argv[2][0] == '2') {  // two compressions in lock step, at 4 and 8 waves per SIMD
         RUN_N(0, 4, 3, 3, 3); RUN_N(1, 4, 3, 3, 3); RUN_N(0, 4, 0, 0, 0); RUN_N(1, 4, 0, 0, 0);
         RUN_N2(0, 4, 1, 1, 1); RUN_N2(0, 4, 2, 2, 2); RUN_N2(0, 4, 3, 3, 3); RUN_N2(0, 4, 4, 4, 4); RUN_N2(0, 4, 3, 0, 3); RUN_N2(0, 4, 6, 0, 0);
