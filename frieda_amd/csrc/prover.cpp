@@ -439,7 +439,9 @@ uint32_t batch_per_call(const k::Tuning& t, size_t ws_per_blob, uint32_t count, 
     const uint64_t ways = (uint64_t)std::max<uint32_t>(1, t.batch_calls_per_ctx) * in_flight;
     const uint64_t spread = (count + ways - 1) / ways;  // every context gets its calls
     per = std::min<uint64_t>(per, spread);
-    per = std::min<uint64_t>(per, 65535);  // the batched entry points' own limit
+    // (the batched entry points take up to 65535 blobs; beyond a few thousand per call the latency chain is amortised to nothing, while
+    // the pinned staging block — ~10 KB of openings per proof — and the host-side proof objects keep growing with the count)
+    per = std::min<uint64_t>(per, 4096);
     return (uint32_t)std::max<uint64_t>(per, 1);
 }
 

@@ -183,7 +183,7 @@ int frieda_verify_samples(const frieda_proof* proof, const uint64_t* seed, int* 
  * blobs want many per call, large blobs few (the device workspace grows with the count).  The library's rule — what
  * frieda_prove_many / frieda_commit_many apply per device, offered here to callers that drive _begin / _finish themselves (the
  * caller loop of benches/proof.rs:30-44 over many blobs):
- *     per_call = clamp(budget / frieda_workspace_bytes(blob), 1, ceil(count / (calls_per_ctx * in_flight)))
+ *     per_call = clamp(budget / frieda_workspace_bytes(blob), 1, min(4096, ceil(count / (calls_per_ctx * in_flight))))
  *     calls    = the smallest multiple of in_flight with no call above per_call, sizes equal to within one
  * budget: context option "FRIEDA_BATCH_BUDGET_MB" (0 = default: the workspace of sixteen proofs on a 2^24 domain, ~43 GB per call in flight — lower it on a shared device);
  * calls_per_ctx: option "FRIEDA_BATCH_CALLS_PER_CTX" (default 1: one call per context when the budget allows — measured equal to

@@ -59,6 +59,11 @@ def test_plan_invariants(fa):
                     assert len(cut) >= in_flight  # every context gets a call
 
 
+def test_plan_caps_the_blobs_per_call(fa):
+    cut = fa.batch_plan(1024, 100000, _cfg(fa))  # tiny blobs: the budget would allow 65535 per call
+    assert sum(cut) == 100000 and max(cut) <= 4096 and len(cut) % 2 == 0 and max(cut) - min(cut) <= 1
+
+
 def test_plan_for_commits_and_errors(fa):
     from frieda_amd import _lib
 

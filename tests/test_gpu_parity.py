@@ -1256,6 +1256,32 @@ def test_batch_budget_option_range(gpu_ctx):
     assert gpu_ctx._L.frieda_ctx_test_set_grind_first_log(gpu_ctx._h, 0) == 0
 
 
+@pytest.mark.parametrize("iters", [1, 4, 8, 64])
+def test_batched_grind_claim_sizes(oracle, iters):
+    """The batched grind claims `FRIEDA_GRIND_ITERS / 4` units of 1024 nonces per atomic (one counter per blob, each on its own cache line):
+    whatever the claim size — also when a claim reaches past the end of the range (test hook: 2^10-nonce first range, then doubling) — the
+    nonce is the MINIMUM and the proofs are the oracle's."""
+    import frieda_amd
+
+    cfg = _cfg(frieda_amd, 14, 4, 0, 8)
+    ocfg = oracle.make_config(14, 4, 0, 8)
+    blobs = [splitmix64_bytes(9800 + i, 1200).tobytes() for i in range(7)]
+    expect = [oracle.commit_and_generate_proof(b, 77 + i, ocfg) for i, b in enumerate(blobs)]
+    ctx = frieda_amd.Context(0)
+    try:
+        ctx.set_option("FRIEDA_GRIND_ITERS", iters)
+        for first_log in (0, 10):
+            assert ctx._L.frieda_ctx_test_set_grind_first_log(ctx._h, first_log) == 0
+            got = ctx.commit_and_generate_proof_batch(blobs, [77 + i for i in range(len(blobs))], cfg)
+            assert [(bytes(r), p.serialize()) for r, p in expect] == [(r, p.serialize()) for r, p in got]
+            r, p = ctx.commit_and_generate_proof(blobs[0], 77, cfg)
+            assert p.serialize() == expect[0][1].serialize()
+        with pytest.raises(frieda_amd.FriedaError):
+            ctx.set_option("FRIEDA_GRIND_ITERS", 65)
+    finally:
+        ctx.close()
+
+
 def test_sharded_batch_helpers_use_the_batched_kernels(oracle):
     """frieda_amd.batch (the multi-GPU sharding layer) on one rank: equal-length shards go through the batched kernels, ragged
     ones through the C ABI's multi entry (frieda_commit_many / frieda_prove_many, two proofs in flight); both give the oracle's
