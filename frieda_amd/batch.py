@@ -3,17 +3,12 @@ data-path collective; the only exchange is an all_gather of the 32-byte commitme
 backend; gloo on CPU in the tests).
 
 `commit_fn(blob) -> bytes[32]` is injected so that the sharding / gather logic is testable without a GPU; the default is the
-HIP path of this package (there is no CPU fallback): a rank's shard goes through the batched kernels
-(`frieda_commit_batch` / `frieda_commit_and_generate_proof_batch`, every kernel launched once for many blobs) whenever its
-blobs have one length, and blob by blob otherwise.
+HIP path of this package (there is no CPU fallback): a rank's shard goes through the C ABI's multi entry on its one device
+(`frieda_commit_many` / `frieda_prove_many`: runs of equal-length blobs through the batched kernels, cut into calls by the library's
+batch policy, two calls in flight, host blobs uploaded ahead of their kernels).
 """
 import torch
 import torch.distributed as dist
-
-
-def _chunk_size(length):
-    """Blobs per batched call: bounded so that the per-blob workspaces (a few hundred bytes per blob byte) stay within ~4 GB."""
-    return max(1, min(1024, (4 << 30) // (400 * max(length, 1) + 65536)))
 
 
 _multi = {}
@@ -55,25 +50,15 @@ def prove_many_on_node(blobs, seeds, pcs_config, devices=None):
 
 
 def _local_commit_many(ctx, blobs, log_blowup_factor):
-    if len(blobs) > 1 and len({len(b) for b in blobs}) == 1:
-        step, out = _chunk_size(len(blobs[0])), []
-        for k in range(0, len(blobs), step):
-            out += ctx.commit_batch(blobs[k : k + step], log_blowup_factor)
-        return out
+    # more than one blob: the C ABI's multi entry on this one device (frieda_commit_many: runs of equal-length blobs go through the
+    # batched kernels, cut into calls by the library's batch policy, two calls in flight, uploads ahead of their kernels)
     if len(blobs) > 1:
         return _multi_for(ctx.device).commit_many(blobs, log_blowup_factor)
     return [ctx.commit(b, log_blowup_factor) for b in blobs]
 
 
 def _local_prove_many(ctx, blobs, seeds, pcs_config):
-    fc = pcs_config.fri_config
-    batched = len(blobs) > 1 and len({len(b) for b in blobs}) == 1 and fc.log_last_layer_degree_bound + fc.log_blowup_factor <= 11
-    if batched:
-        step, out = _chunk_size(len(blobs[0])), []
-        for k in range(0, len(blobs), step):
-            out += ctx.commit_and_generate_proof_batch(blobs[k : k + step], None if seeds is None else seeds[k : k + step], pcs_config)
-        return out
-    if len(blobs) > 1:  # mixed lengths (or a last layer beyond the batched kernels): the C ABI's multi entry, two proofs in flight
+    if len(blobs) > 1:  # frieda_prove_many: batch policy for runs of equal lengths, single proofs otherwise, two calls in flight
         return _multi_for(ctx.device).prove_many(blobs, seeds, pcs_config)
     return [ctx.commit_and_generate_proof(b, None if seeds is None else seeds[i], pcs_config) for i, b in enumerate(blobs)]
 
