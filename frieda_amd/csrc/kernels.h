@@ -37,6 +37,7 @@ struct Tuning {
     uint32_t ntt_cpw_small = 1;  // FRIEDA_NTT_CPW_SMALL: columns per workgroup of fast-kernel launches below 512 tiles
     bool ntt_rep = false;        // FRIEDA_NTT_REP: the first strided pass as ntt_tile12_rep_kernel
     bool ntt_no_pad8 = false;    // FRIEDA_NTT_NO_PAD8: no padded / 4-layer fast passes
+    bool ntt_no_cp = false;      // FRIEDA_NTT_NO_CP: small fold2 launches as one 256-thread workgroup per tile (not four columns side by side)
     bool ntt_tree_reg_only = false;      // FRIEDA_NTT_TREE_REG_ONLY: the fused encode + leaf launch stops after its five register levels
     bool no_encode_tree_fusion = false;  // FRIEDA_NO_ENCODE_TREE_FUSION: last transform pass and leaf launch as two kernels
     bool no_small_fused = false;         // FRIEDA_NO_SMALL_FUSED: the general path for small domains too

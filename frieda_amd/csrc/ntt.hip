@@ -834,6 +834,128 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_last_fold_kernel(NttFoldArgs 
     *reinterpret_cast<uint4*>(d2 + 3 * s2) = make_uint4(l2[0].d, l2[1].d, l2[2].d, l2[3].d);
 }
 
+// ------------------------------------------------------------------------------------------------
+// The same pass for SMALL launches (fewer tiles than the chip has CUs twice over): the four columns side by side
+// ------------------------------------------------------------------------------------------------
+// With one 256-thread workgroup per tile a 2^20 domain is 256 workgroups = one wave per SIMD, and the launch is a latency chain:
+// four columns x three LDS stages one after the other, then the folds (25 us for BASELINE configs[1]).  Here a workgroup has 1024
+// threads: quarter c transforms column c in its own LDS tile (4 x 17 KB of dynamic LDS), all at once; the results go back into the
+// tiles, and every thread folds 4 consecutive points of all four columns (two circle pairs -> one line pair -> one point of line 2).
+constexpr int NTT_CP_THREADS = 1024;
+template <bool ACC>
+__global__ __launch_bounds__(NTT_CP_THREADS) void ntt_last_fold_cp_kernel(NttFoldArgs A) {
+    extern __shared__ uint32_t cp_lds[];
+    const NttArgs& a = A.a;
+    const uint32_t c = threadIdx.x >> 8, g = threadIdx.x & 255u, hblk = blockIdx.x;
+    const uint32_t gbase = hblk << TILE_LOG;
+    uint32_t* lds = cp_lds + c * TILE_WORDS;
+    const uint32_t* in = a.in + (size_t)c * a.in_stride;
+    // ---- column c: 12 layers in three radix-16 stages (as last_pass_four_columns, one column); every global load of the chain —
+    // the tile and the three stages' twiddles — is issued before the first wait ----
+    uint4 pre[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; kk++) pre[kk] = *reinterpret_cast<const uint4*>(in + ((gbase | (4u * g + 1024u * (uint32_t)kk)) & a.in_mask));
+    uint32_t twd[3][15], pbase[3];
+#pragma unroll
+    for (int s = 0; s < 3; s++) {
+        const uint32_t lo = 8 - 4 * s;
+        const uint32_t base = ((g >> lo) << (lo + 4)) | (g & ((1u << lo) - 1));
+        pbase[s] = pad(base);
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const uint32_t b = lo + 3 - q;  // tile bit == global layer index
+            const uint32_t hbase = (hblk << (11 - b)) | (base >> (b + 1));
+            if (s == 2 && q == 3) {  // layer 0: the circle layer
+#pragma unroll
+                for (int u = 0; u < 8; u++) twd[s][7 + u] = 2u * circle_twiddle(a.tw, a.n, hbase + (uint32_t)u, a.init_y);
+            } else {
+                const uint32_t* lvl = a.tw + tw_level_offset_dev(a.n, b - 1) + hbase;
+#pragma unroll
+                for (int u = 0; u < (1 << q); u++) twd[s][(1 << q) - 1 + u] = 2u * lvl[u];  // doubled: radix16_group
+            }
+        }
+    }
+#pragma unroll
+    for (int kk = 0; kk < 4; kk++) {
+        const uint32_t p = pad(4u * g + 1024u * (uint32_t)kk);
+        lds[p] = pre[kk].x;
+        lds[p + 1] = pre[kk].y;
+        lds[p + 2] = pre[kk].z;
+        lds[p + 3] = pre[kk].w;
+    }
+    __syncthreads();
+    uint32_t x[16];
+#pragma unroll
+    for (int s = 0; s < 3; s++) {
+        const uint32_t lo = 8 - 4 * s;
+        uint32_t* col = lds + pbase[s];
+#pragma unroll
+        for (int r = 0; r < 16; r++) x[r] = col[pad((uint32_t)r << lo)];
+        radix16_stage<FRIEDA_NTT_GROUP_FUSED>(x, twd[s]);
+        if (s < 2) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) col[pad((uint32_t)r << lo)] = x[r];
+        }
+        if (s == 1)
+            __builtin_amdgcn_wave_barrier();  // stages 1 and 2 are wave-local (ntt_tile12_kernel)
+        else if (s == 0)
+            __syncthreads();
+    }
+    {  // the evaluation leaves from registers (16 consecutive words per thread); the tile gets it too, for the folds
+        uint4* o = reinterpret_cast<uint4*>(a.out + (size_t)c * a.out_stride + gbase + 16u * g);
+        o[0] = make_uint4(x[0], x[1], x[2], x[3]);
+        o[1] = make_uint4(x[4], x[5], x[6], x[7]);
+        o[2] = make_uint4(x[8], x[9], x[10], x[11]);
+        o[3] = make_uint4(x[12], x[13], x[14], x[15]);
+        uint32_t* mine = lds + pad(16u * g);  // 16 g .. 16 g + 15 sit in one padded group
+#pragma unroll
+        for (int r = 0; r < 16; r++) mine[r] = x[r];
+    }
+    __syncthreads();
+    // ---- folds: thread T owns tile points 4 T .. 4 T + 3 of all four columns ----
+    const uint32_t T = threadIdx.x, n = a.n;
+    const size_t e0 = (size_t)gbase + 4u * T;
+    uint32_t v[4][4];
+#pragma unroll
+    for (int cc = 0; cc < 4; cc++) {
+        const uint32_t* t4 = cp_lds + cc * TILE_WORDS + pad(4u * T);  // (4 T .. 4 T + 3 do not cross a 16-word group)
+#pragma unroll
+        for (int k = 0; k < 4; k++) v[cc][k] = t4[k];
+    }
+    const QM31Mat am0 = qm_matrix({A.alpha0[0], A.alpha0[1], A.alpha0[2], A.alpha0[3]});
+    const QM31Mat am1 = qm_matrix({A.alpha1[0], A.alpha1[1], A.alpha1[2], A.alpha1[3]});
+    // circle pairs i = e0 / 2, e0 / 2 + 1: inverse-Y[i] = [iy, -iy, -ix, ix] of the inverse level-0 pair (x, y) at index i >> 2;
+    // the line pair j = e0 / 4 reads inverse level 0 at j
+    const size_t i0 = e0 >> 1;
+    const uint2 xy = *reinterpret_cast<const uint2*>(A.itw + 2 * (i0 >> 2));
+    const uint32_t it0 = (i0 & 2) ? m31_neg(xy.x) : xy.y, it1 = (i0 & 2) ? xy.x : m31_neg(xy.y);
+    const uint32_t il = A.itw[e0 >> 2];
+    QM31 l1[2];
+    l1[0] = qm_fold_pair(QM31{v[0][0], v[1][0], v[2][0], v[3][0]}, QM31{v[0][1], v[1][1], v[2][1], v[3][1]}, it0, am0);
+    l1[1] = qm_fold_pair(QM31{v[0][2], v[1][2], v[2][2], v[3][2]}, QM31{v[0][3], v[1][3], v[2][3], v[3][3]}, it1, am0);
+    const size_t s1 = (size_t)1 << (n - 1), s2 = (size_t)1 << (n - 2);
+    uint32_t* d1 = A.line1 + i0;
+    if (ACC) {
+        const QM31 al = {A.alpha0[0], A.alpha0[1], A.alpha0[2], A.alpha0[3]};
+        const QM31 asq = qm_mul(al, al);
+        uint2 o[4];
+#pragma unroll
+        for (int cc = 0; cc < 4; cc++) o[cc] = *reinterpret_cast<const uint2*>(d1 + cc * s1);
+        l1[0] = qm_add(qm_mul(QM31{o[0].x, o[1].x, o[2].x, o[3].x}, asq), l1[0]);
+        l1[1] = qm_add(qm_mul(QM31{o[0].y, o[1].y, o[2].y, o[3].y}, asq), l1[1]);
+    }
+    *reinterpret_cast<uint2*>(d1) = make_uint2(l1[0].a, l1[1].a);
+    *reinterpret_cast<uint2*>(d1 + s1) = make_uint2(l1[0].b, l1[1].b);
+    *reinterpret_cast<uint2*>(d1 + 2 * s1) = make_uint2(l1[0].c, l1[1].c);
+    *reinterpret_cast<uint2*>(d1 + 3 * s1) = make_uint2(l1[0].d, l1[1].d);
+    const QM31 l2 = qm_fold_pair(l1[0], l1[1], il, am1);
+    uint32_t* d2 = A.line2 + (e0 >> 2);
+    d2[0] = l2.a;
+    d2[s2] = l2.b;
+    d2[2 * s2] = l2.c;
+    d2[3 * s2] = l2.d;
+}
+
 }  // namespace
 
 FR_CLOCK_READER(frieda_debug_clock_ntt_last_tree, g_clock_ntt_last_tree)
@@ -862,8 +984,12 @@ uint32_t circle_evaluate_into_tree(const Launch& L_, const uint32_t* d_coef, siz
 hipError_t ntt_opt_in_dynamic_lds() {
     // The opt-in belongs to the CURRENT device's function object: called once per context at creation (frieda_multi drives several
     // devices from one process), so no process-wide flag is kept.
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(ntt_tile_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)(MAX_COLS_PER_WG * TILE_WORDS * sizeof(uint32_t)));
+    const int bytes = (int)(MAX_COLS_PER_WG * TILE_WORDS * sizeof(uint32_t));
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ntt_tile_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(ntt_last_fold_cp_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(ntt_last_fold_cp_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
 }
 
 bool circle_evaluate_fold2(const Launch& L_, const uint32_t* d_coef, size_t coef_stride, uint32_t L, uint32_t n, const uint32_t* d_tw,
@@ -978,7 +1104,15 @@ uint32_t evaluate_plan(const Launch& L_, const uint32_t* d_coef, size_t coef_str
             // algorithmic bytes: this pass's share of the encode + fold_circle_into_line (24 N) + fold_line at N / 2 (12 N)
             Scope scope(L_, "ntt_last_fold2", enc_bytes / ((n_mid_fast ? n_mid_fast : n_mid_generic) + 1) + 36.0 * (double)N);
             const dim3 grid((unsigned)(N >> TILE_LOG), 1, 1);
-            if (fsink->accumulate)
+            // below 512 tiles the four columns run side by side in 1024-thread workgroups (the launch is a latency chain there);
+            // needs the 68 KB dynamic-LDS opt-in the context obtained at creation (ntt_cpw == 4 says it did)
+            const bool side_by_side = (N >> TILE_LOG) < 512 && L_.tune->ntt_cpw == 4 && !L_.tune->ntt_no_cp;
+            const size_t cp_lds = (size_t)4 * TILE_WORDS * sizeof(uint32_t);
+            if (side_by_side && fsink->accumulate)
+                ntt_last_fold_cp_kernel<true><<<grid, NTT_CP_THREADS, cp_lds, s>>>(fa);
+            else if (side_by_side)
+                ntt_last_fold_cp_kernel<false><<<grid, NTT_CP_THREADS, cp_lds, s>>>(fa);
+            else if (fsink->accumulate)
                 ntt_last_fold_kernel<true><<<grid, NTT_THREADS, 0, s>>>(fa);
             else
                 ntt_last_fold_kernel<false><<<grid, NTT_THREADS, 0, s>>>(fa);
