@@ -226,11 +226,7 @@ __device__ __forceinline__ void b2_merkle_block_runs(const uint32_t (&m)[16], ui
 #ifndef FRIEDA_B2_IDLE_NTT_LEAF
 #define FRIEDA_B2_IDLE_NTT_LEAF FRIEDA_B2_IDLE_LEAF
 #endif
-// tree5r in NODE mode (every compression node-shaped, children loaded from memory): the plain form is ahead there (92 vs 100 us for
-// the 2^24 proof's node launches, profiles/r05_idle_states_product_ab.txt); -1 = B2_LAT
-#ifndef FRIEDA_B2_IDLE_T5_NODE
-#define FRIEDA_B2_IDLE_T5_NODE -1
-#endif
+// (which form a tree launch takes is decided per launch: tree.hip tp_launch — below ~3 waves per SIMD an idle state is pure delay)
 
 // Blake2sMerkleHasher::hash_node for one 16-word block from the zero state: the shape of every node of
 // frieda's trees (leaf = 4 column words + 12 zero words; inner node = left || right).

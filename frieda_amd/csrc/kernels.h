@@ -50,6 +50,7 @@ struct Tuning {
     uint32_t test_grind_first_log = 0;   // test hook (frieda_ctx_test_set_grind_first_log): a short first nonce range (0 = off)
     // batch policy (host.h, "batch policy"): workspace bytes a batched call may keep in flight, and the fewest calls a context gets
     uint32_t batch_budget_mb = 0;        // FRIEDA_BATCH_BUDGET_MB: 0 = the default (sixteen proofs of a 2^24 domain, ~43 GB)
+    uint32_t tp_min_wgs = 768;           // FRIEDA_TP_MIN_WGS: launches of at least this many 256-thread workgroups hash in the throughput form (blake2s.h)
     uint32_t grind_iters = 0;            // FRIEDA_GRIND_ITERS: nonces per lane and claim in the batched grind (window = 256 x this); 0 = by batch size
     uint32_t batch_calls_per_ctx = 1;    // FRIEDA_BATCH_CALLS_PER_CTX: a stream is cut into at least this many calls per context in flight
                                          // (measured, profiles/r05_batch_policy_sweep.txt: 1 beats 2 by 3 % at 2^20 and 30 % at 1 KiB blobs, equal at 2^22 / 2^24)

@@ -636,7 +636,8 @@ __device__ __forceinline__ void last_pass_four_columns(const NttArgs& a, uint32_
 
 FR_CLOCK_DECL(g_clock_ntt_last_tree)
 // REG_ONLY: stop after the five register levels (256 nodes of level n - 4 per workgroup): see tree5r_kernel in tree.hip
-template <bool STORE_ALL, bool REG_ONLY = false>
+// TP: the compressions in the throughput form (launches of >= 768 tiles; below that the launch is a latency chain: tree.hip tp_launch)
+template <bool STORE_ALL, bool REG_ONLY, bool TP>
 __global__ __launch_bounds__(NTT_THREADS) void ntt_last_tree_kernel(NttTreeArgs A) {
     __shared__ uint32_t lds[TILE_WORDS];
     __shared__ __attribute__((aligned(16))) uint32_t RC[8 * (256 + 4)];
@@ -670,12 +671,12 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_last_tree_kernel(NttTreeArgs 
         auto half_ab = [&](auto half_c) {
             constexpr int half = decltype(half_c)::value;
             uint32_t ha[2][8];
-            leaf_hash<FRIEDA_B2_IDLE_NTT_LEAF>(v[0][2 * half], v[1][2 * half], v[2][2 * half], v[3][2 * half], ha[0]);
-            leaf_hash<FRIEDA_B2_IDLE_NTT_LEAF>(v[0][2 * half + 1], v[1][2 * half + 1], v[2][2 * half + 1], v[3][2 * half + 1], ha[1]);
+            leaf_hash<TP ? FRIEDA_B2_IDLE_NTT_LEAF : B2_LAT>(v[0][2 * half], v[1][2 * half], v[2][2 * half], v[3][2 * half], ha[0]);
+            leaf_hash<TP ? FRIEDA_B2_IDLE_NTT_LEAF : B2_LAT>(v[0][2 * half + 1], v[1][2 * half + 1], v[2][2 * half + 1], v[3][2 * half + 1], ha[1]);
             uint32_t mm[16];
 #pragma unroll
             for (int w = 0; w < 8; w++) mm[w] = ha[0][w], mm[8 + w] = ha[1][w];
-            b2_merkle_block<FRIEDA_B2_IDLE_NTT_NODE>(mm, hb[half]);
+            b2_merkle_block<TP ? FRIEDA_B2_IDLE_NTT_NODE : B2_LAT>(mm, hb[half]);
         };
         half_ab(std::integral_constant<int, 0>{});
         half_ab(std::integral_constant<int, 1>{});
@@ -688,7 +689,7 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_last_tree_kernel(NttTreeArgs 
             uint32_t mm[16];
 #pragma unroll
             for (int w = 0; w < 8; w++) mm[w] = hb[0][w], mm[8 + w] = hb[1][w];
-            b2_merkle_block<FRIEDA_B2_IDLE_NTT_NODE>(mm, hc);
+            b2_merkle_block<TP ? FRIEDA_B2_IDLE_NTT_NODE : B2_LAT>(mm, hc);
         }
         if (STORE_ALL) store_hash(out_c, l0 >> 2, hc);
         if ((it & 1) == 0) {
@@ -698,7 +699,7 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_last_tree_kernel(NttTreeArgs 
             uint32_t hd[8], mm[16];
 #pragma unroll
             for (int w = 0; w < 8; w++) mm[w] = hprev[w], mm[8 + w] = hc[w];
-            b2_merkle_block<FRIEDA_B2_IDLE_NTT_NODE>(mm, hd);
+            b2_merkle_block<TP ? FRIEDA_B2_IDLE_NTT_NODE : B2_LAT>(mm, hd);
             if (STORE_ALL) store_hash(out_d, l0 >> 3, hd);
             if (it == 1) {
 #pragma unroll
@@ -707,7 +708,7 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_last_tree_kernel(NttTreeArgs 
                 uint32_t he[8];
 #pragma unroll
                 for (int w = 0; w < 8; w++) mm[w] = hdprev[w], mm[8 + w] = hd[w];
-                b2_merkle_block<FRIEDA_B2_IDLE_NTT_NODE>(mm, he);
+                b2_merkle_block<TP ? FRIEDA_B2_IDLE_NTT_NODE : B2_LAT>(mm, he);
                 if (STORE_ALL || REG_ONLY) store_hash(out_e, l0 >> 4, he);
                 if (!REG_ONLY) lds_put(RC, 256 + 4, g, he);
             }
@@ -726,7 +727,7 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_last_tree_kernel(NttTreeArgs 
     if (g < 128) {
         uint32_t mm[16], h[8];
         lds_children(RC, 256 + 4, g, mm);
-        b2_merkle_block<FRIEDA_B2_IDLE_NTT_NODE>(mm, h);
+        b2_merkle_block<TP ? FRIEDA_B2_IDLE_NTT_NODE : B2_LAT>(mm, h);
         if (STORE_ALL) store_hash(layers + layer_off(m, m - 5), (wg_e >> 1) + g, h);
         lds_put(RD, 128 + 4, g, h);
     }
@@ -734,7 +735,7 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_last_tree_kernel(NttTreeArgs 
     if (g < 64) {
         uint32_t mm[16], h[8];
         lds_children(RD, 128 + 4, g, mm);
-        b2_merkle_block<FRIEDA_B2_IDLE_NTT_NODE>(mm, h);
+        b2_merkle_block<TP ? FRIEDA_B2_IDLE_NTT_NODE : B2_LAT>(mm, h);
         uint8_t* dst = STORE_ALL ? layers + layer_off(m, m - 6) : A.last_out + blockIdx.z * A.bstride;
         store_hash(dst, (wg_e >> 2) + g, h);
         FR_CLOCK_END(g_clock_ntt_last_tree, h[0])
@@ -1079,14 +1080,23 @@ uint32_t evaluate_plan(const Launch& L_, const uint32_t* d_coef, size_t coef_str
             for (uint32_t l = 1; l < levels; l++) bytes += 96.0 * (double)(N >> l);
             Scope scope(L_, reg_only ? "ntt_last_tree5" : "ntt_last_tree7", bytes);
             const dim3 grid((unsigned)(N >> TILE_LOG), 1, L_.batch);
+            const bool tp = (size_t)grid.x * grid.z >= L_.tune->tp_min_wgs;  // (tree.hip tp_launch: the throughput form pays from ~3 waves per SIMD on)
+#define FR_LAUNCH_LAST_TREE(SA, RO)                                                      \
+    do {                                                                                 \
+        if (tp)                                                                          \
+            ntt_last_tree_kernel<SA, RO, true><<<grid, NTT_THREADS, 0, s>>>(ta);         \
+        else                                                                             \
+            ntt_last_tree_kernel<SA, RO, false><<<grid, NTT_THREADS, 0, s>>>(ta);        \
+    } while (0)
             if (sink->layers && reg_only)
-                ntt_last_tree_kernel<true, true><<<grid, NTT_THREADS, 0, s>>>(ta);
+                FR_LAUNCH_LAST_TREE(true, true);
             else if (sink->layers)
-                ntt_last_tree_kernel<true><<<grid, NTT_THREADS, 0, s>>>(ta);
+                FR_LAUNCH_LAST_TREE(true, false);
             else if (reg_only)
-                ntt_last_tree_kernel<false, true><<<grid, NTT_THREADS, 0, s>>>(ta);
+                FR_LAUNCH_LAST_TREE(false, true);
             else
-                ntt_last_tree_kernel<false><<<grid, NTT_THREADS, 0, s>>>(ta);
+                FR_LAUNCH_LAST_TREE(false, false);
+#undef FR_LAUNCH_LAST_TREE
             fused_levels = levels;
             return;
         }

@@ -119,7 +119,9 @@ __device__ __forceinline__ void tree_args_of_blob(TreeArgs& a) {
 
 namespace {
 
-template <int MODE, uint32_t UNITS>
+// TP: the compressions in the throughput form (blake2s.h) — chosen by the launcher for launches that fill the chip (tp_launch): below
+// ~3 waves per SIMD an idle state is pure delay (a lone 2^20 proof 0.56 -> 0.61 ms with the throughput form everywhere)
+template <int MODE, uint32_t UNITS, bool TP>
 __global__ __launch_bounds__(T5_THREADS) void tree5_kernel(TreeArgs a) {
     __shared__ __attribute__((aligned(16))) uint32_t RA[8 * (UNITS + 4)];
     __shared__ __attribute__((aligned(16))) uint32_t RB[8 * (UNITS / 2 + 4)];
@@ -144,9 +146,9 @@ __global__ __launch_bounds__(T5_THREADS) void tree5_kernel(TreeArgs a) {
             if (MODE == T_NODE) {
                 uint32_t m[16];
                 load_children(a.children, g, m);
-                b2_merkle_block(m, h);
+                b2_merkle_block<TP ? FRIEDA_B2_IDLE_NODE : B2_LAT>(m, h);
             } else if (MODE == T_LEAF4) {
-                leaf_hash(a.cols[g], a.cols[a.col_stride + g], a.cols[2 * a.col_stride + g], a.cols[3 * a.col_stride + g], h);
+                leaf_hash<TP ? FRIEDA_B2_IDLE_LEAF : B2_LAT>(a.cols[g], a.cols[a.col_stride + g], a.cols[2 * a.col_stride + g], a.cols[3 * a.col_stride + g], h);
             } else {
                 uint32_t it = (MODE == T_FOLD_CIRCLE) ? inv_circle_twiddle(a.itw, a.n, g, a.inv_init_y) : a.itw[g];
                 QM31 r = fold_pair(a.cols, a.col_stride, g, it, alpha);
@@ -154,7 +156,7 @@ __global__ __launch_bounds__(T5_THREADS) void tree5_kernel(TreeArgs a) {
                 a.out_vals[a.out_stride + g] = r.b;
                 a.out_vals[2 * a.out_stride + g] = r.c;
                 a.out_vals[3 * a.out_stride + g] = r.d;
-                leaf_hash(r.a, r.b, r.c, r.d, h);
+                leaf_hash<TP ? FRIEDA_B2_IDLE_LEAF : B2_LAT>(r.a, r.b, r.c, r.d, h);
             }
             if (gout) store_hash(gout, g, h);
             if (!last) lds_put(RA, cnt_a + 4, j, h);
@@ -171,7 +173,7 @@ __global__ __launch_bounds__(T5_THREADS) void tree5_kernel(TreeArgs a) {
         for (uint32_t j = t; j < cnt; j += T5_THREADS) {
             uint32_t m[16], h[8];
             lds_children(src, 2 * cnt + 4, j, m);
-            b2_merkle_block(m, h);
+            b2_merkle_block<TP ? FRIEDA_B2_IDLE_NODE : B2_LAT>(m, h);
             if (gout) store_hash(gout, (wg_base >> l) + j, h);
             if (!last) lds_put(dst, cnt + 4, j, h);
         }
@@ -190,7 +192,7 @@ __global__ __launch_bounds__(T5_THREADS) void tree5_kernel(TreeArgs a) {
 // start together and stay in step, so the two LDS levels — half, then a quarter of the waves busy — are phases in which the
 // whole chip runs at 50 % / 25 %; leaving them to the next (eight times smaller) launch keeps the big launch at full rate.
 FR_CLOCK_DECL(g_clock_tree5r)
-template <int MODE, bool REG_ONLY = false>
+template <int MODE, bool REG_ONLY, bool TP>
 __global__ __launch_bounds__(T5_THREADS) void tree5r_kernel(TreeArgs a) {
     __shared__ __attribute__((aligned(16))) uint32_t RC[8 * (256 + 4)];
     __shared__ __attribute__((aligned(16))) uint32_t RD[8 * (128 + 4)];
@@ -254,19 +256,19 @@ __global__ __launch_bounds__(T5_THREADS) void tree5r_kernel(TreeArgs a) {
             {
                 uint32_t m[16];
                 load_children(a.children, g, m);
-                b2_merkle_block<MODE == T_NODE ? FRIEDA_B2_IDLE_T5_NODE : FRIEDA_B2_IDLE_NODE>(m, ha[0]);
+                b2_merkle_block<TP ? FRIEDA_B2_IDLE_NODE : B2_LAT>(m, ha[0]);
             }
             {
                 uint32_t m[16];
                 load_children(a.children, g + 1, m);
-                b2_merkle_block<MODE == T_NODE ? FRIEDA_B2_IDLE_T5_NODE : FRIEDA_B2_IDLE_NODE>(m, ha[1]);
+                b2_merkle_block<TP ? FRIEDA_B2_IDLE_NODE : B2_LAT>(m, ha[1]);
             }
         } else if (half == 0) {
-            leaf_hash(lc0.x, lc1.x, lc2.x, lc3.x, ha[0]);
-            leaf_hash(lc0.y, lc1.y, lc2.y, lc3.y, ha[1]);
+            leaf_hash<TP ? FRIEDA_B2_IDLE_LEAF : B2_LAT>(lc0.x, lc1.x, lc2.x, lc3.x, ha[0]);
+            leaf_hash<TP ? FRIEDA_B2_IDLE_LEAF : B2_LAT>(lc0.y, lc1.y, lc2.y, lc3.y, ha[1]);
         } else {
-            leaf_hash(lc0.z, lc1.z, lc2.z, lc3.z, ha[0]);
-            leaf_hash(lc0.w, lc1.w, lc2.w, lc3.w, ha[1]);
+            leaf_hash<TP ? FRIEDA_B2_IDLE_LEAF : B2_LAT>(lc0.z, lc1.z, lc2.z, lc3.z, ha[0]);
+            leaf_hash<TP ? FRIEDA_B2_IDLE_LEAF : B2_LAT>(lc0.w, lc1.w, lc2.w, lc3.w, ha[1]);
         }
         if (out_a) {
             store_hash(out_a, g, ha[0]);
@@ -275,7 +277,7 @@ __global__ __launch_bounds__(T5_THREADS) void tree5r_kernel(TreeArgs a) {
         uint32_t m[16];
 #pragma unroll
         for (int w = 0; w < 8; w++) m[w] = ha[0][w], m[8 + w] = ha[1][w];
-        b2_merkle_block<MODE == T_NODE ? FRIEDA_B2_IDLE_T5_NODE : FRIEDA_B2_IDLE_NODE>(m, hb[half]);
+        b2_merkle_block<TP ? FRIEDA_B2_IDLE_NODE : B2_LAT>(m, hb[half]);
     };
     half_ab(std::integral_constant<int, 0>{});
     half_ab(std::integral_constant<int, 1>{});
@@ -288,7 +290,7 @@ __global__ __launch_bounds__(T5_THREADS) void tree5r_kernel(TreeArgs a) {
         uint32_t m[16];
 #pragma unroll
         for (int w = 0; w < 8; w++) m[w] = hb[0][w], m[8 + w] = hb[1][w];
-        b2_merkle_block<MODE == T_NODE ? FRIEDA_B2_IDLE_T5_NODE : FRIEDA_B2_IDLE_NODE>(m, hc);
+        b2_merkle_block<TP ? FRIEDA_B2_IDLE_NODE : B2_LAT>(m, hc);
     }
     if (out_c) store_hash(out_c, g0 >> 2, hc);
     if (REG_ONLY) return;
@@ -297,7 +299,7 @@ __global__ __launch_bounds__(T5_THREADS) void tree5r_kernel(TreeArgs a) {
     if (t < 128) {
         uint32_t m[16], h[8];
         lds_children(RC, 256 + 4, t, m);
-        b2_merkle_block<MODE == T_NODE ? FRIEDA_B2_IDLE_T5_NODE : FRIEDA_B2_IDLE_NODE>(m, h);
+        b2_merkle_block<TP ? FRIEDA_B2_IDLE_NODE : B2_LAT>(m, h);
         if (out_d) store_hash(out_d, (wg_base >> 3) + t, h);
         lds_put(RD, 128 + 4, t, h);
     }
@@ -305,7 +307,7 @@ __global__ __launch_bounds__(T5_THREADS) void tree5r_kernel(TreeArgs a) {
     if (t < 64) {
         uint32_t m[16], h[8];
         lds_children(RD, 128 + 4, t, m);
-        b2_merkle_block<MODE == T_NODE ? FRIEDA_B2_IDLE_T5_NODE : FRIEDA_B2_IDLE_NODE>(m, h);
+        b2_merkle_block<TP ? FRIEDA_B2_IDLE_NODE : B2_LAT>(m, h);
         store_hash(out_e, (wg_base >> 4) + t, h);
         FR_CLOCK_END(g_clock_tree5r, h[0])
     }
@@ -583,7 +585,7 @@ __device__ __forceinline__ void tree9_upper(const TreeArgs& a, const uint32_t* R
     }
 }
 
-template <int MODE>
+template <int MODE, bool TP>
 __global__ __launch_bounds__(256) void tree9_kernel(TreeArgs a) {
     __shared__ __attribute__((aligned(16))) uint32_t RA[8 * (256 + 4)];
     __shared__ __attribute__((aligned(16))) uint32_t QQ[2 * QBUF_WORDS];
@@ -600,9 +602,9 @@ __global__ __launch_bounds__(256) void tree9_kernel(TreeArgs a) {
         if (MODE == T_NODE) {
             uint32_t m[16];
             load_children(a.children, g, m);
-            b2_merkle_block(m, h);
+            b2_merkle_block<TP ? FRIEDA_B2_IDLE_NODE : B2_LAT>(m, h);
         } else if (MODE == T_LEAF4) {
-            leaf_hash(a.cols[g], a.cols[a.col_stride + g], a.cols[2 * a.col_stride + g], a.cols[3 * a.col_stride + g], h);
+            leaf_hash<TP ? FRIEDA_B2_IDLE_LEAF : B2_LAT>(a.cols[g], a.cols[a.col_stride + g], a.cols[2 * a.col_stride + g], a.cols[3 * a.col_stride + g], h);
         } else {
             const QM31Mat alpha = qm_matrix({a.tr->alpha[0], a.tr->alpha[1], a.tr->alpha[2], a.tr->alpha[3]});
             uint32_t it = (MODE == T_FOLD_CIRCLE) ? inv_circle_twiddle(a.itw, a.n, g, a.inv_init_y) : a.itw[g];
@@ -611,7 +613,7 @@ __global__ __launch_bounds__(256) void tree9_kernel(TreeArgs a) {
             a.out_vals[a.out_stride + g] = r.b;
             a.out_vals[2 * a.out_stride + g] = r.c;
             a.out_vals[3 * a.out_stride + g] = r.d;
-            leaf_hash(r.a, r.b, r.c, r.d, h);
+            leaf_hash<TP ? FRIEDA_B2_IDLE_LEAF : B2_LAT>(r.a, r.b, r.c, r.d, h);
         }
         if (a.store_all && !a.skip_a) store_hash(a.layers + layer_off(a.tree_log, a.level_a), g, h);
         lds_put(RA, 256 + 4, t, h);
@@ -1163,6 +1165,10 @@ __global__ __launch_bounds__(256) void grind_dev_kernel(GrindArgs a) {
 //   T_SMALL  tree5<256>, 256-node workgroups, five levels: everything else (unaligned Level B buffers; < 2^8 nodes: a partial
 //            workgroup)
 enum TreeKernel { T_WIDE, T_WIDE3, T_NINE, T_SMALL };
+// the compression's throughput form pays from ~3 waves per SIMD on (256-thread workgroups: 3 per CU); latency-shaped launches keep
+// the plain form (microbenchmarks: no gain at 2 waves per SIMD, +12 % latency for a lone wave; tests/cpp/bench_api: 16 KiB .. 256 KiB
+// lone proofs 2 - 3 % slower, a lone 2^20 proof 8 % slower with the throughput form in every launch)
+bool tp_launch(const Tuning& tn, size_t workgroups) { return workgroups >= tn.tp_min_wgs; }
 constexpr uint32_t T9_MIN_LOG = 8;
 // tuning knobs (kernels.h Tuning: defaults = measured best): smallest launch of the register-subtree kernel; three-register-level form;
 // largest level-A size of the nine-level kernel; largest hand-over size of the top kernel
@@ -1196,32 +1202,33 @@ uint32_t launch_tree_a(const Launch& L, int mode, const TreeArgs& a, const char*
     const uint32_t units = (k == T_WIDE || k == T_WIDE3) ? T5_UNITS : 256u;
     const dim3 grid((unsigned)((total + units - 1) / units), L.batch);
     Scope scope(L, name, bytes_of(mode, a.level_a, levels));
+    const bool tp = tp_launch(*L.tune, (size_t)grid.x * grid.y);
     if (k == T_SMALL) {
         switch (mode) {
-            case T_LEAF4: tree5_kernel<T_LEAF4, 256><<<grid, T5_THREADS, 0, L.stream>>>(a); break;
-            case T_NODE: tree5_kernel<T_NODE, 256><<<grid, T5_THREADS, 0, L.stream>>>(a); break;
-            case T_FOLD_CIRCLE: tree5_kernel<T_FOLD_CIRCLE, 256><<<grid, T5_THREADS, 0, L.stream>>>(a); break;
-            default: tree5_kernel<T_FOLD_LINE, 256><<<grid, T5_THREADS, 0, L.stream>>>(a); break;
+            case T_LEAF4: if (tp) tree5_kernel<T_LEAF4, 256, true><<<grid, T5_THREADS, 0, L.stream>>>(a); else tree5_kernel<T_LEAF4, 256, false><<<grid, T5_THREADS, 0, L.stream>>>(a); break;
+            case T_NODE: if (tp) tree5_kernel<T_NODE, 256, true><<<grid, T5_THREADS, 0, L.stream>>>(a); else tree5_kernel<T_NODE, 256, false><<<grid, T5_THREADS, 0, L.stream>>>(a); break;
+            case T_FOLD_CIRCLE: if (tp) tree5_kernel<T_FOLD_CIRCLE, 256, true><<<grid, T5_THREADS, 0, L.stream>>>(a); else tree5_kernel<T_FOLD_CIRCLE, 256, false><<<grid, T5_THREADS, 0, L.stream>>>(a); break;
+            default: if (tp) tree5_kernel<T_FOLD_LINE, 256, true><<<grid, T5_THREADS, 0, L.stream>>>(a); else tree5_kernel<T_FOLD_LINE, 256, false><<<grid, T5_THREADS, 0, L.stream>>>(a); break;
         }
     } else if (k == T_NINE) {
         switch (mode) {
-            case T_LEAF4: tree9_kernel<T_LEAF4><<<grid, 256, 0, L.stream>>>(a); break;
-            case T_NODE: tree9_kernel<T_NODE><<<grid, 256, 0, L.stream>>>(a); break;
-            case T_FOLD_CIRCLE: tree9_kernel<T_FOLD_CIRCLE><<<grid, 256, 0, L.stream>>>(a); break;
-            default: tree9_kernel<T_FOLD_LINE><<<grid, 256, 0, L.stream>>>(a); break;
+            case T_LEAF4: if (tp) tree9_kernel<T_LEAF4, true><<<grid, 256, 0, L.stream>>>(a); else tree9_kernel<T_LEAF4, false><<<grid, 256, 0, L.stream>>>(a); break;
+            case T_NODE: if (tp) tree9_kernel<T_NODE, true><<<grid, 256, 0, L.stream>>>(a); else tree9_kernel<T_NODE, false><<<grid, 256, 0, L.stream>>>(a); break;
+            case T_FOLD_CIRCLE: if (tp) tree9_kernel<T_FOLD_CIRCLE, true><<<grid, 256, 0, L.stream>>>(a); else tree9_kernel<T_FOLD_CIRCLE, false><<<grid, 256, 0, L.stream>>>(a); break;
+            default: if (tp) tree9_kernel<T_FOLD_LINE, true><<<grid, 256, 0, L.stream>>>(a); else tree9_kernel<T_FOLD_LINE, false><<<grid, 256, 0, L.stream>>>(a); break;
         }
     } else if (k == T_WIDE3) {
         switch (mode) {
-            case T_LEAF4: tree5r_kernel<T_LEAF4, true><<<grid, T5_THREADS, 0, L.stream>>>(a); break;
-            case T_FOLD_CIRCLE: tree5r_kernel<T_FOLD_CIRCLE, true><<<grid, T5_THREADS, 0, L.stream>>>(a); break;
-            default: tree5r_kernel<T_FOLD_LINE, true><<<grid, T5_THREADS, 0, L.stream>>>(a); break;
+            case T_LEAF4: if (tp) tree5r_kernel<T_LEAF4, true, true><<<grid, T5_THREADS, 0, L.stream>>>(a); else tree5r_kernel<T_LEAF4, true, false><<<grid, T5_THREADS, 0, L.stream>>>(a); break;
+            case T_FOLD_CIRCLE: if (tp) tree5r_kernel<T_FOLD_CIRCLE, true, true><<<grid, T5_THREADS, 0, L.stream>>>(a); else tree5r_kernel<T_FOLD_CIRCLE, true, false><<<grid, T5_THREADS, 0, L.stream>>>(a); break;
+            default: if (tp) tree5r_kernel<T_FOLD_LINE, true, true><<<grid, T5_THREADS, 0, L.stream>>>(a); else tree5r_kernel<T_FOLD_LINE, true, false><<<grid, T5_THREADS, 0, L.stream>>>(a); break;
         }
     } else {
         switch (mode) {
-            case T_LEAF4: tree5r_kernel<T_LEAF4><<<grid, T5_THREADS, 0, L.stream>>>(a); break;
-            case T_NODE: tree5r_kernel<T_NODE><<<grid, T5_THREADS, 0, L.stream>>>(a); break;
-            case T_FOLD_CIRCLE: tree5r_kernel<T_FOLD_CIRCLE><<<grid, T5_THREADS, 0, L.stream>>>(a); break;
-            default: tree5r_kernel<T_FOLD_LINE><<<grid, T5_THREADS, 0, L.stream>>>(a); break;
+            case T_LEAF4: if (tp) tree5r_kernel<T_LEAF4, false, true><<<grid, T5_THREADS, 0, L.stream>>>(a); else tree5r_kernel<T_LEAF4, false, false><<<grid, T5_THREADS, 0, L.stream>>>(a); break;
+            case T_NODE: if (tp) tree5r_kernel<T_NODE, false, true><<<grid, T5_THREADS, 0, L.stream>>>(a); else tree5r_kernel<T_NODE, false, false><<<grid, T5_THREADS, 0, L.stream>>>(a); break;
+            case T_FOLD_CIRCLE: if (tp) tree5r_kernel<T_FOLD_CIRCLE, false, true><<<grid, T5_THREADS, 0, L.stream>>>(a); else tree5r_kernel<T_FOLD_CIRCLE, false, false><<<grid, T5_THREADS, 0, L.stream>>>(a); break;
+            default: if (tp) tree5r_kernel<T_FOLD_LINE, false, true><<<grid, T5_THREADS, 0, L.stream>>>(a); else tree5r_kernel<T_FOLD_LINE, false, false><<<grid, T5_THREADS, 0, L.stream>>>(a); break;
         }
     }
     return levels;
