@@ -109,22 +109,38 @@ FR_HD void b2_compress(const uint32_t (&h)[8], const uint32_t (&m)[16], uint32_t
 // enough: IR passes move pure arithmetic across it).  The statement's text is the s_nop; the compiler adds an s_nop 0 of its own in
 // front of the next VALU instruction after any inline asm, so N idle states = "s_nop N-2" (N = 1: empty text; N = 0: no statement).
 // IDLE = 0xABC: idle states at the boundaries slow -> fast (A), fast -> slow (B), slow -> slow (C: rotr 7 -> the next add3).
-template <int N>
+// PRIO (IDLE bits 12 - 13, 0 = off): the wave runs its SLOW runs at this priority and its fast runs at priority 0 (s_setprio at the
+// run boundaries, in the same statement as the idle states).  SET: -1 = the statement leaves the priority alone, else what it sets.
+template <int N, int SET = -1>
 __device__ __forceinline__ void b2_pin(uint32_t& a, uint32_t& b, uint32_t& c, uint32_t& d) {
     static_assert(N >= 0 && N <= 6, "idle states 0 .. 6");  // (more than 6 never paid: profiles/r05_blake2s_idle_sweep.txt)
-    if constexpr (N == 1) asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
-    if constexpr (N == 2) asm volatile("s_nop 0" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
-    if constexpr (N == 3) asm volatile("s_nop 1" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
-    if constexpr (N == 4) asm volatile("s_nop 2" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
-    if constexpr (N == 5) asm volatile("s_nop 3" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
-    if constexpr (N == 6) asm volatile("s_nop 4" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+    static_assert(SET >= -1 && SET <= 3, "wave priorities 0 .. 3");
+#define FR_B2_PIN(TXT) asm volatile(TXT : "+v"(a), "+v"(b), "+v"(c), "+v"(d))
+#define FR_B2_PIN_N(PRE)                                    \
+    do {                                                    \
+        if constexpr (N <= 1) FR_B2_PIN(PRE);               \
+        if constexpr (N == 2) FR_B2_PIN(PRE "s_nop 0");     \
+        if constexpr (N == 3) FR_B2_PIN(PRE "s_nop 1");     \
+        if constexpr (N == 4) FR_B2_PIN(PRE "s_nop 2");     \
+        if constexpr (N == 5) FR_B2_PIN(PRE "s_nop 3");     \
+        if constexpr (N == 6) FR_B2_PIN(PRE "s_nop 4");     \
+    } while (0)
+    if constexpr (SET < 0 && N >= 1) FR_B2_PIN_N("");
+    if constexpr (SET == 0) FR_B2_PIN_N("s_setprio 0\n\t");
+    if constexpr (SET == 1) FR_B2_PIN_N("s_setprio 1\n\t");
+    if constexpr (SET == 2) FR_B2_PIN_N("s_setprio 2\n\t");
+    if constexpr (SET == 3) FR_B2_PIN_N("s_setprio 3\n\t");
+#undef FR_B2_PIN_N
+#undef FR_B2_PIN
 }
 // one half-round (R: round, H: 0 = columns, 1 = diagonals); the four G functions are written out (no loops: the unroller gives up on
 // loops that carry inline asm once a kernel holds a few dozen compressions)
 template <int IDLE, int R, int H>
 __device__ __forceinline__ void b2_half_round_runs(uint32_t (&v)[16], const uint32_t (&m)[16]) {
     using b2detail::SIGMA;
-    constexpr int NA = (IDLE >> 8) & 15, NB = (IDLE >> 4) & 15, NC = IDLE & 15;
+    constexpr int NA = (IDLE >> 8) & 15, NB = (IDLE >> 4) & 15, NC = IDLE & 15, PRIO = (IDLE >> 12) & 3;
+    constexpr int LO = PRIO ? 0 : -1, HI = PRIO ? PRIO : -1;  // what the statements after a slow / after a fast run set
+    constexpr bool FIRST = (R == 0 && H == 0), LAST = (R == 9 && H == 1);
     constexpr int a0 = 0, a1 = 1, a2 = 2, a3 = 3;
     constexpr int b0 = H ? 5 : 4, b1 = H ? 6 : 5, b2 = H ? 7 : 6, b3 = H ? 4 : 7;
     constexpr int c0 = H ? 10 : 8, c1 = H ? 11 : 9, c2 = H ? 8 : 10, c3 = H ? 9 : 11;
@@ -140,27 +156,28 @@ __device__ __forceinline__ void b2_half_round_runs(uint32_t (&v)[16], const uint
 #define FR_B2_RD8(q) v[d##q] = b2detail::rotr(v[d##q], 8);
 #define FR_B2_RB12(q) v[b##q] = b2detail::rotr(v[b##q], 12);
 #define FR_B2_RB7(q) v[b##q] = b2detail::rotr(v[b##q], 7);
+    if constexpr (FIRST && PRIO != 0) b2_pin<0, HI>(v[a0], v[a1], v[a2], v[a3]);  // the compression opens with a slow run
     FR_B2_4(FR_B2_AX)
-    b2_pin<NA>(v[a0], v[a1], v[a2], v[a3]);
+    b2_pin<NA, LO>(v[a0], v[a1], v[a2], v[a3]);
     FR_B2_4(FR_B2_DX)
-    b2_pin<NB>(v[d0], v[d1], v[d2], v[d3]);
+    b2_pin<NB, HI>(v[d0], v[d1], v[d2], v[d3]);
     FR_B2_4(FR_B2_RD16)
-    b2_pin<NA>(v[d0], v[d1], v[d2], v[d3]);
+    b2_pin<NA, LO>(v[d0], v[d1], v[d2], v[d3]);
     FR_B2_4(FR_B2_CD)
     FR_B2_4(FR_B2_BX)
-    b2_pin<NB>(v[b0], v[b1], v[b2], v[b3]);
+    b2_pin<NB, HI>(v[b0], v[b1], v[b2], v[b3]);
     FR_B2_4(FR_B2_RB12)
     FR_B2_4(FR_B2_AY)
-    b2_pin<NA>(v[a0], v[a1], v[a2], v[a3]);
+    b2_pin<NA, LO>(v[a0], v[a1], v[a2], v[a3]);
     FR_B2_4(FR_B2_DX)
-    b2_pin<NB>(v[d0], v[d1], v[d2], v[d3]);
+    b2_pin<NB, HI>(v[d0], v[d1], v[d2], v[d3]);
     FR_B2_4(FR_B2_RD8)
-    b2_pin<NA>(v[d0], v[d1], v[d2], v[d3]);
+    b2_pin<NA, LO>(v[d0], v[d1], v[d2], v[d3]);
     FR_B2_4(FR_B2_CD)
     FR_B2_4(FR_B2_BX)
-    b2_pin<NB>(v[b0], v[b1], v[b2], v[b3]);
+    b2_pin<NB, HI>(v[b0], v[b1], v[b2], v[b3]);
     FR_B2_4(FR_B2_RB7)
-    b2_pin<NC>(v[b0], v[b1], v[b2], v[b3]);
+    b2_pin<LAST ? 0 : NC, LAST ? LO : -1>(v[b0], v[b1], v[b2], v[b3]);  // (and back to priority 0 at the end of the compression)
 #undef FR_B2_4
 #undef FR_B2_AX
 #undef FR_B2_AY
@@ -209,22 +226,28 @@ __device__ __forceinline__ void b2_merkle_block_runs(const uint32_t (&m)[16], ui
     b2_compress_runs<IDLE>(z, m, 0, 0, 0, 0, out);
 }
 #endif
-// idle states of the throughput form, per message shape (A/B knobs of the build: tools/build_variant.sh <name> -DFRIEDA_B2_IDLE_NODE=0x...)
-// 0x603: six idle states after every slow run that a fast run follows, none after a fast run, three between the two slow runs at the
-// half-round boundary — a local optimum of the per-position sweep (profiles/r05_blake2s_idle_sweep.txt, last blocks): 3290 - 3320 node /
-// 3130 - 3150 leaf cycles at 8 waves per SIMD (0x333: 3476 - 3506 / 3255), 3606 / 3496 at 4 waves (3808 / 3538)
+// settings of the throughput form, per message shape and kernel family (A/B knobs of the build: tools/build_variant.sh <name>
+// -DFRIEDA_B2_IDLE_NODE=0x...).  0xPABC: P = wave priority of the slow runs, A / B / C = idle states (above).
+//   idle states alone (0x603, the first form of this round): 3290 - 3320 node / 3130 - 3150 leaf cycles per wave-compression at 8 waves
+//   per SIMD, 3606 / 3496 at 4;  priority alone (0x2000): 2391 / 2260 at 8 waves, 2828 / 2716 at 4 (profiles/r05_blake2s_prio.txt) —
+//   960 instructions at one issue slot each is 2300.  In the product (profiles/r05_prio_product_ab.txt) the tree kernels are a little
+//   faster still with the idle states kept (0x2603), the fused transform + tree launch and the grind without them.
 #ifndef FRIEDA_B2_IDLE_NODE
-#define FRIEDA_B2_IDLE_NODE 0x603
+#define FRIEDA_B2_IDLE_NODE 0x2603
 #endif
 #ifndef FRIEDA_B2_IDLE_LEAF
-#define FRIEDA_B2_IDLE_LEAF 0x603
+#define FRIEDA_B2_IDLE_LEAF 0x2603
 #endif
 // the fused last transform pass + tree launch (ntt.hip) runs at 4 waves per SIMD (120 VGPRs), where the optimum differs
 #ifndef FRIEDA_B2_IDLE_NTT_NODE
-#define FRIEDA_B2_IDLE_NTT_NODE FRIEDA_B2_IDLE_NODE
+#define FRIEDA_B2_IDLE_NTT_NODE 0x2000
 #endif
 #ifndef FRIEDA_B2_IDLE_NTT_LEAF
-#define FRIEDA_B2_IDLE_NTT_LEAF FRIEDA_B2_IDLE_LEAF
+#define FRIEDA_B2_IDLE_NTT_LEAF 0x2000
+#endif
+// the grind (one compression per nonce with a chaining value: fri.hip, tree.hip)
+#ifndef FRIEDA_B2_IDLE_GRIND
+#define FRIEDA_B2_IDLE_GRIND 0x2000
 #endif
 // (which form a tree launch takes is decided per launch: tree.hip tp_launch — below ~3 waves per SIMD an idle state is pure delay)
 

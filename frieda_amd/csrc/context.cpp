@@ -125,6 +125,7 @@ const KnobDesc KNOBS[] = {
     {"FRIEDA_NTT_NO_PAD8", 0, 1, [](Tuning& t, long v) { t.ntt_no_pad8 = v != 0; return true; }},
     {"FRIEDA_NTT_TREE_REG_ONLY", 0, 1, [](Tuning& t, long v) { t.ntt_tree_reg_only = v != 0; return true; }},
     {"FRIEDA_NO_ENCODE_TREE_FUSION", 0, 1, [](Tuning& t, long v) { t.no_encode_tree_fusion = v != 0; return true; }},
+    {"FRIEDA_ENCODE_TREE_FUSION_PROVE", 0, 1, [](Tuning& t, long v) { t.encode_tree_fusion_prove = v != 0; return true; }},
     {"FRIEDA_NO_SMALL_FUSED", 0, 1, [](Tuning& t, long v) { t.no_small_fused = v != 0; return true; }},
     {"FRIEDA_UNPACK_TILES", 1, 8, [](Tuning& t, long v) {
          if (v != 1 && v != 2 && v != 4 && v != 8) return false;

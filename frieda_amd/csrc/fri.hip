@@ -108,7 +108,7 @@ __global__ __launch_bounds__(FR_THREADS) void grind_kernel(Digest8 dg, uint32_t 
     uint32_t h[8], r[8];
 #pragma unroll
     for (int i = 0; i < 8; i++) h[i] = dg.w[i];
-    b2_compress_tp<FRIEDA_B2_IDLE_LEAF>(h, m, 0, 0, 0, 0, r);  // (a chip-filling launch: the throughput form, blake2s.h)
+    b2_compress_tp<FRIEDA_B2_IDLE_GRIND>(h, m, 0, 0, 0, 0, r);  // (a chip-filling launch: the throughput form, blake2s.h)
     uint32_t tz;
     if (r[0])
         tz = __ffs(r[0]) - 1;

@@ -39,7 +39,8 @@ struct Tuning {
     bool ntt_no_pad8 = false;    // FRIEDA_NTT_NO_PAD8: no padded / 4-layer fast passes
     bool ntt_no_cp = false;      // FRIEDA_NTT_NO_CP: small fold2 launches as one 256-thread workgroup per tile (not four columns side by side)
     bool ntt_tree_reg_only = false;      // FRIEDA_NTT_TREE_REG_ONLY: the fused encode + leaf launch stops after its five register levels
-    bool no_encode_tree_fusion = false;  // FRIEDA_NO_ENCODE_TREE_FUSION: last transform pass and leaf launch as two kernels
+    bool no_encode_tree_fusion = false;  // FRIEDA_NO_ENCODE_TREE_FUSION: last transform pass and leaf launch as two kernels (commitments too)
+    bool encode_tree_fusion_prove = false;  // FRIEDA_ENCODE_TREE_FUSION_PROVE: the fused launch for proofs too (default: commitments only)
     bool no_small_fused = false;         // FRIEDA_NO_SMALL_FUSED: the general path for small domains too
     uint32_t unpack_tiles = 4;           // FRIEDA_UNPACK_TILES: 1, 2, 4 or 8 tiles of 256 quads per unpacker workgroup
     bool intt_generic = false;           // FRIEDA_INTT_GENERIC: every inverse pass through the generic one-column kernel

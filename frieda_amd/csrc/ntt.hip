@@ -56,7 +56,7 @@ __device__ __forceinline__ uint32_t pad(uint32_t e) { return e + (e >> 4); }
 // idle states after a slow run (A) and after a fast run (B); 0 = the plain form (butterfly by butterfly, the scheduler's order).
 // The twiddles of these stages are kept DOUBLED in their registers (2 tw mod 2^32 = 2 tw): one instruction fewer per butterfly.
 #ifndef FRIEDA_NTT_IDLE
-#define FRIEDA_NTT_IDLE 0x33
+#define FRIEDA_NTT_IDLE 0x200
 #endif
 #ifndef FRIEDA_NTT_GROUP
 #define FRIEDA_NTT_GROUP 8  // butterflies advanced together (8 = a whole layer; 4 halves the temporaries)
@@ -64,24 +64,42 @@ __device__ __forceinline__ uint32_t pad(uint32_t e) { return e + (e >> 4); }
 #ifndef FRIEDA_NTT_GROUP_FUSED
 #define FRIEDA_NTT_GROUP_FUSED 4  // in the kernels that keep all four columns in registers (120+ VGPRs)
 #endif
-template <int N, int G>
+// SET: the wave priority the statement sets (-1: leaves it alone) — bits 8 - 9 of FRIEDA_NTT_IDLE = the priority of the slow runs,
+// the fast runs at 0 (see blake2s.h b2_pin)
+// what a transform kernel runs at outside its butterflies (loads, LDS traffic, stores)
+#ifndef FRIEDA_NTT_OUTER_PRIO
+#define FRIEDA_NTT_OUTER_PRIO 3
+#endif
+__device__ __forceinline__ void ntt_enter() {
+    if constexpr (FRIEDA_NTT_OUTER_PRIO != 0 && ((FRIEDA_NTT_IDLE >> 8) & 3) != 0) __builtin_amdgcn_s_setprio(FRIEDA_NTT_OUTER_PRIO);
+}
+template <int N, int G, int SET = -1>
 __device__ __forceinline__ void ntt_pin(uint32_t (&a)[G]) {
-    static_assert(N >= 0 && N <= 5 && (G == 4 || G == 8), "idle states 0 .. 5, groups of 4 or 8");
+    static_assert(N >= 0 && N <= 5 && (G == 4 || G == 8) && SET >= -1 && SET <= 3, "idle states 0 .. 5, groups of 4 or 8, priorities 0 .. 3");
 #define FR_PIN_OPS4 "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3])
 #define FR_PIN_OPS8 "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7])
-    if constexpr (G == 8) {
-        if constexpr (N == 1) asm volatile("" : FR_PIN_OPS8);
-        if constexpr (N == 2) asm volatile("s_nop 0" : FR_PIN_OPS8);
-        if constexpr (N == 3) asm volatile("s_nop 1" : FR_PIN_OPS8);
-        if constexpr (N == 4) asm volatile("s_nop 2" : FR_PIN_OPS8);
-        if constexpr (N == 5) asm volatile("s_nop 3" : FR_PIN_OPS8);
-    } else {
-        if constexpr (N == 1) asm volatile("" : FR_PIN_OPS4);
-        if constexpr (N == 2) asm volatile("s_nop 0" : FR_PIN_OPS4);
-        if constexpr (N == 3) asm volatile("s_nop 1" : FR_PIN_OPS4);
-        if constexpr (N == 4) asm volatile("s_nop 2" : FR_PIN_OPS4);
-        if constexpr (N == 5) asm volatile("s_nop 3" : FR_PIN_OPS4);
-    }
+#define FR_PIN_N(PRE, ...)                                      \
+    do {                                                         \
+        if constexpr (N <= 1) asm volatile(PRE : __VA_ARGS__);           \
+        if constexpr (N == 2) asm volatile(PRE "s_nop 0" : __VA_ARGS__); \
+        if constexpr (N == 3) asm volatile(PRE "s_nop 1" : __VA_ARGS__); \
+        if constexpr (N == 4) asm volatile(PRE "s_nop 2" : __VA_ARGS__); \
+        if constexpr (N == 5) asm volatile(PRE "s_nop 3" : __VA_ARGS__); \
+    } while (0)
+#define FR_PIN_SET(...)                                              \
+    do {                                                             \
+        if constexpr (SET < 0 && N >= 1) FR_PIN_N("", __VA_ARGS__);          \
+        if constexpr (SET == 0) FR_PIN_N("s_setprio 0\n\t", __VA_ARGS__);    \
+        if constexpr (SET == 1) FR_PIN_N("s_setprio 1\n\t", __VA_ARGS__);    \
+        if constexpr (SET == 2) FR_PIN_N("s_setprio 2\n\t", __VA_ARGS__);    \
+        if constexpr (SET == 3) FR_PIN_N("s_setprio 3\n\t", __VA_ARGS__);    \
+    } while (0)
+    if constexpr (G == 8)
+        FR_PIN_SET(FR_PIN_OPS8);
+    else
+        FR_PIN_SET(FR_PIN_OPS4);
+#undef FR_PIN_SET
+#undef FR_PIN_N
 #undef FR_PIN_OPS4
 #undef FR_PIN_OPS8
 }
@@ -89,7 +107,8 @@ __device__ __forceinline__ void ntt_pin(uint32_t (&a)[G]) {
 // tw[(1 << Q) - 1 + (r >> (bit + 1))]
 template <int IDLE, int Q, int G, int K0, typename TW>
 __device__ __forceinline__ void radix16_group(uint32_t (&x)[16], const TW& tw) {
-    constexpr int bit = 3 - Q, NA = (IDLE >> 4) & 15, NB = IDLE & 15;
+    constexpr int bit = 3 - Q, NA = (IDLE >> 4) & 15, NB = IDLE & 15, PRIO = (IDLE >> 8) & 3;
+    constexpr int LO = PRIO ? 0 : -1, HI = PRIO ? PRIO : -1;  // what the statements after a slow / after a fast run set
     // the eight (low, high) index pairs of a layer
     constexpr int LOW[4][8] = {{0, 1, 2, 3, 4, 5, 6, 7}, {0, 1, 2, 3, 8, 9, 10, 11}, {0, 1, 4, 5, 8, 9, 12, 13}, {0, 2, 4, 6, 8, 10, 12, 14}};
     uint32_t hi[G], lo[G], d[G];
@@ -102,17 +121,17 @@ __device__ __forceinline__ void radix16_group(uint32_t (&x)[16], const TW& tw) {
         hi[k] = (uint32_t)(p >> 32);
         lo[k] = (uint32_t)p;
     }
-    ntt_pin<NA, G>(hi);  // (lo follows from the same multiply: pinning one of the two results orders both)
+    ntt_pin<NA, G, LO>(hi);  // (lo follows from the same multiply: pinning one of the two results orders both)
 #pragma unroll
     for (int k = 0; k < G; k++) {
         lo[k] >>= 1;
         lo[k] += hi[k];  // <= (P - 1) + P
         hi[k] = lo[k] - P31;
     }
-    ntt_pin<NB, G>(hi);
+    ntt_pin<NB, G, HI>(hi);
 #pragma unroll
     for (int k = 0; k < G; k++) lo[k] = umin32(lo[k], hi[k]);  // t = x_high * tw, canonical
-    ntt_pin<NA, G>(lo);
+    ntt_pin<NA, G, LO>(lo);
 #pragma unroll
     for (int k = 0; k < G; k++) {
         const int r = LOW[Q][K0 + k];
@@ -122,7 +141,7 @@ __device__ __forceinline__ void radix16_group(uint32_t (&x)[16], const TW& tw) {
         hi[k] = d[k] + P31;
         lo[k] = x[r] - P31;
     }
-    ntt_pin<NB, G>(lo);
+    ntt_pin<NB, G, HI>(lo);
 #pragma unroll
     for (int k = 0; k < G; k++) {
         const int r = LOW[Q][K0 + k];
@@ -142,6 +161,12 @@ __device__ __forceinline__ void radix16_stage(uint32_t (&x)[16], const TW& tw) {
         radix16_layer<FRIEDA_NTT_IDLE, 1, G>(x, tw);
         radix16_layer<FRIEDA_NTT_IDLE, 2, G>(x, tw);
         radix16_layer<FRIEDA_NTT_IDLE, 3, G>(x, tw);
+        if constexpr (((FRIEDA_NTT_IDLE >> 8) & 3) != 0) {  // back to the priority of everything that is not a butterfly (ntt_enter)
+            if constexpr (FRIEDA_NTT_OUTER_PRIO == 0) asm volatile("s_setprio 0" : "+v"(x[0]), "+v"(x[8]), "+v"(x[7]), "+v"(x[15]));
+            if constexpr (FRIEDA_NTT_OUTER_PRIO == 1) asm volatile("s_setprio 1" : "+v"(x[0]), "+v"(x[8]), "+v"(x[7]), "+v"(x[15]));
+            if constexpr (FRIEDA_NTT_OUTER_PRIO == 2) asm volatile("s_setprio 2" : "+v"(x[0]), "+v"(x[8]), "+v"(x[7]), "+v"(x[15]));
+            if constexpr (FRIEDA_NTT_OUTER_PRIO == 3) asm volatile("s_setprio 3" : "+v"(x[0]), "+v"(x[8]), "+v"(x[7]), "+v"(x[15]));
+        }
     } else {
 #pragma unroll
         for (int q = 0; q < 4; q++) {
@@ -324,6 +349,7 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_tile_kernel(NttArgs a) {
 // ------------------------------------------------------------------------------------------------
 template <int NS, int LOG_W>
 __global__ __launch_bounds__(NTT_THREADS) void ntt_tile12_kernel(NttArgs a) {
+    ntt_enter();
     __shared__ uint32_t lds[TILE_WORDS];
     const uint32_t g = threadIdx.x;
     const uint32_t nwb_log = a.i_lo - LOG_W;
@@ -443,6 +469,7 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_tile12_kernel(NttArgs a) {
 // ------------------------------------------------------------------------------------------------
 template <int COLS>
 __global__ __launch_bounds__(NTT_THREADS) void ntt_tile12_rep_kernel(NttArgs a) {
+    ntt_enter();
     constexpr int NS = 2;
     constexpr uint32_t LOG_W = MID_LOG_W;
     __shared__ uint32_t lds[TILE_WORDS];
@@ -639,6 +666,7 @@ FR_CLOCK_DECL(g_clock_ntt_last_tree)
 // TP: the compressions in the throughput form (launches of >= 768 tiles; below that the launch is a latency chain: tree.hip tp_launch)
 template <bool STORE_ALL, bool REG_ONLY, bool TP>
 __global__ __launch_bounds__(NTT_THREADS) void ntt_last_tree_kernel(NttTreeArgs A) {
+    ntt_enter();
     __shared__ uint32_t lds[TILE_WORDS];
     __shared__ __attribute__((aligned(16))) uint32_t RC[8 * (256 + 4)];
     __shared__ __attribute__((aligned(16))) uint32_t RD[8 * (128 + 4)];
@@ -779,6 +807,7 @@ struct NttFoldArgs {
 
 template <bool ACC>
 __global__ __launch_bounds__(NTT_THREADS) void ntt_last_fold_kernel(NttFoldArgs A) {
+    ntt_enter();
     __shared__ uint32_t lds[TILE_WORDS];
     const NttArgs& a = A.a;
     const uint32_t g = threadIdx.x, hblk = blockIdx.x;
@@ -845,6 +874,7 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_last_fold_kernel(NttFoldArgs 
 constexpr int NTT_CP_THREADS = 1024;
 template <bool ACC>
 __global__ __launch_bounds__(NTT_CP_THREADS) void ntt_last_fold_cp_kernel(NttFoldArgs A) {
+    ntt_enter();
     extern __shared__ uint32_t cp_lds[];
     const NttArgs& a = A.a;
     const uint32_t c = threadIdx.x >> 8, g = threadIdx.x & 255u, hblk = blockIdx.x;

@@ -209,6 +209,10 @@ __global__ __launch_bounds__(T5_THREADS) void tree5r_kernel(TreeArgs a) {
     uint8_t* out_e = a.store_all ? a.layers + layer_off(a.tree_log, a.level_a - 4) : a.last_out;
 
     // the four level-A inputs of this thread, one uint4 per column: loaded (LEAF4) or folded from the previous layer (FOLD)
+#ifndef FRIEDA_T5R_LOAD_PRIO
+#define FRIEDA_T5R_LOAD_PRIO 3
+#endif
+    if (TP && FRIEDA_T5R_LOAD_PRIO != 0) __builtin_amdgcn_s_setprio(FRIEDA_T5R_LOAD_PRIO);
     uint4 lc0 = {}, lc1 = {}, lc2 = {}, lc3 = {};
     if (MODE == T_LEAF4) {
         lc0 = *reinterpret_cast<const uint4*>(a.cols + g0);
@@ -1141,7 +1145,7 @@ __global__ __launch_bounds__(256) void grind_dev_kernel(GrindArgs a) {
             if (__hip_atomic_load(&tr->nonce, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < nonce) break;
             const uint32_t m[16] = {(uint32_t)nonce, (uint32_t)(nonce >> 32), 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
             uint32_t r[8];
-            b2_compress_tp<FRIEDA_B2_IDLE_LEAF>(h, m, 0, 0, 0, 0, r);  // (a chip-filling launch: the throughput form, blake2s.h)
+            b2_compress_tp<FRIEDA_B2_IDLE_GRIND>(h, m, 0, 0, 0, 0, r);  // (a chip-filling launch: the throughput form, blake2s.h)
             uint32_t tz;
             if (r[0])
                 tz = __ffs(r[0]) - 1;
@@ -1320,7 +1324,12 @@ void encode_and_first_tree(const Launch& L, const uint32_t* d_coef, size_t coef_
     // the chip idles while 32 - 128 workgroups each run ~32 compressions per thread; the separate transform + 256-leaf tree launches
     // spread the same work over 16 times the workgroups (commit of 64 KiB: 123 -> 76 us, of 256 KiB: 133 -> 121; from 256 tiles on the
     // fused launch is ahead again: 120 vs 136 us at 2^20).  Batches count: 64 blobs of 64 KiB are 2048 tiles.
-    const bool no_fuse = L.tune->no_encode_tree_fusion /* A/B knob */ || (((size_t)1 << (n > 12 ? n - 12 : 0)) * L.batch < 256);
+    // With every level KEPT (a proof) the two launches win at every size since the compressions switch wave priority (blake2s.h): the
+    // tree launch runs 8 waves per SIMD, the fused one 4 (120 VGPRs), and a compression costs 2390 against 2830 cycles there (stream of
+    // 2^24 proofs 1.50 vs 1.55 ms, 2^22 0.404 vs 0.415, lone 2^21 0.655 vs 0.680; profiles/r05_prio_product_ab.txt).  A commitment
+    // (nothing kept) stays fused: the evaluations are never written (lone 2^24 0.785 vs 0.830 ms, stream 0.77 vs 0.85).
+    const bool no_fuse = L.tune->no_encode_tree_fusion /* A/B knob */ || (((size_t)1 << (n > 12 ? n - 12 : 0)) * L.batch < 256) ||
+                         (d_layers != nullptr && !L.tune->encode_tree_fusion_prove /* A/B knob */);
     uint8_t* s0 = d_scratch;
     uint8_t* s1 = d_scratch ? d_scratch + ((size_t)32 << (n > 4 ? n - 4 : 0)) : nullptr;
     EncodeTreeSink sink{d_layers, s0};

@@ -176,7 +176,7 @@ def test_blake2s_ceiling_is_plausible(gpu_ctx):
     """frieda_ctx_blake2s_ceiling: tens of G compressions per second on an MI355X; leaf-shaped messages are cheaper than node-shaped."""
     leaf, node = gpu_ctx.blake2s_ceiling()
     ex = gpu_ctx.blake2s_ceiling_ex()
-    assert 1.2 < ex["node_clock_ghz"] < 3.0 and 2500 < ex["node_cycles_per_wave_compression"] < 6000 and ex["leaf_per_s"] > 1e10
+    assert 1.2 < ex["node_clock_ghz"] < 3.0 and 1900 < ex["node_cycles_per_wave_compression"] < 6000 and ex["leaf_per_s"] > 1e10
     assert 1e10 < node < 1e11 and 1e10 < leaf < 1e11 and leaf > 0.98 * node
 
 

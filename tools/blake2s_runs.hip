@@ -418,6 +418,96 @@ __global__ __launch_bounds__(256, WAVES) void chain_p_kernel(uint32_t* out, int 
     out[blockIdx.x * 256 + threadIdx.x] = s;
 }
 
+// ---- K = 1, wave PRIORITY switched at the run boundaries (s_setprio), with or without the idle states of 6-0-3 ----
+// V: 1 = slow runs at priority 2, fast runs at 0, with idle states; 2 = the opposite, with idle states; 3 / 4 = the same two without
+template <int V, int KIND>  // KIND: 0 = after a slow run that a fast run follows, 1 = after a fast run, 2 = slow -> slow
+__device__ __forceinline__ void pin_prio(uint32_t& a, uint32_t& b, uint32_t& c, uint32_t& d) {
+    if constexpr (V == 1 && KIND == 0) asm volatile("s_setprio 0\n\ts_nop 4" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+    if constexpr (V == 1 && KIND == 1) asm volatile("s_setprio 2" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+    if constexpr (V == 1 && KIND == 2) asm volatile("s_nop 1" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+    if constexpr (V == 2 && KIND == 0) asm volatile("s_setprio 2\n\ts_nop 4" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+    if constexpr (V == 2 && KIND == 1) asm volatile("s_setprio 0" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+    if constexpr (V == 2 && KIND == 2) asm volatile("s_nop 1" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+    if constexpr (V == 3 && KIND == 0) asm volatile("s_setprio 0" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+    if constexpr (V == 3 && KIND == 1) asm volatile("s_setprio 2" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+    if constexpr (V == 3 && KIND == 2) asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+    if constexpr (V == 4 && KIND == 0) asm volatile("s_setprio 2" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+    if constexpr (V == 4 && KIND == 1) asm volatile("s_setprio 0" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+    if constexpr (V == 4 && KIND == 2) asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+}
+template <int LEAF, int V>
+__device__ __forceinline__ void half_round_prio(uint32_t (&v)[16], const uint32_t (&m)[16], const int (&ia)[4], const int (&ib)[4], const int (&ic)[4],
+                                                const int (&id)[4], const uint8_t* sx) {
+#define PQ(KIND, ix) pin_prio<V, KIND>(v[ix[0]], v[ix[1]], v[ix[2]], v[ix[3]])
+#define FQ for (int q = 0; q < 4; q++)
+    _Pragma("unroll") FQ {
+        const int x = sx[2 * q];
+        v[ia[q]] = v[ia[q]] + v[ib[q]] + ((LEAF && x >= 4) ? 0u : m[x]);
+    }
+    PQ(0, ia);
+    _Pragma("unroll") FQ v[id[q]] ^= v[ia[q]];
+    PQ(1, id);
+    _Pragma("unroll") FQ v[id[q]] = b2detail::rotr(v[id[q]], 16);
+    PQ(0, id);
+    _Pragma("unroll") FQ v[ic[q]] += v[id[q]];
+    _Pragma("unroll") FQ v[ib[q]] ^= v[ic[q]];
+    PQ(1, ib);
+    _Pragma("unroll") FQ v[ib[q]] = b2detail::rotr(v[ib[q]], 12);
+    _Pragma("unroll") FQ {
+        const int y = sx[2 * q + 1];
+        v[ia[q]] = v[ia[q]] + v[ib[q]] + ((LEAF && y >= 4) ? 0u : m[y]);
+    }
+    PQ(0, ia);
+    _Pragma("unroll") FQ v[id[q]] ^= v[ia[q]];
+    PQ(1, id);
+    _Pragma("unroll") FQ v[id[q]] = b2detail::rotr(v[id[q]], 8);
+    PQ(0, id);
+    _Pragma("unroll") FQ v[ic[q]] += v[id[q]];
+    _Pragma("unroll") FQ v[ib[q]] ^= v[ic[q]];
+    PQ(1, ib);
+    _Pragma("unroll") FQ v[ib[q]] = b2detail::rotr(v[ib[q]], 7);
+    PQ(2, ib);
+#undef FQ
+#undef PQ
+}
+template <int LEAF, int WAVES, int V>
+__global__ __launch_bounds__(256, WAVES) void chain_prio_kernel(uint32_t* out, int iters, Stamp* st) {
+    using b2detail::IV;
+    using b2detail::SIGMA;
+    uint32_t m[16], h[8];
+    for (int i = 0; i < 16; i++) m[i] = threadIdx.x * 2654435761u + i * 40503u + blockIdx.x;
+    for (int i = 0; i < 8; i++) h[i] = 0;
+    unsigned long long c0, r0, c1, r1;
+    stamp_pair(c0, r0);
+    asm volatile("" : "+v"(m[0]) : "s"(c0));
+    constexpr int ca[4] = {0, 1, 2, 3}, cb[4] = {4, 5, 6, 7}, cc[4] = {8, 9, 10, 11}, cd[4] = {12, 13, 14, 15};
+    constexpr int db[4] = {5, 6, 7, 4}, dc[4] = {10, 11, 8, 9}, dd[4] = {15, 12, 13, 14};
+    for (int it = 0; it < iters; it++) {
+        uint32_t v[16];
+        for (int i = 0; i < 8; i++) v[i] = 0u, v[8 + i] = IV[i];
+#pragma unroll
+        for (int r = 0; r < 10; r++) {
+            half_round_prio<LEAF, V>(v, m, ca, cb, cc, cd, &SIGMA[r][0]);
+            half_round_prio<LEAF, V>(v, m, ca, db, dc, dd, &SIGMA[r][8]);
+        }
+        for (int i = 0; i < 8; i++) h[i] = v[i] ^ v[8 + i];
+        if (LEAF) {
+            for (int i = 0; i < 4; i++) m[i] = h[i] ^ h[4 + i];
+        } else {
+            for (int i = 0; i < 8; i++) {
+                m[i] ^= h[i];
+                m[8 + i] += h[i];
+            }
+        }
+    }
+    asm volatile("s_setprio 0" ::"v"(h[0]), "v"(h[7]));
+    stamp_pair(c1, r1);
+    if (threadIdx.x == 0) st[blockIdx.x] = Stamp{c0, r0, c1, r1};
+    uint32_t s = 0;
+    for (int i = 0; i < 8; i++) s += h[i];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+
 typedef void (*kern_t)(uint32_t*, int, Stamp*);
 
 static double run(const char* name, kern_t kfn, int K, int waves, double seconds) {
@@ -483,6 +573,22 @@ static double run(const char* name, kern_t kfn, int K, int waves, double seconds
 
 int main(int argc, char** argv) {
     const double secs = argc > 1 ? atof(argv[1]) : 0.5;
+    if (argc > 2 && argv[2][0] == 's') {  // wave priority switched at the run boundaries
+        RUN_N(0, 8, 6, 0, 3); RUN_N(1, 8, 6, 0, 3);
+        run("node prio: slow runs high, idle states 6-0-3", chain_prio_kernel<0, 8, 1>, 1, 8, secs);
+        run("leaf prio: slow runs high, idle states 6-0-3", chain_prio_kernel<1, 8, 1>, 1, 8, secs);
+        run("node prio: fast runs high, idle states 6-0-3", chain_prio_kernel<0, 8, 2>, 1, 8, secs);
+        run("leaf prio: fast runs high, idle states 6-0-3", chain_prio_kernel<1, 8, 2>, 1, 8, secs);
+        run("node prio: slow runs high, no idle states", chain_prio_kernel<0, 8, 3>, 1, 8, secs);
+        run("leaf prio: slow runs high, no idle states", chain_prio_kernel<1, 8, 3>, 1, 8, secs);
+        run("node prio: fast runs high, no idle states", chain_prio_kernel<0, 8, 4>, 1, 8, secs);
+        run("leaf prio: fast runs high, no idle states", chain_prio_kernel<1, 8, 4>, 1, 8, secs);
+        run("node prio: slow runs high, idle states, 4 waves", chain_prio_kernel<0, 4, 1>, 1, 4, secs);
+        run("leaf prio: slow runs high, idle states, 4 waves", chain_prio_kernel<1, 4, 1>, 1, 4, secs);
+        run("node prio: fast runs high, idle states, 4 waves", chain_prio_kernel<0, 4, 2>, 1, 4, secs);
+        run("leaf prio: fast runs high, idle states, 4 waves", chain_prio_kernel<1, 4, 2>, 1, 4, secs);
+        return 0;
+    }
     if (argc > 2 && argv[2][0] == 'p') {  // per-position idle states, one coordinate at a time around 6-0-6-0-6-0-6-0-3
 #define RUN_P(W, ...)                                                                              \
     do {                                                                                           \
