@@ -233,10 +233,10 @@ __device__ __forceinline__ void b2_merkle_block_runs(const uint32_t (&m)[16], ui
 //   960 instructions at one issue slot each is 2300.  In the product (profiles/r05_prio_product_ab.txt) the tree kernels are a little
 //   faster still with the idle states kept (0x2603), the fused transform + tree launch and the grind without them.
 #ifndef FRIEDA_B2_IDLE_NODE
-#define FRIEDA_B2_IDLE_NODE 0x2603
+#define FRIEDA_B2_IDLE_NODE 0x2000
 #endif
 #ifndef FRIEDA_B2_IDLE_LEAF
-#define FRIEDA_B2_IDLE_LEAF 0x2603
+#define FRIEDA_B2_IDLE_LEAF 0x2000
 #endif
 // the fused last transform pass + tree launch (ntt.hip) runs at 4 waves per SIMD (120 VGPRs), where the optimum differs
 #ifndef FRIEDA_B2_IDLE_NTT_NODE

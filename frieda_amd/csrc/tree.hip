@@ -121,6 +121,17 @@ namespace {
 
 // TP: the compressions in the throughput form (blake2s.h) — chosen by the launcher for launches that fill the chip (tp_launch): below
 // ~3 waves per SIMD an idle state is pure delay (a lone 2^20 proof 0.56 -> 0.61 ms with the throughput form everywhere)
+// In the chip-filling launches a wave runs its prologue — the loads of its inputs and the fold arithmetic — at a priority above the
+// compressions' slow runs (blake2s.h): its loads are in flight before it competes for the vector pipe, and the folds do not queue
+// behind eight waves' worth of compressions (tree5_fold_circle 335 -> 296 us, tree5_fold_line 553 -> 520, tree5_leaf 528 -> 512;
+// profiles/r05_prio_product_ab.txt).  The first compression's first statement sets the compressions' own priorities.
+#ifndef FRIEDA_T5R_LOAD_PRIO
+#define FRIEDA_T5R_LOAD_PRIO 3
+#endif
+__device__ __forceinline__ void tree_prologue_priority() {
+    if constexpr (FRIEDA_T5R_LOAD_PRIO != 0) __builtin_amdgcn_s_setprio(FRIEDA_T5R_LOAD_PRIO);
+}
+
 template <int MODE, uint32_t UNITS, bool TP>
 __global__ __launch_bounds__(T5_THREADS) void tree5_kernel(TreeArgs a) {
     __shared__ __attribute__((aligned(16))) uint32_t RA[8 * (UNITS + 4)];
@@ -209,10 +220,7 @@ __global__ __launch_bounds__(T5_THREADS) void tree5r_kernel(TreeArgs a) {
     uint8_t* out_e = a.store_all ? a.layers + layer_off(a.tree_log, a.level_a - 4) : a.last_out;
 
     // the four level-A inputs of this thread, one uint4 per column: loaded (LEAF4) or folded from the previous layer (FOLD)
-#ifndef FRIEDA_T5R_LOAD_PRIO
-#define FRIEDA_T5R_LOAD_PRIO 3
-#endif
-    if (TP && FRIEDA_T5R_LOAD_PRIO != 0) __builtin_amdgcn_s_setprio(FRIEDA_T5R_LOAD_PRIO);
+    if (TP) tree_prologue_priority();
     uint4 lc0 = {}, lc1 = {}, lc2 = {}, lc3 = {};
     if (MODE == T_LEAF4) {
         lc0 = *reinterpret_cast<const uint4*>(a.cols + g0);

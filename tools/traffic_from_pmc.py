@@ -29,10 +29,10 @@ RULES = [
     (r"tree5_kernel<1, ", "tree5_node", 2.0),
     (r"tree5_kernel<2, ", "tree5_fold_circle", 2.0),
     (r"tree5_kernel<3, ", "tree5_fold_line", 2.0),
-    (r"tree9_kernel<0>", "tree5_leaf", 2.0),
-    (r"tree9_kernel<1>", "tree5_node", 2.0),
-    (r"tree9_kernel<2>", "tree5_fold_circle", 2.0),
-    (r"tree9_kernel<3>", "tree5_fold_line", 2.0),
+    (r"tree9_kernel<0, ", "tree5_leaf", 2.0),
+    (r"tree9_kernel<1, ", "tree5_node", 2.0),
+    (r"tree9_kernel<2, ", "tree5_fold_circle", 2.0),
+    (r"tree9_kernel<3, ", "tree5_fold_line", 2.0),
     (r"tree7q_kernel", "tree7q_node", 2.0),
     (r"top_kernel", "tree_top", 2.0),
     (r"tail_kernel", "fri_tail", 2.0),
