@@ -96,21 +96,26 @@ FR_HD void b2_compress(const uint32_t (&h)[8], const uint32_t (&m)[16], uint32_t
 
 #if defined(__HIP_DEVICE_COMPILE__)
 // ---- throughput form for the chip-filling kernels (round 5; profiles/r05_issue_pattern.txt, r05_blake2s_runs.txt,
-// r05_blake2s_idle_sweep.txt) ----
-// What a gfx950 SIMD sustains on this instruction stream depends on HOW the stream is laid out, not only on its instruction count:
+// r05_blake2s_idle_sweep.txt, r05_issue_overlap.txt, r05_blake2s_prio.txt) ----
+// What a gfx950 SIMD sustains on this instruction stream depends on HOW the stream is laid out and on WHICH WAVE the arbiter serves,
+// not only on its instruction count:
 //  * a fine interleave of fast-class (v_xor / v_add) and slow-class (v_alignbit / v_add3) instructions — what the scheduler emits when
 //    left alone (average run 2.1) — costs 3975 SIMD cycles per wave-compression (node shape, 8 waves per SIMD);
 //  * the same instructions as RUNS of one class (the four columns / diagonals advance one G step at a time): 3860;
-//  * and with a few IDLE issue states (s_nop) between the runs: 3290 - 3320 (node), 3130 - 3150 (leaf, from 3810) — 17 - 18 % fewer
-//    cycles for ~250 extra (scalar) instructions.  The waves of a SIMD hand the vector pipe to each other at the run boundaries
-//    instead of contending instruction by instruction; the optimum is occupancy-dependent (nothing to gain at 2 waves per SIMD).
+//  * with a few IDLE issue states (s_nop) between the runs: 3290 - 3320 (the first half of the round);
+//  * with the wave's PRIORITY raised for its slow runs and dropped for its fast runs (s_setprio at the run boundaries): 2310 - 2430.
+//    The pipe overlaps a slow instruction of one wave with a fast instruction of ANOTHER wave (four waves of v_alignbit + four of
+//    v_xor on a SIMD take 0.72 of the sum of the two alone, tools/issue_overlap.hip), but the arbiter — priority, then age — does not
+//    look for such pairs; with the slow runs prioritised the waves in a slow run always win, the others fill in with their fast runs,
+//    and the stream issues at ~2.5 cycles per instruction whatever its class.  The other way round (fast runs raised) costs 4000.
 // The runs are pinned by data flow: one volatile asm statement takes the four values a step has just written as read-write
 // operands, so the step's instructions lie between two such statements at every level of the compiler (a scheduling barrier is not
-// enough: IR passes move pure arithmetic across it).  The statement's text is the s_nop; the compiler adds an s_nop 0 of its own in
-// front of the next VALU instruction after any inline asm, so N idle states = "s_nop N-2" (N = 1: empty text; N = 0: no statement).
-// IDLE = 0xABC: idle states at the boundaries slow -> fast (A), fast -> slow (B), slow -> slow (C: rotr 7 -> the next add3).
-// PRIO (IDLE bits 12 - 13, 0 = off): the wave runs its SLOW runs at this priority and its fast runs at priority 0 (s_setprio at the
-// run boundaries, in the same statement as the idle states).  SET: -1 = the statement leaves the priority alone, else what it sets.
+// enough: IR passes move pure arithmetic across it).  The statement's text is the s_setprio and / or the s_nop; the compiler adds
+// an s_nop 0 of its own in front of the next VALU instruction after any inline asm, so N idle states = "s_nop N-2" (N = 1: empty
+// text; N = 0 without a priority: no statement).
+// IDLE = 0xABC: idle states at the boundaries slow -> fast (A), fast -> slow (B), slow -> slow (C: rotr 7 -> the next add3);
+// bits 12 - 13 / 14 - 15: the priorities of the slow runs (b2_half_round_runs).  SET: -1 = the statement leaves the priority
+// alone, else what it sets.
 template <int N, int SET = -1>
 __device__ __forceinline__ void b2_pin(uint32_t& a, uint32_t& b, uint32_t& c, uint32_t& d) {
     static_assert(N >= 0 && N <= 6, "idle states 0 .. 6");  // (more than 6 never paid: profiles/r05_blake2s_idle_sweep.txt)
@@ -138,8 +143,10 @@ __device__ __forceinline__ void b2_pin(uint32_t& a, uint32_t& b, uint32_t& c, ui
 template <int IDLE, int R, int H>
 __device__ __forceinline__ void b2_half_round_runs(uint32_t (&v)[16], const uint32_t (&m)[16]) {
     using b2detail::SIGMA;
-    constexpr int NA = (IDLE >> 8) & 15, NB = (IDLE >> 4) & 15, NC = IDLE & 15, PRIO = (IDLE >> 12) & 3;
-    constexpr int LO = PRIO ? 0 : -1, HI = PRIO ? PRIO : -1;  // what the statements after a slow / after a fast run set
+    constexpr int NA = (IDLE >> 8) & 15, NB = (IDLE >> 4) & 15, NC = IDLE & 15, PRIO = (IDLE >> 12) & 3, PADD = (IDLE >> 14) & 3;
+    // what the statements set: LO before a fast run, HI before a run of rotates, HA before a run that holds the v_add3 (bits 14 - 15,
+    // 0 = as the rotates).  Rotates above add3 above the fast class measures 3 - 4 % below one raised level (r05_blake2s_prio.txt).
+    constexpr int LO = PRIO ? 0 : -1, HI = PRIO ? PRIO : -1, HA = PRIO ? (PADD ? PADD : PRIO) : -1;
     constexpr bool FIRST = (R == 0 && H == 0), LAST = (R == 9 && H == 1);
     constexpr int a0 = 0, a1 = 1, a2 = 2, a3 = 3;
     constexpr int b0 = H ? 5 : 4, b1 = H ? 6 : 5, b2 = H ? 7 : 6, b3 = H ? 4 : 7;
@@ -156,7 +163,7 @@ __device__ __forceinline__ void b2_half_round_runs(uint32_t (&v)[16], const uint
 #define FR_B2_RD8(q) v[d##q] = b2detail::rotr(v[d##q], 8);
 #define FR_B2_RB12(q) v[b##q] = b2detail::rotr(v[b##q], 12);
 #define FR_B2_RB7(q) v[b##q] = b2detail::rotr(v[b##q], 7);
-    if constexpr (FIRST && PRIO != 0) b2_pin<0, HI>(v[a0], v[a1], v[a2], v[a3]);  // the compression opens with a slow run
+    if constexpr (FIRST && PRIO != 0) b2_pin<0, HA>(v[a0], v[a1], v[a2], v[a3]);  // the compression opens with a slow run
     FR_B2_4(FR_B2_AX)
     b2_pin<NA, LO>(v[a0], v[a1], v[a2], v[a3]);
     FR_B2_4(FR_B2_DX)
@@ -165,7 +172,7 @@ __device__ __forceinline__ void b2_half_round_runs(uint32_t (&v)[16], const uint
     b2_pin<NA, LO>(v[d0], v[d1], v[d2], v[d3]);
     FR_B2_4(FR_B2_CD)
     FR_B2_4(FR_B2_BX)
-    b2_pin<NB, HI>(v[b0], v[b1], v[b2], v[b3]);
+    b2_pin<NB, HA>(v[b0], v[b1], v[b2], v[b3]);
     FR_B2_4(FR_B2_RB12)
     FR_B2_4(FR_B2_AY)
     b2_pin<NA, LO>(v[a0], v[a1], v[a2], v[a3]);
@@ -177,7 +184,8 @@ __device__ __forceinline__ void b2_half_round_runs(uint32_t (&v)[16], const uint
     FR_B2_4(FR_B2_BX)
     b2_pin<NB, HI>(v[b0], v[b1], v[b2], v[b3]);
     FR_B2_4(FR_B2_RB7)
-    b2_pin<LAST ? 0 : NC, LAST ? LO : -1>(v[b0], v[b1], v[b2], v[b3]);  // (and back to priority 0 at the end of the compression)
+    // (the next half-round opens with the add3 run; back to priority 0 at the end of the compression)
+    b2_pin<LAST ? 0 : NC, LAST ? LO : (HA != HI ? HA : -1)>(v[b0], v[b1], v[b2], v[b3]);
 #undef FR_B2_4
 #undef FR_B2_AX
 #undef FR_B2_AY
@@ -227,27 +235,29 @@ __device__ __forceinline__ void b2_merkle_block_runs(const uint32_t (&m)[16], ui
 }
 #endif
 // settings of the throughput form, per message shape and kernel family (A/B knobs of the build: tools/build_variant.sh <name>
-// -DFRIEDA_B2_IDLE_NODE=0x...).  0xPABC: P = wave priority of the slow runs, A / B / C = idle states (above).
-//   idle states alone (0x603, the first form of this round): 3290 - 3320 node / 3130 - 3150 leaf cycles per wave-compression at 8 waves
-//   per SIMD, 3606 / 3496 at 4;  priority alone (0x2000): 2391 / 2260 at 8 waves, 2828 / 2716 at 4 (profiles/r05_blake2s_prio.txt) —
-//   960 instructions at one issue slot each is 2300.  In the product (profiles/r05_prio_product_ab.txt) the tree kernels are a little
-//   faster still with the idle states kept (0x2603), the fused transform + tree launch and the grind without them.
+// -DFRIEDA_B2_IDLE_NODE=0x...).  0xQPABC in bit fields: bits 12 - 13 P = wave priority of the runs of rotates, bits 14 - 15 Q = of
+// the runs that hold the v_add3 (0 = P), A / B / C = idle states (above).  SIMD cycles per wave-compression, node / leaf shape,
+// 8 waves per SIMD (tools/blake2s_runs.hip; profiles/r05_blake2s_idle_sweep.txt, r05_blake2s_prio.txt):
+//   the scheduler's own order 3975 / 3810;  idle states alone (0x603, the first form of this round) 3290 - 3320 / 3130 - 3150;
+//   one raised priority for every slow run (0x2000) 2370 - 2430 / 2250 - 2290 (2690 / 2460 at 4 waves, 3200 / 2960 at 2);
+//   rotates 3, add3 runs 2 (0xB000, the default) 2310 - 2350 / 2190 - 2260;  the idle states on top of the priorities 2440 / 2350.
+// In the product (profiles/r05_prio_product_ab.txt) 0x2000, 0x2603 and 0xB000 are within a per cent of each other.
 #ifndef FRIEDA_B2_IDLE_NODE
-#define FRIEDA_B2_IDLE_NODE 0x2000
+#define FRIEDA_B2_IDLE_NODE 0xB000
 #endif
 #ifndef FRIEDA_B2_IDLE_LEAF
-#define FRIEDA_B2_IDLE_LEAF 0x2000
+#define FRIEDA_B2_IDLE_LEAF 0xB000
 #endif
-// the fused last transform pass + tree launch (ntt.hip) runs at 4 waves per SIMD (120 VGPRs), where the optimum differs
+// the fused last transform pass + tree launch (ntt.hip: 4 waves per SIMD, 120 VGPRs) has its own pair of knobs
 #ifndef FRIEDA_B2_IDLE_NTT_NODE
-#define FRIEDA_B2_IDLE_NTT_NODE 0x2000
+#define FRIEDA_B2_IDLE_NTT_NODE 0xB000
 #endif
 #ifndef FRIEDA_B2_IDLE_NTT_LEAF
-#define FRIEDA_B2_IDLE_NTT_LEAF 0x2000
+#define FRIEDA_B2_IDLE_NTT_LEAF 0xB000
 #endif
 // the grind (one compression per nonce with a chaining value: fri.hip, tree.hip)
 #ifndef FRIEDA_B2_IDLE_GRIND
-#define FRIEDA_B2_IDLE_GRIND 0x2000
+#define FRIEDA_B2_IDLE_GRIND 0xB000
 #endif
 // (which form a tree launch takes is decided per launch: tree.hip tp_launch — below ~3 waves per SIMD an idle state is pure delay)
 

@@ -434,6 +434,18 @@ __device__ __forceinline__ void pin_prio(uint32_t& a, uint32_t& b, uint32_t& c, 
     if constexpr (V == 4 && KIND == 0) asm volatile("s_setprio 2" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
     if constexpr (V == 4 && KIND == 1) asm volatile("s_setprio 0" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
     if constexpr (V == 4 && KIND == 2) asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+    // KIND 3 = before a run of rotates only (KIND 1 then = before the rotate-12 + add3 run, KIND 2 = before the add3 run of the next half-round)
+    // V 5: rotate runs at 3, runs with add3 at 2, fast 0;  6: rotate runs 2, add3 runs 3;  7: slow 2, fast 1
+    if constexpr (V <= 4 && KIND == 3) pin_prio<V, 1>(a, b, c, d);
+    // KIND 4 = before the short fast run d ^= a (KIND 0 then = before the long fast run c += d, b ^= c);  V 8: short fast run 1, long 0;  9: short 0, long 1
+    if constexpr (V <= 7 && KIND == 4) pin_prio<V, 0>(a, b, c, d);
+#define PP(v_, k_, txt) if constexpr (V == v_ && KIND == k_) asm volatile(txt : "+v"(a), "+v"(b), "+v"(c), "+v"(d))
+    PP(5, 0, "s_setprio 0"); PP(5, 1, "s_setprio 2"); PP(5, 2, "s_setprio 2"); PP(5, 3, "s_setprio 3");
+    PP(6, 0, "s_setprio 0"); PP(6, 1, "s_setprio 3"); PP(6, 2, "s_setprio 3"); PP(6, 3, "s_setprio 2");
+    PP(7, 0, "s_setprio 1"); PP(7, 1, "s_setprio 2"); PP(7, 2, ""); PP(7, 3, "s_setprio 2");
+    PP(8, 0, "s_setprio 0"); PP(8, 4, "s_setprio 1"); PP(8, 1, "s_setprio 2"); PP(8, 2, "s_setprio 2"); PP(8, 3, "s_setprio 3");
+    PP(9, 0, "s_setprio 1"); PP(9, 4, "s_setprio 0"); PP(9, 1, "s_setprio 2"); PP(9, 2, "s_setprio 2"); PP(9, 3, "s_setprio 3");
+#undef PP
 }
 template <int LEAF, int V>
 __device__ __forceinline__ void half_round_prio(uint32_t (&v)[16], const uint32_t (&m)[16], const int (&ia)[4], const int (&ib)[4], const int (&ic)[4],
@@ -444,9 +456,9 @@ __device__ __forceinline__ void half_round_prio(uint32_t (&v)[16], const uint32_
         const int x = sx[2 * q];
         v[ia[q]] = v[ia[q]] + v[ib[q]] + ((LEAF && x >= 4) ? 0u : m[x]);
     }
-    PQ(0, ia);
+    PQ(4, ia);
     _Pragma("unroll") FQ v[id[q]] ^= v[ia[q]];
-    PQ(1, id);
+    PQ(3, id);
     _Pragma("unroll") FQ v[id[q]] = b2detail::rotr(v[id[q]], 16);
     PQ(0, id);
     _Pragma("unroll") FQ v[ic[q]] += v[id[q]];
@@ -457,14 +469,14 @@ __device__ __forceinline__ void half_round_prio(uint32_t (&v)[16], const uint32_
         const int y = sx[2 * q + 1];
         v[ia[q]] = v[ia[q]] + v[ib[q]] + ((LEAF && y >= 4) ? 0u : m[y]);
     }
-    PQ(0, ia);
+    PQ(4, ia);
     _Pragma("unroll") FQ v[id[q]] ^= v[ia[q]];
-    PQ(1, id);
+    PQ(3, id);
     _Pragma("unroll") FQ v[id[q]] = b2detail::rotr(v[id[q]], 8);
     PQ(0, id);
     _Pragma("unroll") FQ v[ic[q]] += v[id[q]];
     _Pragma("unroll") FQ v[ib[q]] ^= v[ic[q]];
-    PQ(1, ib);
+    PQ(3, ib);
     _Pragma("unroll") FQ v[ib[q]] = b2detail::rotr(v[ib[q]], 7);
     PQ(2, ib);
 #undef FQ
@@ -583,6 +595,22 @@ int main(int argc, char** argv) {
         run("leaf prio: slow runs high, no idle states", chain_prio_kernel<1, 8, 3>, 1, 8, secs);
         run("node prio: fast runs high, no idle states", chain_prio_kernel<0, 8, 4>, 1, 8, secs);
         run("leaf prio: fast runs high, no idle states", chain_prio_kernel<1, 8, 4>, 1, 8, secs);
+        run("node prio: rotate runs 3, add3 runs 2, fast 0", chain_prio_kernel<0, 8, 5>, 1, 8, secs);
+        run("leaf prio: rotate runs 3, add3 runs 2, fast 0", chain_prio_kernel<1, 8, 5>, 1, 8, secs);
+        run("node prio: rotate runs 2, add3 runs 3, fast 0", chain_prio_kernel<0, 8, 6>, 1, 8, secs);
+        run("leaf prio: rotate runs 2, add3 runs 3, fast 0", chain_prio_kernel<1, 8, 6>, 1, 8, secs);
+        run("node prio: rotates 3, add3 2, d ^= a runs 1, c += d / b ^= c runs 0", chain_prio_kernel<0, 8, 8>, 1, 8, secs);
+        run("leaf prio: rotates 3, add3 2, d ^= a runs 1, c += d / b ^= c runs 0", chain_prio_kernel<1, 8, 8>, 1, 8, secs);
+        run("node prio: rotates 3, add3 2, d ^= a runs 0, c += d / b ^= c runs 1", chain_prio_kernel<0, 8, 9>, 1, 8, secs);
+        run("leaf prio: rotates 3, add3 2, d ^= a runs 0, c += d / b ^= c runs 1", chain_prio_kernel<1, 8, 9>, 1, 8, secs);
+        run("node prio: slow 2, fast 1", chain_prio_kernel<0, 8, 7>, 1, 8, secs);
+        run("leaf prio: slow 2, fast 1", chain_prio_kernel<1, 8, 7>, 1, 8, secs);
+        run("node prio: slow runs high, no idle states, 6 waves", chain_prio_kernel<0, 6, 3>, 1, 6, secs);
+        run("leaf prio: slow runs high, no idle states, 6 waves", chain_prio_kernel<1, 6, 3>, 1, 6, secs);
+        run("node prio: slow runs high, no idle states, 4 waves", chain_prio_kernel<0, 4, 3>, 1, 4, secs);
+        run("leaf prio: slow runs high, no idle states, 4 waves", chain_prio_kernel<1, 4, 3>, 1, 4, secs);
+        run("node prio: slow runs high, no idle states, 2 waves", chain_prio_kernel<0, 2, 3>, 1, 2, secs);
+        run("leaf prio: slow runs high, no idle states, 2 waves", chain_prio_kernel<1, 2, 3>, 1, 2, secs);
         run("node prio: slow runs high, idle states, 4 waves", chain_prio_kernel<0, 4, 1>, 1, 4, secs);
         run("leaf prio: slow runs high, idle states, 4 waves", chain_prio_kernel<1, 4, 1>, 1, 4, secs);
         run("node prio: fast runs high, idle states, 4 waves", chain_prio_kernel<0, 4, 2>, 1, 4, secs);
