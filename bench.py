@@ -1191,10 +1191,11 @@ def main():
     # secondary ceiling: the path is bound by the integer VALU rate of Blake2s, not by HBM.  For the kernels that hash
     # a whole layer compare with the pure-compute compression rate of THIS device, measured here and now (frieda_ctx_blake2s_ceiling:
     # the rate depends on the clock the chip holds under the load and on the device; round 1's box gave 40.9 G leaf / 39.8 G node
-    # compressions per second, profiles/r01_blake2s_rate_mi355x.txt; round 5's throughput form of the compression reaches ~48 G leaf / ~45 G node,
-    # profiles/r05_blake2s_idle_sweep.txt): the first tree (fused with the last transform pass: its butterflies are NOT in the ideal
-    # time and the launch runs at 4 waves per SIMD where the ceiling kernel runs at 8, so this fraction is a lower bound on the hashing
-    # efficiency) and the fused fold + tree of the first FRI layer.
+    # compressions per second, profiles/r01_blake2s_rate_mi355x.txt; round 5's throughput form of the compression — runs of one rate
+    # class, the wave's priority raised for its slow runs — reaches ~63 - 66 G leaf / ~60 - 62 G node, profiles/r05_blake2s_prio.txt):
+    # the first tree (a proof: its leaf launch tree5_leaf; a commitment: fused with the last transform pass, whose butterflies are
+    # NOT in the ideal time and which runs at 4 waves per SIMD where the ceiling kernel runs at 8, so that fraction is a lower bound
+    # on the hashing efficiency) and the fused fold + tree of the first FRI layer.
     valu = None
     if args.only_measured_loop:
         ceil = {"leaf_per_s": 1.0, "node_per_s": 1.0, "node_clock_ghz": 0.0, "leaf_cycles_per_wave_compression": 0.0, "node_cycles_per_wave_compression": 0.0}
@@ -1215,8 +1216,9 @@ def main():
                 "peak_source": f"measured in this run on this device: {leaf_rate / 1e9:.2f} G leaf / {node_rate / 1e9:.2f} G node compressions/s "
                                f"on register-resident data at an in-kernel clock of {ceil['node_clock_ghz']:.2f} GHz (s_memtime / s_memrealtime, "
                                "frieda_ctx_blake2s_ceiling_ex), every lane chaining compressions in the product's own throughput form (runs of one "
-                               "VALU rate class with idle issue states between them, blake2s.h) at 8 waves per SIMD: ~3250 (leaf) / ~3480 (node) SIMD cycles "
-                               "per wave-compression, against ~3950 for the scheduler's own fine interleave (rounds 1-4); the chip holds its clock under this load"}
+                               "VALU rate class, the wave's priority raised for its slow runs, blake2s.h) at 8 waves per SIMD: ~2250 (leaf) / ~2400 (node) SIMD cycles "
+                               "per wave-compression, against ~3950 for the scheduler's own fine interleave (rounds 1-4) and ~3150 / ~3300 with idle issue "
+                               "states instead of priorities (first half of round 5)"}
 
     if args.only_measured_loop:
         valu = {"skipped": "--only-measured-loop: neither the ceiling nor the per-kernel replay was measured"}
