@@ -120,7 +120,7 @@ const KnobDesc KNOBS[] = {
     {"FRIEDA_TOP_MAX_LOG", 9, 11, [](Tuning& t, long v) { t.top_max_log = (uint32_t)v; return true; }},
     {"FRIEDA_NTT_CPW", 1, 4, [](Tuning& t, long v) { t.ntt_cpw = (uint32_t)v; return true; }},
     {"FRIEDA_NTT_CPW_SMALL", 1, 4, [](Tuning& t, long v) { t.ntt_cpw_small = (uint32_t)v; return true; }},
-    {"FRIEDA_NTT_REP", 0, 1, [](Tuning& t, long v) { t.ntt_rep = v != 0; return true; }},
+    {"FRIEDA_NTT_REP", 0, 2, [](Tuning& t, long v) { t.ntt_rep = (uint32_t)v; return true; }},
     {"FRIEDA_NTT_NO_CP", 0, 1, [](Tuning& t, long v) { t.ntt_no_cp = v != 0; return true; }},
     {"FRIEDA_NTT_NO_PAD8", 0, 1, [](Tuning& t, long v) { t.ntt_no_pad8 = v != 0; return true; }},
     {"FRIEDA_NTT_TREE_REG_ONLY", 0, 1, [](Tuning& t, long v) { t.ntt_tree_reg_only = v != 0; return true; }},

@@ -35,7 +35,7 @@ struct Tuning {
     uint32_t top_max_log = 9;    // FRIEDA_TOP_MAX_LOG: largest hand-over size of the top kernel (9 .. 11)
     uint32_t ntt_cpw = 4;        // FRIEDA_NTT_CPW: columns per workgroup of the generic transform kernel
     uint32_t ntt_cpw_small = 1;  // FRIEDA_NTT_CPW_SMALL: columns per workgroup of fast-kernel launches below 512 tiles
-    bool ntt_rep = false;        // FRIEDA_NTT_REP: the first strided pass as ntt_tile12_rep_kernel
+    uint32_t ntt_rep = 2;        // FRIEDA_NTT_REP: the first strided pass as ntt_tile12_rep_kernel: 0 never, 1 wherever the shape allows, 2 from 1024 workgroups on
     bool ntt_no_pad8 = false;    // FRIEDA_NTT_NO_PAD8: no padded / 4-layer fast passes
     bool ntt_no_cp = false;      // FRIEDA_NTT_NO_CP: small fold2 launches as one 256-thread workgroup per tile (not four columns side by side)
     bool ntt_tree_reg_only = false;      // FRIEDA_NTT_TREE_REG_ONLY: the fused encode + leaf launch stops after its five register levels

@@ -1160,12 +1160,15 @@ uint32_t evaluate_plan(const Launch& L_, const uint32_t* d_coef, size_t coef_str
             return;
         }
         Scope scope(L_, name, enc_bytes / ((n_mid_fast ? n_mid_fast : n_mid_generic) + 1));
-        // FRIEDA_NTT_REP=1: one workgroup per source tile looping over the high blocks (ntt_tile12_rep_kernel).  Off by default: it
-        // cuts the pass's fetches from the memory side to the unique coefficients but is no faster (142 vs 140 us at 2^24, 41 vs 35 us at
-        // 2^22, profiles/r03_ntt_mid_rep_ab.txt) — the pass is bound by its butterflies and LDS round trips, not by the re-reads,
-        // which the L2 / Infinity Cache absorb.
-        const bool use_rep = L_.tune->ntt_rep;
+        // ntt_tile12_rep_kernel: one workgroup per source tile looping over the high blocks.  It cuts the pass's fetches from the memory
+        // side to the unique coefficients; the pass is bound by its butterflies and LDS round trips, so that bought nothing in round 3
+        // (142 vs 140 us at 2^24, profiles/r03_ntt_mid_rep_ab.txt) and costs a launch that no longer fills the chip its width
+        // (a lone 2^22 blob: 256 workgroups, 33 vs 26 us).  With the round-5 kernels it is ahead where it still fills the chip:
+        // 102 vs 106 us at 2^24 and the pass AFTER it 144 vs 150 (profiles/r05_prio_product_ab.txt, last block); streams of 2^22 / 2^20
+        // blobs equal.  FRIEDA_NTT_REP: 0 = never, 1 = wherever the shape allows, 2 (default) = from 1024 workgroups on.
         const uint32_t hb_log = n - 1 - a.i_hi;  // high blocks = 2^hb_log
+        const uint64_t rep_wgs = (uint64_t)((N >> TILE_LOG) >> (hb_log < 3 ? hb_log : 3)) * (ncols / 2) * L_.batch;
+        const bool use_rep = L_.tune->ntt_rep == 1 || (L_.tune->ntt_rep == 2 && rep_wgs >= 1024);
         if (use_rep && out_log == n && aligned && t == 8 && a.log_w == MID_LOG_W && hb_log >= 1 && ((uint64_t)a.in_mask >> (a.i_hi + 1)) == 0 && ncols % 2 == 0) {
             // this pass reads the (replicated) coefficient vector: every high block has the same source tile
             a.rep_log = hb_log < 3 ? hb_log : 3;

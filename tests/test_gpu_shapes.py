@@ -163,7 +163,7 @@ def test_circle_evaluate_mb_scale_shapes(gpu_ctx, oracle, L, n, ncols):
 
 
 @pytest.mark.parametrize("knob", ["FRIEDA_NO_ENCODE_TREE_FUSION", "FRIEDA_ENCODE_TREE_FUSION_PROVE", "FRIEDA_NTT_NO_PAD8", "FRIEDA_NTT_TREE_REG_ONLY", "FRIEDA_T5_REG3_LOG=18", "FRIEDA_NTT_CPW=2",
-                                  "FRIEDA_HOST_DECOMMIT", "FRIEDA_NO_SMALL_FUSED", "FRIEDA_NTT_CPW_SMALL=4", "FRIEDA_NTT_REP", "FRIEDA_TAIL_RUN_LOG=6",
+                                  "FRIEDA_HOST_DECOMMIT", "FRIEDA_NO_SMALL_FUSED", "FRIEDA_NTT_CPW_SMALL=4", "FRIEDA_NTT_REP", "FRIEDA_NTT_REP=0", "FRIEDA_TAIL_RUN_LOG=6",
                                   "FRIEDA_T9_MAX_LOG=12", "FRIEDA_UNPACK_TILES=1", "FRIEDA_T5_WIDE_LOG=16"])
 def test_knob_variants_on_their_own_context(oracle, knob):
     """The A/B options of DESIGN.md §10 select other kernels / templates for the same result (unfused encode + leaf launch, generic

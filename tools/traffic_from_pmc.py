@@ -37,6 +37,9 @@ RULES = [
     (r"top_kernel", "tree_top", 2.0),
     (r"tail_kernel", "fri_tail", 2.0),
     (r"ntt_tile12_kernel<2, 4>", "ntt_pass_mid", 1.0),
+    # the same pass as one workgroup per SOURCE tile (default from 1024 workgroups on, round 5): the 16.8 MB of coefficients are read once,
+    # 16 bytes per lane fully coalesced (the halved pattern); the pass's traffic is its 268 MB of stores either way
+    (r"ntt_tile12_rep_kernel", "ntt_pass_mid", 2.0),
     (r"ntt_tile12_kernel<3, 0>", "ntt_pass_last", 2.0),
     # the fused last pass + leaf hashing reads the strided pass's output with 16-byte fully coalesced loads (the halved pattern)
     (r"ntt_last_tree_kernel", "ntt_last_tree7", 2.0),
