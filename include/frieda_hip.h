@@ -99,9 +99,10 @@ int frieda_ctx_blake2s_ceiling(frieda_ctx* ctx, double* leaf_per_s, double* node
 /* the same after ~0.25 s of that load per shape (~0.5 s in all), with the clock the chip holds under it read inside the kernel (shader-clock counter against
  * the 100 MHz wall-clock counter, median over the workgroups): out = {leaf compressions/s, node compressions/s, leaf clock GHz,
  * leaf SIMD cycles per wave-compression, node clock GHz, node SIMD cycles per wave-compression}.  On MI355X the clock stays at
- * ~2.4 GHz under this load (profiles/r03_clock_probe_mi355x.txt) and a compression costs ~3250 (leaf) / ~3480 (node) cycles per wave
- * in the library's throughput form (runs of one VALU rate class with idle issue states between them; ~3950 for the scheduler's own
- * fine interleave, profiles/r05_blake2s_idle_sweep.txt): the ceiling is the instruction stream, not a lowered clock. */
+ * 2.3 - 2.4 GHz under this load and a compression costs ~2250 (leaf) / ~2400 (node) cycles per wave in the library's throughput
+ * form (runs of one VALU rate class, the wave's priority raised for its slow-class runs; ~3950 for the scheduler's own fine
+ * interleave, ~3150 / ~3300 with idle issue states instead of priorities: profiles/r05_blake2s_prio.txt, r05_blake2s_idle_sweep.txt):
+ * the ceiling is the instruction stream and how the waves of a SIMD share the vector pipe. */
 int frieda_ctx_blake2s_ceiling_ex(frieda_ctx* ctx, double out[6]);
 /* diagnostic: the Fiat-Shamir transcript of the last finished generate_proof on this ctx (blob 0 of a batch) — what
  * FriProver::commit derives between src/proof.rs:52 and :58 and the Proof does not carry: per FRI layer (first, then inner)
