@@ -259,7 +259,7 @@ __device__ __forceinline__ void b2_merkle_block_runs(const uint32_t (&m)[16], ui
 #ifndef FRIEDA_B2_IDLE_GRIND
 #define FRIEDA_B2_IDLE_GRIND 0xB000
 #endif
-// (which form a tree launch takes is decided per launch: tree.hip tp_launch — below ~3 waves per SIMD an idle state is pure delay)
+// (which form a tree launch takes is decided per launch: tree.hip tp_launch — below ~3 waves per SIMD the runs only cost latency)
 
 // Blake2sMerkleHasher::hash_node for one 16-word block from the zero state: the shape of every node of
 // frieda's trees (leaf = 4 column words + 12 zero words; inner node = left || right).

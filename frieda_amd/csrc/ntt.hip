@@ -51,9 +51,12 @@ __device__ __forceinline__ uint32_t pad(uint32_t e) { return e + (e >> 4); }
 
 // ---- the four layers of a radix-16 stage on 16 register-resident values, eight butterflies at a time ----
 // Same idea as the hash kernels' throughput form (blake2s.h): the eight independent butterflies of a layer advance together, one
-// arithmetic step at a time, so that the VALU stream is made of runs of one rate class (v_mad_u64_u32 / v_alignbit / v_min: slow;
-// v_and / v_add / v_sub: fast) with a few idle issue states (s_nop) between the runs, pinned by data flow.  FRIEDA_NTT_IDLE = 0xAB:
-// idle states after a slow run (A) and after a fast run (B); 0 = the plain form (butterfly by butterfly, the scheduler's order).
+// arithmetic step at a time, so that the VALU stream is made of runs of one rate class (v_mad_u64_u32 / v_min: slow; v_and / v_add /
+// v_sub / shifts: fast), pinned by data flow, and the wave runs its slow runs at a raised priority (s_setprio in the pin statements):
+// the SIMD then overlaps one wave's slow instruction with another wave's fast one (blake2s.h).  FRIEDA_NTT_IDLE = 0xPAB: P = priority
+// of the slow runs (0 = no switching), A / B = idle issue states (s_nop) after a slow / after a fast run — the first form of round 5,
+// 0x33, superseded by the priorities: 0x200; 0 = the plain form (butterfly by butterfly, the scheduler's order).  Everything of a
+// transform kernel that is NOT a butterfly (loads, LDS traffic, stores) runs at FRIEDA_NTT_OUTER_PRIO (ntt_enter).
 // The twiddles of these stages are kept DOUBLED in their registers (2 tw mod 2^32 = 2 tw): one instruction fewer per butterfly.
 #ifndef FRIEDA_NTT_IDLE
 #define FRIEDA_NTT_IDLE 0x200
@@ -78,21 +81,21 @@ __device__ __forceinline__ void ntt_pin(uint32_t (&a)[G]) {
     static_assert(N >= 0 && N <= 5 && (G == 4 || G == 8) && SET >= -1 && SET <= 3, "idle states 0 .. 5, groups of 4 or 8, priorities 0 .. 3");
 #define FR_PIN_OPS4 "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3])
 #define FR_PIN_OPS8 "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7])
-#define FR_PIN_N(PRE, ...)                                      \
-    do {                                                         \
+#define FR_PIN_N(PRE, ...)                                               \
+    do {                                                                 \
         if constexpr (N <= 1) asm volatile(PRE : __VA_ARGS__);           \
         if constexpr (N == 2) asm volatile(PRE "s_nop 0" : __VA_ARGS__); \
         if constexpr (N == 3) asm volatile(PRE "s_nop 1" : __VA_ARGS__); \
         if constexpr (N == 4) asm volatile(PRE "s_nop 2" : __VA_ARGS__); \
         if constexpr (N == 5) asm volatile(PRE "s_nop 3" : __VA_ARGS__); \
     } while (0)
-#define FR_PIN_SET(...)                                              \
-    do {                                                             \
-        if constexpr (SET < 0 && N >= 1) FR_PIN_N("", __VA_ARGS__);          \
-        if constexpr (SET == 0) FR_PIN_N("s_setprio 0\n\t", __VA_ARGS__);    \
-        if constexpr (SET == 1) FR_PIN_N("s_setprio 1\n\t", __VA_ARGS__);    \
-        if constexpr (SET == 2) FR_PIN_N("s_setprio 2\n\t", __VA_ARGS__);    \
-        if constexpr (SET == 3) FR_PIN_N("s_setprio 3\n\t", __VA_ARGS__);    \
+#define FR_PIN_SET(...)                                                   \
+    do {                                                                  \
+        if constexpr (SET < 0 && N >= 1) FR_PIN_N("", __VA_ARGS__);       \
+        if constexpr (SET == 0) FR_PIN_N("s_setprio 0\n\t", __VA_ARGS__); \
+        if constexpr (SET == 1) FR_PIN_N("s_setprio 1\n\t", __VA_ARGS__); \
+        if constexpr (SET == 2) FR_PIN_N("s_setprio 2\n\t", __VA_ARGS__); \
+        if constexpr (SET == 3) FR_PIN_N("s_setprio 3\n\t", __VA_ARGS__); \
     } while (0)
     if constexpr (G == 8)
         FR_PIN_SET(FR_PIN_OPS8);

@@ -120,7 +120,7 @@ __device__ __forceinline__ void tree_args_of_blob(TreeArgs& a) {
 namespace {
 
 // TP: the compressions in the throughput form (blake2s.h) — chosen by the launcher for launches that fill the chip (tp_launch): below
-// ~3 waves per SIMD an idle state is pure delay (a lone 2^20 proof 0.56 -> 0.61 ms with the throughput form everywhere)
+// ~3 waves per SIMD the run structure buys nothing and costs latency (a lone 2^20 proof 0.555 -> 0.600 ms with the throughput form everywhere)
 // In the chip-filling launches a wave runs its prologue — the loads of its inputs and the fold arithmetic — at a priority above the
 // compressions' slow runs (blake2s.h): its loads are in flight before it competes for the vector pipe, and the folds do not queue
 // behind eight waves' worth of compressions (tree5_fold_circle 335 -> 296 us, tree5_fold_line 553 -> 520, tree5_leaf 528 -> 512;
