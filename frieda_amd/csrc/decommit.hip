@@ -21,6 +21,7 @@
 
 #include "dev_transcript.h"
 #include "kernels.h"
+#include "tree_dev.h"
 
 namespace frieda {
 namespace k {
@@ -45,6 +46,36 @@ __device__ __forceinline__ bool emit_of(const uint32_t* u, uint32_t nu, uint32_t
         return true;
     }
     return false;
+}
+
+// A node of the two levels above the leaves, re-hashed from the layer's values (4 columns of 2^m words): the large trees of a proof
+// do not store these levels (tree.hip TreeArgs::skip_bc).  level = log2 of the level's size: m - 1 (the parent of leaves 2 c, 2 c + 1)
+// or m - 2 (of leaves 4 c .. 4 c + 3): three or seven compressions in the plain form.
+__device__ void node_from_values(const uint32_t* __restrict__ v, uint32_t m, uint32_t level, uint32_t child, uint32_t (&h)[8]) {
+    const size_t cs = (size_t)1 << m;
+    const uint32_t nb = level + 1 == m ? 1u : 2u;  // level-(m-1) nodes under the requested one
+    uint32_t hb[2][8];
+#pragma unroll
+    for (uint32_t q = 0; q < 2; q++) {
+        if (q < nb) {
+            const size_t b = nb == 1 ? child : 2 * (size_t)child + q, j = 2 * b;
+            uint32_t l[8], r[8], mm[16];
+            treedev::leaf_hash<B2_LAT>(v[j], v[cs + j], v[2 * cs + j], v[3 * cs + j], l);
+            treedev::leaf_hash<B2_LAT>(v[j + 1], v[cs + j + 1], v[2 * cs + j + 1], v[3 * cs + j + 1], r);
+#pragma unroll
+            for (int w = 0; w < 8; w++) mm[w] = l[w], mm[8 + w] = r[w];
+            b2_merkle_block<B2_LAT>(mm, hb[q]);
+        }
+    }
+    if (nb == 1) {
+#pragma unroll
+        for (int w = 0; w < 8; w++) h[w] = hb[0][w];
+    } else {
+        uint32_t mm[16];
+#pragma unroll
+        for (int w = 0; w < 8; w++) mm[w] = hb[0][w], mm[8 + w] = hb[1][w];
+        b2_merkle_block<B2_LAT>(mm, h);
+    }
 }
 
 __global__ __launch_bounds__(DC_THREADS) void decommit_kernel(DecommitArgs a) {
@@ -247,7 +278,8 @@ __global__ __launch_bounds__(DC_THREADS) void decommit_kernel(DecommitArgs a) {
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
                     const uint32_t li = li0 + j;
-                    if (li < li_end) {
+                    // (a level the tree does not hold is re-hashed below, by the thread of the entry's first half)
+                    if (li < li_end && !(n - li >= a.skip_log && level + 2 >= n - li)) {
                         const uint8_t* tree = a.trees[li] + boff + (((size_t)64 << (n - li)) - ((size_t)64 << level));
                         v[j] = reinterpret_cast<const uint4*>(tree + 32 * (size_t)child)[half];
                     }
@@ -255,7 +287,19 @@ __global__ __launch_bounds__(DC_THREADS) void decommit_kernel(DecommitArgs a) {
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
                     const uint32_t li = li0 + j;
-                    if (li < li_end) oh[2 * (size_t)(s_hoff[li] + (idx - s_base[li + 2])) + half] = v[j];
+                    if (li < li_end && !(n - li >= a.skip_log && level + 2 >= n - li)) oh[2 * (size_t)(s_hoff[li] + (idx - s_base[li + 2])) + half] = v[j];
+                }
+            }
+            // the (at most two) layers in which this entry sits one or two levels above the leaves of a tree that keeps neither
+            if (half == 0) {
+#pragma unroll 1
+                for (uint32_t li = (s >= 3 ? s - 3 : 0); li < li_end; li++) {  // level + 2 >= n - li  <=>  li >= s - 3
+                    if (n - li < a.skip_log) continue;
+                    uint32_t h[8];
+                    node_from_values(reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(a.vals[li]) + boff), n - li, level, child, h);
+                    uint4* o = oh + 2 * (size_t)(s_hoff[li] + (idx - s_base[li + 2]));
+                    o[0] = make_uint4(h[0], h[1], h[2], h[3]);
+                    o[1] = make_uint4(h[4], h[5], h[6], h[7]);
                 }
             }
         }

@@ -51,6 +51,8 @@ struct Tuning {
     uint32_t test_grind_first_log = 0;   // test hook (frieda_ctx_test_set_grind_first_log): a short first nonce range (0 = off)
     // batch policy (host.h, "batch policy"): workspace bytes a batched call may keep in flight, and the fewest calls a context gets
     uint32_t batch_budget_mb = 0;        // FRIEDA_BATCH_BUDGET_MB: 0 = the default (sixteen proofs of a 2^24 domain, ~43 GB)
+    uint32_t tree_skip_log = 18;         // FRIEDA_TREE_SKIP_LOG: a proof's trees of >= 2^v leaves keep their levels from the fourth on only; the
+                                         // openings re-hash the two levels above the leaves from the layer's values (decommit.hip)
     uint32_t tp_min_wgs = 768;           // FRIEDA_TP_MIN_WGS: launches of at least this many 256-thread workgroups hash in the throughput form (blake2s.h)
     uint32_t grind_iters = 0;            // FRIEDA_GRIND_ITERS: nonces per lane and claim in the batched grind (window = 256 x this); 0 = by batch size
     uint32_t batch_calls_per_ctx = 1;    // FRIEDA_BATCH_CALLS_PER_CTX: a stream is cut into at least this many calls per context in flight
@@ -311,6 +313,7 @@ struct DecommitArgs {
     uint32_t max_words, max_hashes;  // capacity of the two regions (u32 words / hashes) per blob
     const uint32_t* vals[DECOMMIT_MAX_LAYERS];  // blob 0's layers: 4 columns of 2^(n - li) words, column stride 2^(n - li)
     const uint8_t* trees[DECOMMIT_MAX_LAYERS];  // their trees (leaves-first layout)
+    uint32_t skip_log;  // trees of >= 2^skip_log leaves: the two levels above the leaves are re-hashed from vals, not read (Tuning::tree_skip_log)
 };
 void decommit(const Launch& L, const DecommitArgs& a, uint32_t wgs_per_blob);
 

@@ -492,6 +492,7 @@ static void launch_decommit(Ctx* ctx, const ProveJob& J, const k::Launch& LN) {
     a.hashes_off = J.dec_hashes_off;
     a.max_words = J.dec_max_words;
     a.max_hashes = J.dec_max_hashes;
+    a.skip_log = ctx->tuning.tree_skip_log;
     a.vals[0] = reinterpret_cast<const uint32_t*>(A + J.first.o_vals);
     a.trees[0] = A + J.first.o_tree;
     for (uint32_t kx = 0; kx < J.n_inner; kx++) {
@@ -891,6 +892,22 @@ int prove_finish_batch(Ctx* ctx, uint8_t* out_commitments, std::vector<ProofData
         ctx->phase_ms[2] = ctx->phase_ms[3] = ms_since(J.t_start);
     }
     if (!from_device) {
+        // The host plans against COMPLETE trees; the large ones were built without the two levels above their leaves (the device
+        // decommitment re-hashes those, tree.hip TreeArgs::skip_bc): rebuild such a tree from its layer's values first (a rare path).
+        {
+            k::Launch Lb = ctx->launch();  // single-blob launches
+            for (uint32_t b = 0; b < count; b++) {
+                const size_t boff = (size_t)b * J.bstride;
+                auto rebuild = [&](const FriLayerDev& lay) {
+                    if (lay.log < ctx->tuning.tree_skip_log) return;
+                    const uint32_t* c0 = reinterpret_cast<const uint32_t*>(A + lay.o_vals + boff);
+                    const size_t cs = (size_t)1 << lay.log;
+                    k::merkle_tree4(Lb, c0, c0 + cs, c0 + 2 * cs, c0 + 3 * cs, lay.log, A + lay.o_tree + boff);
+                };
+                rebuild(first);
+                for (uint32_t kx = 0; kx < n_inner; kx++) rebuild(inner[kx]);
+            }
+        }
         static thread_local GatherPlan g;  // capacity is kept from proof to proof
         g.word_idx.clear();
         g.hash_idx.clear();

@@ -103,6 +103,9 @@ struct TreeArgs {
     int store_all;
     int skip_a;               // store_all, but level A itself is not written (nothing reads the leaf hashes of a FRI layer's tree:
                               // a decommitment opens both members of every queried pair, so the verifier derives them from values)
+    int skip_bc;              // store_all + skip_a, large trees (Tuning::tree_skip_log): the register-subtree kernel does not write the two
+                              // levels above the leaves either — 3/4 of a tree's bytes, read back only along ~20 opened paths, which
+                              // decommit.hip re-hashes from the layer's values instead (2.7 % of a 2^24 proof, profiles/r05_skip_levels.txt)
     size_t bstride;           // batch: bytes between consecutive blobs' workspaces (blob = blockIdx.y); tr is an array
 };
 
@@ -214,8 +217,9 @@ __global__ __launch_bounds__(T5_THREADS) void tree5r_kernel(TreeArgs a) {
     const size_t wg_base = (size_t)blockIdx.x * 1024;  // the launcher guarantees 2^level_a >= 1024
     const size_t g0 = wg_base + 4 * t;
     uint8_t* out_a = a.store_all && !a.skip_a ? a.layers + layer_off(a.tree_log, a.level_a) : nullptr;
-    uint8_t* out_b = a.store_all ? a.layers + layer_off(a.tree_log, a.level_a - 1) : nullptr;
-    uint8_t* out_c = a.store_all ? a.layers + layer_off(a.tree_log, a.level_a - 2) : (REG_ONLY ? a.last_out : nullptr);
+    // (skip_bc: levels B and C stay unwritten; the register-only variant hands level C to the next launch and keeps it)
+    uint8_t* out_b = a.store_all && !a.skip_bc ? a.layers + layer_off(a.tree_log, a.level_a - 1) : nullptr;
+    uint8_t* out_c = a.store_all ? (a.skip_bc && !REG_ONLY ? nullptr : a.layers + layer_off(a.tree_log, a.level_a - 2)) : (REG_ONLY ? a.last_out : nullptr);
     uint8_t* out_d = a.store_all ? a.layers + layer_off(a.tree_log, a.level_a - 3) : nullptr;
     uint8_t* out_e = a.store_all ? a.layers + layer_off(a.tree_log, a.level_a - 4) : a.last_out;
 
@@ -1269,6 +1273,7 @@ void finish_tree(const Launch& L, const TreeArgs& a, uint32_t m, uint32_t cur, c
     while (cur > L.tune->top_max_log) {
         TreeArgs b = a;
         b.skip_a = 0;
+        b.skip_bc = 0;
         b.level_a = cur - 1;
         b.children = cur_ptr;
         b.last_out = (cur_ptr == s0) ? s1 : s0;
@@ -1310,6 +1315,7 @@ void build_tree(const Launch& L, int mode, TreeArgs a, uint32_t m, uint8_t* laye
     a.tree_log = m;
     a.layers = layers;
     a.store_all = layers != nullptr;
+    a.skip_bc = a.store_all && a.skip_a && m >= L.tune->tree_skip_log && mode != T_NODE;  // (level A == the leaves of this tree)
     a.bstride = L.bstride;
     uint8_t* s0 = scratch;
     uint8_t* s1 = scratch ? scratch + ((size_t)32 << (m > 4 ? m - 4 : 0)) : nullptr;

@@ -164,7 +164,7 @@ def test_circle_evaluate_mb_scale_shapes(gpu_ctx, oracle, L, n, ncols):
 
 @pytest.mark.parametrize("knob", ["FRIEDA_NO_ENCODE_TREE_FUSION", "FRIEDA_ENCODE_TREE_FUSION_PROVE", "FRIEDA_NTT_NO_PAD8", "FRIEDA_NTT_TREE_REG_ONLY", "FRIEDA_T5_REG3_LOG=18", "FRIEDA_NTT_CPW=2",
                                   "FRIEDA_HOST_DECOMMIT", "FRIEDA_NO_SMALL_FUSED", "FRIEDA_NTT_CPW_SMALL=4", "FRIEDA_NTT_REP", "FRIEDA_NTT_REP=0", "FRIEDA_TAIL_RUN_LOG=6",
-                                  "FRIEDA_T9_MAX_LOG=12", "FRIEDA_UNPACK_TILES=1", "FRIEDA_T5_WIDE_LOG=16", "FRIEDA_TP_MIN_WGS=0", "FRIEDA_TP_MIN_WGS=1073741824"])
+                                  "FRIEDA_T9_MAX_LOG=12", "FRIEDA_UNPACK_TILES=1", "FRIEDA_T5_WIDE_LOG=16", "FRIEDA_TP_MIN_WGS=0", "FRIEDA_TP_MIN_WGS=1073741824", "FRIEDA_TREE_SKIP_LOG=10", "FRIEDA_TREE_SKIP_LOG=40"])
 def test_knob_variants_on_their_own_context(oracle, knob):
     """The A/B options of DESIGN.md §10 select other kernels / templates for the same result (unfused encode + leaf launch, generic
     strided pass instead of the padded 8-layer one, the register-only tree variants, the compressions' throughput form — runs with
@@ -185,6 +185,36 @@ def test_knob_variants_on_their_own_context(oracle, knob):
             r, p = ctx.commit_and_generate_proof(data, 9, cfg)
             o_r, o_p = oracle.commit_and_generate_proof(data, 9, oracle.make_config(6, B, 0, 40))
             assert r == o_r and p.serialize() == o_p.serialize(), ("prove", L, B)
+    finally:
+        ctx.close()
+
+
+@pytest.mark.parametrize("host_decommit", [0, 1])
+def test_unstored_tree_levels_are_rehashed_or_rebuilt(oracle, host_decommit):
+    """A proof's large trees do not keep the two levels above their leaves (FRIEDA_TREE_SKIP_LOG, default 2^18 leaves): the device
+    decommitment re-hashes the opened nodes of those levels from the layer's values, and the host planner (FRIEDA_HOST_DECOMMIT, or the
+    device kernel's overflow exit) rebuilds such trees before it gathers.  Threshold lowered to 2^10 so that every layer of these shapes
+    above the single-workgroup tail takes the new path; 20 and 300 queries (duplicates, many opened paths); whole proofs against the oracle."""
+    import frieda_amd
+
+    ctx = frieda_amd.Context(0)
+    try:
+        ctx.set_option("FRIEDA_TREE_SKIP_LOG", 10)
+        ctx.set_option("FRIEDA_HOST_DECOMMIT", host_decommit)
+        for L, B, nq in ((16, 4, 20), (14, 3, 300), (12, 4, 64), (17, 1, 20)):
+            length = (4 << L) * 30 // 8 - 1234
+            data = splitmix64_bytes(4100 + L, length).tobytes()
+            cfg = frieda_amd.PcsConfig(frieda_amd.FriConfig(B, 0, nq), 5)
+            r, p = ctx.commit_and_generate_proof(data, 11, cfg)
+            o_r, o_p = oracle.commit_and_generate_proof(data, 11, oracle.make_config(5, B, 0, nq))
+            assert r == o_r and p.serialize() == o_p.serialize(), (L, B, nq, host_decommit)
+        # a batch: every blob's own workspace offset in the re-hash and in the rebuild
+        blobs = [splitmix64_bytes(4200 + i, (4 << 14) * 30 // 8).tobytes() for i in range(3)]
+        cfg = frieda_amd.PcsConfig(frieda_amd.FriConfig(4, 0, 20), 5)
+        got = ctx.commit_and_generate_proof_batch(blobs, [7, 8, 9], cfg)
+        for (r, p), blob, seed in zip(got, blobs, [7, 8, 9]):
+            o_r, o_p = oracle.commit_and_generate_proof(blob, seed, oracle.make_config(5, 4, 0, 20))
+            assert r == o_r and p.serialize() == o_p.serialize()
     finally:
         ctx.close()
 
