@@ -321,5 +321,5 @@ def test_traffic_fingerprint_is_one_function():
     t = load("traffic_mod", os.path.join(root, "tools", "traffic_from_pmc.py"))
     assert b._csrc_sha16() == t.csrc_sha16() and len(b._csrc_sha16()) == 16
     val, src, per_blob = b.traffic_from_profiles("tree5_leaf", 24, "prove")  # (the dominant launch of a proof since round 5)
-    assert val and val > 5e8 and "collected at commit" in src and ("unchanged since" in src or "STALE" in src)
+    assert val and val > 1e8 and "collected at commit" in src and ("unchanged since" in src or "STALE" in src)
     assert b.traffic_from_profiles("tree5_leaf", 22, "prove")[0] is None
