@@ -138,6 +138,7 @@ const KnobDesc KNOBS[] = {
     {"FRIEDA_HOST_DECOMMIT", 0, 1, [](Tuning& t, long v) { t.host_decommit = v != 0; return true; }},
     {"FRIEDA_GATHER_COPY", 0, 1, [](Tuning& t, long v) { t.gather_copy = v != 0; return true; }},
     {"FRIEDA_TREE_SKIP_LOG", 10, 40, [](Tuning& t, long v) { t.tree_skip_log = (uint32_t)v; return true; }},
+    {"FRIEDA_TREE_SKIP_LONE_LOG", 10, 40, [](Tuning& t, long v) { t.tree_skip_lone_log = (uint32_t)v; return true; }},
     {"FRIEDA_TP_MIN_WGS", 0, 1 << 30, [](Tuning& t, long v) { t.tp_min_wgs = (uint32_t)v; return true; }},
     {"FRIEDA_GRIND_ITERS", 0, 64, [](Tuning& t, long v) { t.grind_iters = (uint32_t)v; return true; }},
     {"FRIEDA_BATCH_BUDGET_MB", 0, 262144, [](Tuning& t, long v) { t.batch_budget_mb = (uint32_t)v; return true; }},

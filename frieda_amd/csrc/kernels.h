@@ -53,11 +53,18 @@ struct Tuning {
     uint32_t batch_budget_mb = 0;        // FRIEDA_BATCH_BUDGET_MB: 0 = the default (sixteen proofs of a 2^24 domain, ~43 GB)
     uint32_t tree_skip_log = 18;         // FRIEDA_TREE_SKIP_LOG: a proof's trees of >= 2^v leaves keep their levels from the fourth on only; the
                                          // openings re-hash the two levels above the leaves from the layer's values (decommit.hip)
+    uint32_t tree_skip_lone_log = 23;    // FRIEDA_TREE_SKIP_LONE_LOG: the same threshold for a call of ONE blob (the re-hash is a ~15 us chain
+                                         // in the decommitment whatever the size; a batch shares it, a lone proof pays it: worth it from 2^23 on)
     uint32_t tp_min_wgs = 768;           // FRIEDA_TP_MIN_WGS: launches of at least this many 256-thread workgroups hash in the throughput form (blake2s.h)
     uint32_t grind_iters = 0;            // FRIEDA_GRIND_ITERS: nonces per lane and claim in the batched grind (window = 256 x this); 0 = by batch size
     uint32_t batch_calls_per_ctx = 1;    // FRIEDA_BATCH_CALLS_PER_CTX: a stream is cut into at least this many calls per context in flight
                                          // (measured, profiles/r05_batch_policy_sweep.txt: 1 beats 2 by 3 % at 2^20 and 30 % at 1 KiB blobs, equal at 2^22 / 2^24)
 };
+// trees of a proof with at least 2^(this) leaves are built without the two levels above their leaves (tree.hip TreeArgs::skip_bc,
+// decommit.hip node_from_values, prover.cpp's host-planner fallback): ONE rule for the three places, by the blobs of the call
+inline uint32_t tree_skip_threshold(const Tuning& t, uint32_t batch) {
+    return batch >= 2 ? t.tree_skip_log : (t.tree_skip_lone_log > t.tree_skip_log ? t.tree_skip_lone_log : t.tree_skip_log);
+}
 Tuning tuning_from_env();
 // `name`: the environment variable's name ("FRIEDA_NTT_REP"); false = unknown name or value out of range
 bool tuning_set(Tuning& t, const char* name, long value);

@@ -492,7 +492,7 @@ static void launch_decommit(Ctx* ctx, const ProveJob& J, const k::Launch& LN) {
     a.hashes_off = J.dec_hashes_off;
     a.max_words = J.dec_max_words;
     a.max_hashes = J.dec_max_hashes;
-    a.skip_log = ctx->tuning.tree_skip_log;
+    a.skip_log = k::tree_skip_threshold(ctx->tuning, J.count);
     a.vals[0] = reinterpret_cast<const uint32_t*>(A + J.first.o_vals);
     a.trees[0] = A + J.first.o_tree;
     for (uint32_t kx = 0; kx < J.n_inner; kx++) {
@@ -899,7 +899,7 @@ int prove_finish_batch(Ctx* ctx, uint8_t* out_commitments, std::vector<ProofData
             for (uint32_t b = 0; b < count; b++) {
                 const size_t boff = (size_t)b * J.bstride;
                 auto rebuild = [&](const FriLayerDev& lay) {
-                    if (lay.log < ctx->tuning.tree_skip_log) return;
+                    if (lay.log < k::tree_skip_threshold(ctx->tuning, count)) return;
                     const uint32_t* c0 = reinterpret_cast<const uint32_t*>(A + lay.o_vals + boff);
                     const size_t cs = (size_t)1 << lay.log;
                     k::merkle_tree4(Lb, c0, c0 + cs, c0 + 2 * cs, c0 + 3 * cs, lay.log, A + lay.o_tree + boff);

@@ -1315,7 +1315,7 @@ void build_tree(const Launch& L, int mode, TreeArgs a, uint32_t m, uint8_t* laye
     a.tree_log = m;
     a.layers = layers;
     a.store_all = layers != nullptr;
-    a.skip_bc = a.store_all && a.skip_a && m >= L.tune->tree_skip_log && mode != T_NODE;  // (level A == the leaves of this tree)
+    a.skip_bc = a.store_all && a.skip_a && m >= tree_skip_threshold(*L.tune, L.batch) && mode != T_NODE;  // (level A == the leaves of this tree)
     a.bstride = L.bstride;
     uint8_t* s0 = scratch;
     uint8_t* s1 = scratch ? scratch + ((size_t)32 << (m > 4 ? m - 4 : 0)) : nullptr;

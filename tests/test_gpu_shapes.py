@@ -164,7 +164,7 @@ def test_circle_evaluate_mb_scale_shapes(gpu_ctx, oracle, L, n, ncols):
 
 @pytest.mark.parametrize("knob", ["FRIEDA_NO_ENCODE_TREE_FUSION", "FRIEDA_ENCODE_TREE_FUSION_PROVE", "FRIEDA_NTT_NO_PAD8", "FRIEDA_NTT_TREE_REG_ONLY", "FRIEDA_T5_REG3_LOG=18", "FRIEDA_NTT_CPW=2",
                                   "FRIEDA_HOST_DECOMMIT", "FRIEDA_NO_SMALL_FUSED", "FRIEDA_NTT_CPW_SMALL=4", "FRIEDA_NTT_REP", "FRIEDA_NTT_REP=0", "FRIEDA_TAIL_RUN_LOG=6",
-                                  "FRIEDA_T9_MAX_LOG=12", "FRIEDA_UNPACK_TILES=1", "FRIEDA_T5_WIDE_LOG=16", "FRIEDA_TP_MIN_WGS=0", "FRIEDA_TP_MIN_WGS=1073741824", "FRIEDA_TREE_SKIP_LOG=10", "FRIEDA_TREE_SKIP_LOG=40"])
+                                  "FRIEDA_T9_MAX_LOG=12", "FRIEDA_UNPACK_TILES=1", "FRIEDA_T5_WIDE_LOG=16", "FRIEDA_TP_MIN_WGS=0", "FRIEDA_TP_MIN_WGS=1073741824", "FRIEDA_TREE_SKIP_LOG=10", "FRIEDA_TREE_SKIP_LONE_LOG=10", "FRIEDA_TREE_SKIP_LOG=40"])
 def test_knob_variants_on_their_own_context(oracle, knob):
     """The A/B options of DESIGN.md §10 select other kernels / templates for the same result (unfused encode + leaf launch, generic
     strided pass instead of the padded 8-layer one, the register-only tree variants, the compressions' throughput form — runs with
@@ -200,6 +200,7 @@ def test_unstored_tree_levels_are_rehashed_or_rebuilt(oracle, host_decommit):
     ctx = frieda_amd.Context(0)
     try:
         ctx.set_option("FRIEDA_TREE_SKIP_LOG", 10)
+        ctx.set_option("FRIEDA_TREE_SKIP_LONE_LOG", 10)  # (a call of one blob has its own, higher threshold)
         ctx.set_option("FRIEDA_HOST_DECOMMIT", host_decommit)
         for L, B, nq in ((16, 4, 20), (14, 3, 300), (12, 4, 64), (17, 1, 20)):
             length = (4 << L) * 30 // 8 - 1234
