@@ -28,7 +28,8 @@ barriers, root all_gather and max-reduce on CPU tensors with the GPU work stubbe
 its line carries "dry_run": true and value 0).
 
 The JSON line also carries
-  roofline     — the dominant kernel family (by summed HIP-event time on the kernels' own stream, instrumented replay of
+  roofline     — the dominant launch (dominant_launch(): longest average launch among the kernel families within a factor two of the
+                 largest summed HIP-event time on the kernels' own stream, instrumented replay of
                  the same K steps): achieved = algorithmic bytes / time against the 8 TB/s HBM peak;
   cpu_baseline — the CPU oracle (oracle/, a restated port of the reference's single-threaded CPU path) timed on this
                  host on a bounded sample (rank 0, N = 1 only).
@@ -74,6 +75,18 @@ def algorithmic_bytes(n, workload, log_blowup=4, log_last=0):
             total += tree(m) + 24.0 * m  # per inner layer: tree + fold_line
             m /= 2
     return total
+
+
+def dominant_launch(kern):
+    """The kernel `roofline` is quoted on.  The timer's families are named by what a launch produces, and one family can hold launches of
+    very different sizes and kernels (tree5_fold_line: thirteen launches from 2^22 leaves down, three kernel templates), so "the family
+    with the largest summed time" can flip between two near-equal families from run to run and its average launch then describes no
+    launch in particular.  Taken instead: among the families within a factor two of the largest summed time, the one with the longest
+    AVERAGE launch — at the headline size the single 2^24-leaf launch of the first tree (also the largest kernel symbol of the rocprofv3
+    summary under profiles/)."""
+    top = max(k["total_ms"] for k in kern)
+    cand = [k for k in kern if k["total_ms"] >= 0.5 * top and k["launches"] > 0]
+    return max(cand, key=lambda k: k["total_ms"] / k["launches"]) if cand else kern[0]
 
 
 def traffic_from_profiles(kernel, n, workload):
@@ -418,7 +431,7 @@ def measure_config(frieda_amd, torch, device, n, workload, K, BSZ, D, cfg):
     ctx.set_kernel_timing(False)
     if kern:
         kern.sort(key=lambda k: -k["total_ms"])
-        dom = kern[0]
+        dom = dominant_launch(kern)
         ach = dom["alg_bytes"] / (dom["total_ms"] * 1e-3) / 1e9 if dom["total_ms"] > 0 else 0.0
         out["dominant_kernel"] = {"kernel": dom["name"], "avg_launch_us": 1e3 * dom["total_ms"] / max(dom["launches"], 1), "achieved_GBps": ach,
                                   "frac": ach / HBM_PEAK_GBS, "gpu_kernel_ms_per_call": sum(k["total_ms"] for k in kern) / 5,
@@ -1085,7 +1098,7 @@ def main():
     kern.sort(key=lambda k: -k["total_ms"])
     roofline = None
     if kern:
-        dom = kern[0]
+        dom = dominant_launch(kern)
         ach = dom["alg_bytes"] / (dom["total_ms"] * 1e-3) / 1e9 if dom["total_ms"] > 0 else 0.0
         roofline = {
             "bound": "hbm",
