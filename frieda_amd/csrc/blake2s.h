@@ -14,6 +14,9 @@
 #include <stdint.h>
 
 #include "field.h"
+#if defined(__HIP_DEVICE_COMPILE__)
+#include "blake2s_asm.h"
+#endif
 
 namespace frieda {
 
@@ -234,6 +237,18 @@ __device__ __forceinline__ void b2_merkle_block_runs(const uint32_t (&m)[16], ui
     b2_compress_runs<IDLE>(z, m, 0, 0, 0, 0, out);
 }
 #endif
+// ---- round 6: the same stream as ONE asm block per message shape (blake2s_asm.h, generated by tools/gen_blake2s_asm.py) ----
+// Every pin above is an inline-asm statement, and the compiler puts an s_nop 0 behind each one (180 per compression).  With the
+// whole compression as one block — the run order and the priorities of the 0xB000 setting, round 0 folded against the zero state
+// and the IV by the generator — there is no statement boundary inside and the order no longer depends on how the compiler treats the
+// pins: 2330 -> 2270 SIMD cycles per node-shaped wave-compression, 2225 -> 2130 per leaf (8 waves per SIMD; 2510 -> 2390 / 2430 ->
+// 2300 at 4; tools/blake2s_asm.hip, profiles/r06_asm_block.txt).  Measured against it and not kept: one raised level for every slow
+// run, the add3 runs at 1, the priority per instruction instead of per run, the leaf's two-operand adds after its add3 in a run
+// (all within 1 %), rotr 16 as v_pk_add_u16 op_sel (VOP3P: slower than v_alignbit: 2960 / 2790).
+// The block form serves the 0xB000 setting only; any other IDLE value (the A/B builds) and -DFRIEDA_B2_NO_ASM take the pinned form.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(FRIEDA_B2_NO_ASM)
+#define FRIEDA_B2_ASM_BLOCK 1
+#endif
 // settings of the throughput form, per message shape and kernel family (A/B knobs of the build: tools/build_variant.sh <name>
 // -DFRIEDA_B2_IDLE_NODE=0x...).  0xQPABC in bit fields: bits 12 - 13 P = wave priority of the runs of rotates, bits 14 - 15 Q = of
 // the runs that hold the v_add3 (0 = P), A / B / C = idle states (above).  SIMD cycles per wave-compression, node / leaf shape,
@@ -280,16 +295,34 @@ FR_HD void b2_compress_tp(const uint32_t (&h)[8], const uint32_t (&m)[16], uint3
 // IDLE = B2_LAT selects the plain form (call sites of the latency-bound kernels: one workgroup, or few waves per SIMD, where an idle
 // state is pure delay)
 constexpr int B2_LAT = -1;
+constexpr int B2_ASM_SETTING = 0xB000;  // the setting the generated asm blocks implement
 template <int IDLE = FRIEDA_B2_IDLE_NODE>
 FR_HD void b2_merkle_block(const uint32_t (&m)[16], uint32_t (&out)[8]) {
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(FRIEDA_B2_NO_RUNS)
-    if constexpr (IDLE >= 0)
-        b2_merkle_block_runs<IDLE>(m, out);
-    else
+    if constexpr (IDLE < 0) {
         b2_merkle_block_lat(m, out);
+    } else {
+#if defined(FRIEDA_B2_ASM_BLOCK)
+        if constexpr (IDLE == B2_ASM_SETTING)
+            b2_asm_node(m, out);
+        else
+#endif
+            b2_merkle_block_runs<IDLE>(m, out);
+    }
 #else
     b2_merkle_block_lat(m, out);
 #endif
+}
+// the leaf shape: 4 column words + 12 zero words (their adds fold: at compile time in the C++ forms, in the generator for the block)
+template <int IDLE = FRIEDA_B2_IDLE_LEAF>
+FR_HD void b2_merkle_leaf(uint32_t v0, uint32_t v1, uint32_t v2, uint32_t v3, uint32_t (&out)[8]) {
+    const uint32_t m[16] = {v0, v1, v2, v3, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#if defined(FRIEDA_B2_ASM_BLOCK) && !defined(FRIEDA_B2_NO_RUNS)
+    if constexpr (IDLE == B2_ASM_SETTING)
+        b2_asm_leaf(m, out);
+    else
+#endif
+        b2_merkle_block<IDLE>(m, out);
 }
 
 // Standard unkeyed Blake2s-256 of a message given as little-endian words, at most one... any number of

@@ -41,8 +41,7 @@ __global__ __launch_bounds__(256) void b2_chain_kernel(uint32_t* out, int iters,
     }
     for (int it = 0; it < iters; it++) {
         if (LEAF) {
-            const uint32_t mm[16] = {m[0], m[1], m[2], m[3], 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-            b2_merkle_block<FRIEDA_B2_IDLE_LEAF>(mm, h);  // (the leaf shape's own setting of the throughput form, as treedev::leaf_hash)
+            b2_merkle_leaf<FRIEDA_B2_IDLE_LEAF>(m[0], m[1], m[2], m[3], h);  // (the leaf shape's own setting of the throughput form, as treedev::leaf_hash)
             for (int i = 0; i < 4; i++) m[i] = h[i] ^ h[4 + i];
         } else {
             b2_merkle_block(m, h);

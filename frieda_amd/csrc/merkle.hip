@@ -45,9 +45,8 @@ __global__ __launch_bounds__(MK_THREADS) void merkle_leaf4_kernel(const uint32_t
                                                                   uint8_t* __restrict__ out) {
     size_t i = (size_t)blockIdx.x * MK_THREADS + threadIdx.x;
     if (i >= n) return;
-    uint32_t m[16] = {c0[i], c1[i], c2[i], c3[i], 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     uint32_t h[8];
-    b2_merkle_block(m, h);
+    b2_merkle_leaf(c0[i], c1[i], c2[i], c3[i], h);
     store_hash(out, i, h);
 }
 

@@ -39,8 +39,7 @@ __device__ __forceinline__ void load_children(const uint8_t* prev, size_t i, uin
 // leaf of 4 column words: the twelve zero message words are compile-time constants, so their adds fold away
 template <int IDLE = FRIEDA_B2_IDLE_LEAF>
 __device__ __forceinline__ void leaf_hash(uint32_t v0, uint32_t v1, uint32_t v2, uint32_t v3, uint32_t (&h)[8]) {
-    const uint32_t m[16] = {v0, v1, v2, v3, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    b2_merkle_block<IDLE>(m, h);
+    b2_merkle_leaf<IDLE>(v0, v1, v2, v3, h);
 }
 __device__ __forceinline__ size_t layer_off(uint32_t tree_log, uint32_t layer) {
     return ((size_t)64 << tree_log) - ((size_t)64 << layer);

@@ -180,6 +180,22 @@ def test_blake2s_ceiling_is_plausible(gpu_ctx):
     assert 1e10 < node < 1e11 and 1e10 < leaf < 1e11 and leaf > 0.98 * node
 
 
+def test_blake2s_throughput_form_regression(gpu_ctx):
+    """Guards the compression's instruction stream (VERDICT r05 task 1a): the throughput form — runs of one VALU rate class, the wave's
+    priority switched at the run boundaries (blake2s.h, round 5), as one asm block per shape (blake2s_asm.h, round 6) — costs
+    ~2260 (node) / ~2130 (leaf) SIMD cycles per wave-compression at 8 waves per SIMD (the pinned C++ form 2330 - 2390 / 2220 - 2260).
+    The scheduler's own order of rounds 1 - 4 cost 3975 / 3810 and the idle-state form 3300 / 3150: both must fail here.  Cycles, not
+    rates: the in-kernel clock moves with the box, the cycle count does not (best of three: a probe that shares the chip with another
+    job's tail reads high)."""
+    best = None
+    for _ in range(3):
+        ex = gpu_ctx.blake2s_ceiling_ex()
+        cur = (ex["node_cycles_per_wave_compression"], ex["leaf_cycles_per_wave_compression"])
+        best = cur if best is None else (min(best[0], cur[0]), min(best[1], cur[1]))
+    assert best[0] <= 2600, f"node-shaped compression costs {best[0]:.0f} SIMD cycles per wave (guard 2600): the run / priority structure was lost"
+    assert best[1] <= 2450, f"leaf-shaped compression costs {best[1]:.0f} SIMD cycles per wave (guard 2450): the run / priority structure was lost"
+
+
 def test_dev_at(gpu_ctx):
     """Column::at on a BaseField column and on a SecureColumn."""
     rng = np.random.default_rng(8)

@@ -1,0 +1,97 @@
+"""CPU guards on the instruction stream of the dominant kernel (VERDICT r05 task 1a).
+
+Round 5's +45 % came from HOW the Blake2s compression is laid out (runs of one VALU rate class, the wave's priority switched at the run
+boundaries); round 6 wrote that layout down as one generated asm block per message shape.  A toolchain update, a changed flag or an edit
+that silently falls back to the compiler's own fine interleave would keep every parity test green and lose the gain.  These tests compile
+`tree.hip` for gfx950 (device only, no GPU needed) and check the emitted ISA of `tree5r_kernel<LEAF4, false, true>` — the launch
+`bench.py` quotes its roofline on — plus the generator against its own interpreter and the committed header.
+"""
+import os
+import re
+import subprocess
+import sys
+from collections import Counter
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "frieda_amd", "csrc")
+HIPCC = "/opt/rocm/bin/hipcc"
+SLOW = ("v_alignbit_b32", "v_add3_u32")  # the slow VALU rate class of the compression
+
+
+@pytest.fixture(scope="module")
+def tree_isa(tmp_path_factory):
+    if not os.path.exists(HIPCC):
+        pytest.skip("no hipcc")
+    out = tmp_path_factory.mktemp("isa") / "tree.s"
+    # the flags of frieda_amd/csrc/Makefile
+    cmd = [HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-x", "hip", "--cuda-device-only", "-S",
+           "-I" + os.path.join(ROOT, "include"), os.path.join(CSRC, "tree.hip"), "-o", str(out)]
+    subprocess.check_call(cmd, stderr=subprocess.DEVNULL)
+    return out.read_text()
+
+
+def kernel(isa, mangled_part):
+    """(instruction mnemonics, metadata text) of the one kernel whose mangled name contains `mangled_part`"""
+    found = [m for m in re.finditer(r"^(_Z\w+):[^\n]*\n(.*?)s_endpgm", isa, re.S | re.M) if mangled_part in m.group(1)]
+    assert len(found) == 1, [m.group(1) for m in found]
+    name, body = found[0].group(1), found[0].group(2)
+    ins = [ln.split()[0] for ln in body.splitlines() if ln.startswith("\t") and ln.strip() and not ln.strip().startswith((".", ";"))]
+    kd = isa[isa.index(".amdhsa_kernel " + name):]
+    kd = kd[: kd.index(".end_amdhsa_kernel")]
+    return ins, kd
+
+
+def kd_int(kd, key):
+    return int(re.search(r"\." + key + r"\s+(\d+)", kd).group(1))
+
+
+def test_dominant_kernel_keeps_the_throughput_form(tree_isa):
+    # tree5r_kernel<MODE = LEAF4 (0), SKIP = false, TP = true>: leaf level + 4 node levels of a proof's first tree
+    ins, kd = kernel(tree_isa, "tree5r_kernelILi0ELb0ELb1EE")
+    c = Counter(ins)
+    assert kd_int(kd, "amdhsa_next_free_vgpr") <= 64, "more than 64 VGPRs: the launch drops below 8 waves per SIMD"
+    assert kd_int(kd, "amdhsa_private_segment_fixed_size") == 0, "scratch in use: something spilled"
+    # 9 compressions per thread (4 leaves, 2 + 1 nodes in registers, 2 LDS levels): 80 G functions each, 4 rotates per G
+    assert c["v_alignbit_b32"] in range(2800, 2900), c["v_alignbit_b32"]
+    assert c["s_setprio"] >= 1600, f"{c['s_setprio']} s_setprio: the priority switches at the run boundaries are gone"
+    # the pinned C++ form carried 1556 compiler-inserted s_nop (one behind every pin statement); the asm blocks have none inside
+    assert c["s_nop"] <= 64, f"{c['s_nop']} s_nop: the compressions are no longer single asm blocks"
+    # mean length of a run of VALU instructions of one rate class (the scheduler's own order: 2.1; the run form: > 5)
+    runs, cur, n = [], None, 0
+    for op in ins:
+        if not op.startswith("v_"):
+            continue
+        cls = op in SLOW
+        if cls == cur:
+            n += 1
+        else:
+            if cur is not None:
+                runs.append(n)
+            cur, n = cls, 1
+    runs.append(n)
+    mean = sum(runs) / len(runs)
+    assert mean >= 4.0, f"mean VALU class-run length {mean:.2f}: the run structure was lost"
+
+
+def test_plain_form_stays_plain(tree_isa):
+    # TP = false (launches below FRIEDA_TP_MIN_WGS workgroups): the latency form must carry no priority switches
+    ins, _ = kernel(tree_isa, "tree5r_kernelILi0ELb0ELb0EE")
+    assert Counter(ins)["s_setprio"] == 0
+
+
+def test_generated_header_is_current_and_correct():
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    try:
+        import gen_blake2s_asm as G
+    finally:
+        sys.path.pop(0)
+    G.selfcheck(G.VARIANTS)  # the emitted text, interpreted on integers, equals a plain Blake2s F(0, m, 0, 0)
+    out = subprocess.check_output([sys.executable, os.path.join(ROOT, "tools", "gen_blake2s_asm.py")], text=True)
+    assert out == open(os.path.join(CSRC, "blake2s_asm.h")).read(), "frieda_amd/csrc/blake2s_asm.h is stale: regenerate it"
+    # the counts the design documents: a node compression is 476 slow + 488 fast VALU instructions, a leaf 350 + 591
+    n_node, _, cn = G.build("node", G.VARIANTS)
+    n_leaf, _, cl = G.build("leaf", G.VARIANTS)
+    assert (n_node, cn["slow"], cn["fast"]) == (16, 476, 488)
+    assert (n_leaf, cl["slow"], cl["fast"]) == (4, 350, 591)
