@@ -39,6 +39,7 @@ extern "C" {
     pub fn frieda_abi_version() -> u32;
     pub fn frieda_status_string(status: c_int) -> *const c_char;
     pub fn frieda_last_error(ctx: *const frieda_ctx) -> *const c_char;
+    pub fn frieda_ctx_notes(ctx: *const frieda_ctx) -> *const c_char;
 
     // context
     pub fn frieda_ctx_create(device: c_int, stream: *mut c_void, out: *mut *mut frieda_ctx) -> c_int;
@@ -52,6 +53,7 @@ extern "C" {
     /// test hook (include/frieda_hip_testing.h), not part of the boundary
     pub fn frieda_ctx_test_set_draw_bound(ctx: *mut frieda_ctx, bound: u32) -> c_int;
     pub fn frieda_ctx_test_set_grind_first_log(ctx: *mut frieda_ctx, log_first: u32) -> c_int;
+    pub fn frieda_ctx_test_set_arena_limit(ctx: *mut frieda_ctx, bytes: u64) -> c_int;
     pub fn frieda_test_parse_cpulist(text: *const c_char, out_cpus: *mut c_int, cap: usize, n: *mut usize) -> c_int;
     /// batch policy: device workspace one blob adds to a batched call; the cut of `count` equal-length blobs into calls
     pub fn frieda_workspace_bytes(len: usize, log_blowup_factor: u32, log_last_layer_degree_bound: u32, prove: c_int) -> usize;
@@ -89,6 +91,7 @@ extern "C" {
     pub fn frieda_multi_uses_rccl(m: *const frieda_multi) -> c_int;
     pub fn frieda_multi_gather_count(m: *const frieda_multi) -> u64;
     pub fn frieda_multi_ctx(m: *mut frieda_multi, device_slot: u32) -> *mut frieda_ctx;
+    pub fn frieda_multi_release_workspace(m: *mut frieda_multi) -> c_int;
     pub fn frieda_multi_near_cpus(m: *const frieda_multi, device_slot: u32, out_cpus: *mut c_int, cap: usize) -> u32;
     pub fn frieda_commit_many(m: *mut frieda_multi, blobs: *const *const u8, lens: *const usize, count: u32, log_blowup_factor: u32, out_roots: *mut u8) -> c_int;
     pub fn frieda_prove_many(m: *mut frieda_multi, blobs: *const *const u8, lens: *const usize, count: u32, seeds: *const u64, cfg: frieda_pcs_config, out_commitments: *mut u8, out_proofs: *mut *mut frieda_proof) -> c_int;

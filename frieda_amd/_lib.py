@@ -73,6 +73,7 @@ def lib():
         "frieda_abi_version": (u32, []),
         "frieda_status_string": (C.c_char_p, [C.c_int]),
         "frieda_last_error": (C.c_char_p, [vp]),
+        "frieda_ctx_notes": (C.c_char_p, [vp]),
         "frieda_ctx_create": (C.c_int, [C.c_int, vp, pp]),
         "frieda_ctx_destroy": (C.c_int, [vp]),
         "frieda_ctx_synchronize": (C.c_int, [vp]),
@@ -82,6 +83,7 @@ def lib():
         "frieda_ctx_set_option": (C.c_int, [vp, C.c_char_p, C.c_int64]),
         "frieda_ctx_test_set_draw_bound": (C.c_int, [vp, u32]),
         "frieda_ctx_test_set_grind_first_log": (C.c_int, [vp, u32]),
+        "frieda_ctx_test_set_arena_limit": (C.c_int, [vp, u64]),
         "frieda_workspace_bytes": (sz, [sz, u32, u32, C.c_int]),
         "frieda_batch_plan": (C.c_int, [vp, sz, u32, u32, C.c_int, u32, u32, C.POINTER(u32), sz, C.POINTER(u32)]),
         "frieda_ctx_set_kernel_timing": (C.c_int, [vp, C.c_int]),
@@ -112,6 +114,7 @@ def lib():
         "frieda_multi_uses_rccl": (C.c_int, [vp]),
         "frieda_multi_gather_count": (u64, [vp]),
         "frieda_multi_ctx": (vp, [vp, u32]),
+        "frieda_multi_release_workspace": (C.c_int, [vp]),
         "frieda_multi_near_cpus": (u32, [vp, u32, C.POINTER(C.c_int), sz]),
         "frieda_test_parse_cpulist": (C.c_int, [C.c_char_p, C.POINTER(C.c_int), sz, C.POINTER(sz)]),
         "frieda_commit_many": (C.c_int, [vp, pp, C.POINTER(sz), u32, u32, vp]),

@@ -442,6 +442,10 @@ class MultiContext:
         except Exception:
             pass
 
+    def release_workspace(self):
+        """Frees the device workspaces (two per device, up to the batch budget each) and upload rings the handle keeps between calls."""
+        self._check(self._L.frieda_multi_release_workspace(self._h))
+
     @property
     def device_count(self):
         return self._L.frieda_multi_device_count(self._h)

@@ -24,6 +24,25 @@ def _multi_for(device):
     return _multi[device]
 
 
+def release_workspaces():
+    """The handles cached above keep their device workspaces between calls (up to two batch budgets per device: that is what makes a
+    second call cheap).  A process that is done with batches for a while hands the memory back with this; the next call allocates again."""
+    for mc in _multi.values():
+        mc.release_workspace()
+
+
+def close():
+    """Destroys the cached handles (workspaces, streams, RCCL communicators).  Registered with atexit."""
+    while _multi:
+        _, mc = _multi.popitem()
+        mc.close()
+
+
+import atexit  # noqa: E402
+
+atexit.register(close)
+
+
 def commit_many_on_node(blobs, log_blowup_factor, devices=None):
     """ONE process, every GPU of the node, through the C ABI (frieda_commit_many): blob i -> devices[i mod n]; the roots are gathered
     with ncclAllGather on a single-process RCCL communicator.  The alternative to one process per GPU + torch.distributed below."""

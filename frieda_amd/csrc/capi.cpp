@@ -28,6 +28,7 @@ const char* frieda_status_string(int status) {
 }
 
 const char* frieda_last_error(const frieda_ctx* ctx) { return ctx ? ctx->c.err.c_str() : "null context"; }
+const char* frieda_ctx_notes(const frieda_ctx* ctx) { return ctx ? ctx->c.notes.c_str() : ""; }
 
 int frieda_ctx_create(int device, void* stream, frieda_ctx** out) {
     if (!out) return FRIEDA_ERR_ARG;
@@ -57,15 +58,22 @@ int frieda_ctx_create(int device, void* stream, frieda_ctx** out) {
     }
     // Two kernels want more LDS than the 64 KB default.  A device (or build) that refuses either keeps every other path: the generic
     // transform kernel then takes 3 columns per workgroup (51 KB) and small domains take the general path.
+    // (what gets degraded is recorded in `notes`, frieda_ctx_notes — a successful create leaves last_error empty)
     if (k::ntt_opt_in_dynamic_lds() != hipSuccess) {
         (void)hipGetLastError();
+        ctx->c.tuning.lds_opt_in_ok = false;
         if (ctx->c.tuning.ntt_cpw > 3) ctx->c.tuning.ntt_cpw = 3;
-        ctx->c.err = "note: 68 KB of dynamic LDS refused for the generic transform kernel; 3 columns per workgroup";
+        ctx->c.notes += "68 KB of dynamic LDS refused for the transform kernels: 3 columns per workgroup, no side-by-side fold kernel\n";
     }
     if (!k::small_first_opt_in()) {
         ctx->c.tuning.no_small_fused = true;
-        ctx->c.err = "note: the fused small-domain kernel does not fit this device's LDS; general path for small domains";
+        ctx->c.notes += "the fused small-domain kernel does not fit this device's LDS: general path for small domains\n";
     }
+    size_t mem_free = 0, mem_total = 0;
+    if (hipMemGetInfo(&mem_free, &mem_total) == hipSuccess)
+        ctx->c.tuning.device_mem_bytes = mem_total;  // the batch policy's budget is a share of THIS device (batch_budget_bytes)
+    else
+        (void)hipGetLastError();
     *out = ctx;
     return FRIEDA_OK;
 }
@@ -181,6 +189,12 @@ int frieda_ctx_test_set_draw_bound(frieda_ctx* ctx, uint32_t bound) {
 int frieda_ctx_test_set_grind_first_log(frieda_ctx* ctx, uint32_t log_first) {
     if (!ctx || (log_first != 0 && (log_first < 8 || log_first > 40))) return FRIEDA_ERR_ARG;
     ctx->c.tuning.test_grind_first_log = log_first;
+    return FRIEDA_OK;
+}
+
+int frieda_ctx_test_set_arena_limit(frieda_ctx* ctx, uint64_t bytes) {
+    if (!ctx) return FRIEDA_ERR_ARG;
+    ctx->c.tuning.test_arena_limit = bytes;
     return FRIEDA_OK;
 }
 

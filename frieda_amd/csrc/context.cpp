@@ -6,8 +6,11 @@
 #include <cstdio>
 
 #include <algorithm>
+#include <mutex>
 
 #include "host.h"
+
+extern char** environ;  // (POSIX; scanned once for FRIEDA_* names nobody reads)
 
 namespace frieda {
 
@@ -118,7 +121,11 @@ const KnobDesc KNOBS[] = {
     {"FRIEDA_T5_REG3_LOG", 0, 30, [](Tuning& t, long v) { t.t5_reg3_log = (uint32_t)v; return true; }},
     {"FRIEDA_T9_MAX_LOG", 8, 19, [](Tuning& t, long v) { t.t9_max_log = (uint32_t)v; return true; }},
     {"FRIEDA_TOP_MAX_LOG", 9, 11, [](Tuning& t, long v) { t.top_max_log = (uint32_t)v; return true; }},
-    {"FRIEDA_NTT_CPW", 1, 4, [](Tuning& t, long v) { t.ntt_cpw = (uint32_t)v; return true; }},
+    {"FRIEDA_NTT_CPW", 1, 4, [](Tuning& t, long v) {
+         if (v == 4 && !t.lds_opt_in_ok) return false;  // four columns per workgroup need the 68 KB LDS opt-in this device refused
+         t.ntt_cpw = (uint32_t)v;
+         return true;
+     }},
     {"FRIEDA_NTT_CPW_SMALL", 1, 4, [](Tuning& t, long v) { t.ntt_cpw_small = (uint32_t)v; return true; }},
     {"FRIEDA_NTT_REP", 0, 2, [](Tuning& t, long v) { t.ntt_rep = (uint32_t)v; return true; }},
     {"FRIEDA_NTT_NO_CP", 0, 1, [](Tuning& t, long v) { t.ntt_no_cp = v != 0; return true; }},
@@ -157,8 +164,29 @@ bool tuning_set(Tuning& t, const char* name, long value) {
     return false;
 }
 
+// Process-level FRIEDA_* variables that are read where they apply (not options of a context); DESIGN.md §10
+static const char* const PROCESS_VARS[] = {"FRIEDA_HIP_LIB", "FRIEDA_RCCL_PATH", "FRIEDA_MULTI_FORCE_RCCL", "FRIEDA_MULTI_NO_PREFETCH",
+                                           "FRIEDA_MULTI_NO_NUMA_PIN", "FRIEDA_BENCH_FORCE_DIST", "FRIEDA_BENCH_CPU_THREADS", "FRIEDA_TEST_"};
+// A FRIEDA_* variable nobody reads is almost always a typo or a knob of an older round (FRIEDA_TEST_GRIND_FIRST_LOG became a test
+// hook in round 5): say so once per process instead of silently doing nothing.
+static void warn_unknown_env_once() {
+    static std::once_flag once;
+    std::call_once(once, [] {
+        for (char** e = ::environ; e && *e; e++) {
+            if (strncmp(*e, "FRIEDA_", 7) != 0) continue;
+            const char* eq = strchr(*e, '=');
+            const size_t len = eq ? (size_t)(eq - *e) : strlen(*e);
+            bool known = false;
+            for (const KnobDesc& k : KNOBS) known = known || (strlen(k.name) == len && strncmp(k.name, *e, len) == 0);
+            for (const char* pv : PROCESS_VARS) known = known || strncmp(pv, *e, strlen(pv)) == 0;
+            if (!known) fprintf(stderr, "libfrieda_hip: note: environment variable %.*s is not an option of this library (ignored)\n", (int)len, *e);
+        }
+    });
+}
+
 Tuning tuning_from_env() {
     Tuning t;
+    warn_unknown_env_once();
     for (const KnobDesc& k : KNOBS) {
         const char* e = getenv(k.name);
         if (!e) continue;
@@ -239,6 +267,10 @@ int Ctx::hip_fail(hipError_t e, const char* what) {
 }
 
 int Ctx::ensure_arena(size_t bytes) {
+    if (tuning.test_arena_limit && bytes > tuning.test_arena_limit) {  // test hook: a device with less memory than this one
+        err = "workspace of " + std::to_string(bytes) + " B refused by the test limit";
+        return FRIEDA_ERR_NOMEM;
+    }
     if (bytes <= arena_bytes) return FRIEDA_OK;
     if (arena) {
         FR_HIP(this, hipStreamSynchronize(stream));

@@ -94,6 +94,7 @@ struct Ctx {
     size_t pinned_bytes = 0;
     void* pinned_in = nullptr;  // page-locked input block for lone small host blobs (read by the fused small-domain kernel in place)
     std::string err;
+    std::string notes;  // what context creation degraded (refused LDS opt-ins ...), one line each: frieda_ctx_notes — never in `err`
     double phase_ms[8] = {0};  // host wall-clock marks of the last prove() (ms since entry): enqueued, device done, queries, gather, assembled
     KernelTimerImpl* timer = nullptr;  // non-null while kernel timing is enabled
     std::unique_ptr<ProveJob, ProveJobDeleter> job;  // the proof in flight, if any
@@ -177,7 +178,9 @@ int commit_batch_finish(Ctx* ctx, uint8_t* out_roots);
 // One implementation for frieda_prove_many / frieda_commit_many (multi.cpp), frieda_batch_plan (callers that drive _begin / _finish
 // themselves: frieda_amd.BatchPipeline, bench.py) and the tests.
 size_t workspace_bytes_per_blob(size_t len, uint32_t log_blowup, uint32_t log_last_layer, bool prove, bool data_on_device);
-uint64_t batch_budget_bytes(const k::Tuning& t);  // FRIEDA_BATCH_BUDGET_MB, or the default: sixteen proofs of a 2^24 domain (blowup 2^4), ~43 GB
+// FRIEDA_BATCH_BUDGET_MB, or the default: sixteen proofs of a 2^24 domain (blowup 2^4), ~43 GB — clamped to the device the context sits on:
+// the default to 15 % of its memory (two calls in flight: 30 %, what 43 GB are of an MI355X's 288 GB), an explicit value to 45 %
+uint64_t batch_budget_bytes(const k::Tuning& t);
 uint32_t batch_per_call(const k::Tuning& t, size_t ws_per_blob, uint32_t count, uint32_t in_flight);
 void batch_cut(uint32_t count, uint32_t per_call, uint32_t in_flight, std::vector<uint32_t>& calls);
 

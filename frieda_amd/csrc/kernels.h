@@ -59,6 +59,11 @@ struct Tuning {
     uint32_t grind_iters = 0;            // FRIEDA_GRIND_ITERS: nonces per lane and claim in the batched grind (window = 256 x this); 0 = by batch size
     uint32_t batch_calls_per_ctx = 1;    // FRIEDA_BATCH_CALLS_PER_CTX: a stream is cut into at least this many calls per context in flight
                                          // (measured, profiles/r05_batch_policy_sweep.txt: 1 beats 2 by 3 % at 2^20 and 30 % at 1 KiB blobs, equal at 2^22 / 2^24)
+    // facts about the context's device, recorded at creation (not knobs: tuning_set does not reach them)
+    uint64_t device_mem_bytes = 0;       // total device memory (hipMemGetInfo); 0 = unknown (a Tuning without a context): the budget is not clamped
+    bool lds_opt_in_ok = true;           // the 68 KB dynamic-LDS opt-in of the transform kernels was granted: gates FRIEDA_NTT_CPW = 4 and the
+                                         // four-columns-side-by-side fold2 kernel (ntt.hip), also against a later set_option
+    uint64_t test_arena_limit = 0;       // test hook (frieda_ctx_test_set_arena_limit): ensure_arena refuses more than this many bytes (0 = off)
 };
 // trees of a proof with at least 2^(this) leaves are built without the two levels above their leaves (tree.hip TreeArgs::skip_bc,
 // decommit.hip node_from_values, prover.cpp's host-planner fallback): ONE rule for the three places, by the blobs of the call

@@ -183,6 +183,7 @@ static void drain_ctx(frieda_ctx* c) {
 }
 
 inline size_t ring_stride(size_t len) { return (len + 255) & ~(size_t)255; }
+constexpr uint32_t RING_SLOTS_C = 3;  // (= RING_SLOTS below)
 
 // A device's share of the blobs (blob d, d + n, ...) cut into units = calls of the batched kernels.  A run of equal-length blobs is
 // cut by the library's batch policy (host.h: workspace bytes in flight, two calls in flight per device), anything else is a single
@@ -191,18 +192,25 @@ inline size_t ring_stride(size_t len) { return (len + 255) & ~(size_t)255; }
 struct Unit {
     uint32_t slot, cnt;
 };
+//  The policy's budget is a figure for an otherwise empty MI355X.  `mem_cap` = the bytes this device can give the pass NOW
+// (what hipMemGetInfo reports free + what the device's two contexts and its ring already hold, less a margin; 0 = unknown): two calls'
+// workspaces and three ring slots must fit.  `shrink`: the per-call count halved that many times (the workers' retry after a
+// FRIEDA_ERR_NOMEM that the estimate did not foresee).  `from_slot`: the device's first blob not yet done.
 static void cut_device_units(const size_t* lens, uint32_t d, uint32_t n, uint32_t mine, bool batchable, bool prove, uint32_t log_blowup,
-                             uint32_t log_last, const k::Tuning& tune, bool first_single, std::vector<Unit>& units, size_t& ring_need) {
+                             uint32_t log_last, const k::Tuning& tune, bool first_single, std::vector<Unit>& units, size_t& ring_need,
+                             uint32_t from_slot = 0, uint64_t mem_cap = 0, uint32_t shrink = 0) {
     units.clear();
     ring_need = 0;
     std::vector<uint32_t> calls;
-    for (uint32_t slot = 0; slot < mine;) {
+    for (uint32_t slot = from_slot; slot < mine;) {
         const uint32_t i0 = d + slot * n;
         uint32_t run = 1;
         while (batchable && slot + run < mine && lens[i0 + run * n] == lens[i0]) run++;
         const size_t ws = workspace_bytes_per_blob(lens[i0], log_blowup, log_last, prove, true);  // 0: the call itself reports the shape error
-        const uint32_t per = ws ? batch_per_call(tune, ws, run, 2) : 1u;
-        if (first_single && slot == 0 && mine > 1 && run > 1) {
+        uint32_t per = ws ? batch_per_call(tune, ws, run, 2) : 1u;
+        if (ws && mem_cap) per = (uint32_t)std::min<uint64_t>(per, std::max<uint64_t>(1, mem_cap / (2 * (uint64_t)ws + RING_SLOTS_C * ring_stride(lens[i0]))));
+        per = std::max<uint32_t>(1, per >> std::min<uint32_t>(shrink, 31));
+        if (first_single && slot == from_slot && mine - from_slot > 1 && run > 1) {
             // Host blobs: a unit starts when its last blob has arrived, and the upload of unit u + 1 runs under the kernels of unit u.  A
             // pageable upload is about as slow per blob as the proof itself, so the units grow from one blob by at most half a unit at
             // a time (1, 2, 3, 5, 8, 12, ...) until they reach the policy's size: the chip starts after one upload and never waits for
@@ -234,7 +242,7 @@ static void cut_device_units(const size_t* lens, uint32_t d, uint32_t n, uint32_
 // idle (measured: 1.15 ms per unit of four 15.7 MB blobs, 0.3 ms per blob — profiles/r03_multi_trace_before.txt).  Instead
 // each device has a copy stream and three staging slots in device memory: the blobs of unit u + 2 are uploaded while units u and
 // u + 1 compute, an event orders the unit's first kernel behind its upload, and the kernels read the blobs where they landed.
-constexpr uint32_t RING_SLOTS = 3;
+constexpr uint32_t RING_SLOTS = RING_SLOTS_C;
 struct UploadRing {
     hipStream_t stream = nullptr;
     hipEvent_t ready[RING_SLOTS] = {};
@@ -267,6 +275,35 @@ struct frieda_multi {
     // enqueue the upload of `cnt` host blobs of `len` bytes (blob k at ptrs[k]) into slot `s` of device d; records ready[s]
     int upload(size_t d, uint32_t s, const uint8_t* const* ptrs, size_t len, uint32_t cnt, std::string& what);
     int gather_roots(const std::vector<std::vector<Hash32>>& local, uint32_t count, uint8_t* out_roots);
+    // device d's worker thread only (the device is current).  Bytes a pass over this device may plan with: free now + held by the
+    // device's two workspaces and its ring, less 10 %; 0 = the runtime would not say.
+    uint64_t mem_cap_now(size_t d) const {
+        size_t fr = 0, tot = 0;
+        if (hipMemGetInfo(&fr, &tot) != hipSuccess) {
+            (void)hipGetLastError();
+            return 0;
+        }
+        const uint64_t held = (uint64_t)ctx[2 * d]->c.arena_bytes + ctx[2 * d + 1]->c.arena_bytes + (uint64_t)ring[d].cap * RING_SLOTS;
+        return (fr + held) / 10 * 9;
+    }
+    // frees device d's two workspaces (nothing may be in flight on them): before a retry with smaller calls, and for
+    // frieda_multi_release_workspace
+    void drop_device_workspace(size_t d, bool ring_too) {
+        for (frieda_ctx* c : {ctx[2 * d], ctx[2 * d + 1]}) {
+            (void)hipStreamSynchronize(c->c.stream);
+            if (c->c.arena) (void)hipFree(c->c.arena);
+            c->c.arena = nullptr;
+            c->c.arena_bytes = 0;
+        }
+        if (ring_too) {
+            (void)hipStreamSynchronize(ring[d].stream);
+            for (uint32_t k = 0; k < RING_SLOTS; k++) {
+                if (ring[d].slot[k]) (void)hipFree(ring[d].slot[k]);
+                ring[d].slot[k] = nullptr;
+            }
+            ring[d].cap = 0;
+        }
+    }
 };
 
 int frieda_multi::ensure_ring(size_t d, size_t bytes, std::string& what) {
@@ -492,6 +529,16 @@ int frieda_test_parse_cpulist(const char* text, int* out_cpus, size_t cap, size_
         return FRIEDA_ERR_NOMEM;
     }
 }
+int frieda_multi_release_workspace(frieda_multi* m) {
+    if (!m) return FRIEDA_ERR_ARG;
+    for (size_t d = 0; d < m->devices.size(); d++) {
+        if (hipSetDevice(m->devices[d]) != hipSuccess) return m->fail(FRIEDA_ERR_HIP, "hipSetDevice");
+        for (frieda_ctx* c : {m->ctx[2 * d], m->ctx[2 * d + 1]})
+            if (c->c.job || c->c.commit_pending) return m->fail(FRIEDA_ERR_ARG, "a call is in flight on this handle");
+        m->drop_device_workspace(d, true);
+    }
+    return FRIEDA_OK;
+}
 frieda_ctx* frieda_multi_ctx(frieda_multi* m, uint32_t device_slot) {
     return m && device_slot < m->devices.size() ? m->ctx[2 * (size_t)device_slot] : nullptr;
 }
@@ -516,6 +563,7 @@ int frieda_commit_many(frieda_multi* m, const uint8_t* const* blobs, const size_
             workers.emplace_back([&, d] {
                 pin_this_thread(m->near_cpus[d]);
                 frieda_ctx* cx[2] = {m->ctx[2 * d], m->ctx[2 * d + 1]};
+                cx[1]->c.tuning.test_arena_limit = cx[0]->c.tuning.test_arena_limit;  // (test hook set through frieda_multi_ctx: the slot's both contexts)
                 const bool pf = m->prefetch;
                 struct DrainUploads {  // no upload may still be reading the caller's blobs when the worker returns
                     frieda_multi* m;
@@ -530,19 +578,34 @@ int frieda_commit_many(frieda_multi* m, const uint8_t* const* blobs, const size_
                     // batched kernels, sized by the batch policy); two units in flight on the two contexts, the blobs of the unit after them being uploaded
                     // meanwhile on the copy stream.
                     const uint32_t mine = (uint32_t)local[d].size();
+                    if (mine == 0) return;
+                    if (hipSetDevice(m->devices[d]) != hipSuccess) {
+                        status[d] = FRIEDA_ERR_HIP;
+                        what[d] = "hipSetDevice";
+                        abort.store(true);
+                        return;
+                    }
+                    // One PASS over what is left of this device's blobs; a pass that ran out of device memory is repeated from its first
+                    // unfinished blob with the calls halved (pass_st / pass_msg: the pass's own status, published when final).
+                    uint32_t done = 0, shrink = 0;
+                    for (;;) {
+                    int pass_st = FRIEDA_OK;
+                    std::string pass_msg;
+                    uint32_t largest = 1;
+                    auto pass = [&] {
                     std::vector<Unit> units;
                     size_t ring_need = 0;
-                    cut_device_units(lens, (uint32_t)d, (uint32_t)n, mine, true, false, log_blowup_factor, 0, cx[0]->c.tuning, pf, units, ring_need);
+                    cut_device_units(lens, (uint32_t)d, (uint32_t)n, mine, true, false, log_blowup_factor, 0, cx[0]->c.tuning, pf, units, ring_need, done,
+                                     m->mem_cap_now(d), shrink);
+                    for (const Unit& un : units) largest = std::max(largest, un.cnt);
                     auto bail_msg = [&](int rc, const std::string& msg) {
-                        if (status[d] == FRIEDA_OK) {
-                            status[d] = rc;
-                            what[d] = msg;
+                        if (pass_st == FRIEDA_OK) {
+                            pass_st = rc;
+                            pass_msg = msg;
                         }
-                        abort.store(true);
                     };
                     auto bail = [&](int rc, frieda_ctx* c) { bail_msg(rc, c->c.err); };
                     if (units.empty()) return;
-                    if (hipSetDevice(m->devices[d]) != hipSuccess) return bail_msg(FRIEDA_ERR_HIP, "hipSetDevice");
                     std::string uw;
                     if (pf) {
                         const int rr = m->ensure_ring(d, ring_need, uw);
@@ -584,8 +647,11 @@ int frieda_commit_many(frieda_multi* m, const uint8_t* const* blobs, const size_
                             if (rc != FRIEDA_OK) bail_msg(rc, uw);
                         }
                         const int rf = commit_batch_finish(&cx[u & 1]->c, local[d][units[u].slot].data());
-                        if (rf != FRIEDA_OK) bail(rf, cx[u & 1]);
-                        if (status[d] != FRIEDA_OK || abort.load()) {
+                        if (rf != FRIEDA_OK)
+                            bail(rf, cx[u & 1]);
+                        else
+                            done = units[u].slot + units[u].cnt;
+                        if (pass_st != FRIEDA_OK || abort.load()) {
                             if (next_begun) {
                                 std::vector<uint8_t> r(32 * (size_t)units[u + 1].cnt);
                                 (void)commit_batch_finish(&cx[(u + 1) & 1]->c, r.data());
@@ -593,6 +659,20 @@ int frieda_commit_many(frieda_multi* m, const uint8_t* const* blobs, const size_
                             return;
                         }
                     }
+                    };  // pass
+                    pass();
+                    if (pass_st == FRIEDA_ERR_NOMEM && largest > 1 && !abort.load() && shrink < 16) {
+                        m->drop_device_workspace(d, pf);  // (synchronises the contexts' streams and the copy stream first)
+                        shrink++;
+                        continue;
+                    }
+                    if (pass_st != FRIEDA_OK) {
+                        status[d] = pass_st;
+                        what[d] = pass_msg;
+                        abort.store(true);
+                    }
+                    return;
+                    }  // passes
                 } catch (...) {  // nothing may unwind out of a worker thread
                     what[d] = "host allocation failed";
                     status[d] = FRIEDA_ERR_NOMEM;
@@ -653,6 +733,7 @@ int frieda_prove_many(frieda_multi* m, const uint8_t* const* blobs, const size_t
                 // flight: begin(u + 1) is enqueued on the other context before finish(u) waits; the blobs of unit u + 2 are
                 // uploaded on the copy stream meanwhile.
                 frieda_ctx* cx[2] = {m->ctx[2 * d], m->ctx[2 * d + 1]};
+                cx[1]->c.tuning.test_arena_limit = cx[0]->c.tuning.test_arena_limit;  // (test hook set through frieda_multi_ctx: the slot's both contexts)
                 const uint32_t mine = (uint32_t)local[d].size();
                 if (mine == 0) return;
                 // batches need the device transcript (prover.cpp): small last layers, and neither context switched to the host channel
@@ -660,19 +741,33 @@ int frieda_prove_many(frieda_multi* m, const uint8_t* const* blobs, const size_t
                 const bool batchable = cfg.log_last_layer_degree_bound <= 11 && cfg.log_blowup_factor <= 11 &&
                                        cfg.log_last_layer_degree_bound + cfg.log_blowup_factor <= 11 && !cx[0]->c.host_channel &&
                                        !cx[1]->c.host_channel;
+                if (hipSetDevice(m->devices[d]) != hipSuccess) {
+                    status[d] = FRIEDA_ERR_HIP;
+                    what[d] = "hipSetDevice";
+                    abort.store(true);
+                    return;
+                }
+                // passes over what is left of this device's blobs: see frieda_commit_many (a pass that ran out of device memory is
+                // repeated from its first unfinished blob with the calls halved)
+                uint32_t done = 0, shrink = 0;
+                for (;;) {
+                int pass_st = FRIEDA_OK;
+                std::string pass_msg;
+                uint32_t largest = 1;
+                auto pass = [&] {
                 std::vector<Unit> units;
                 size_t ring_need = 0;
                 cut_device_units(lens, (uint32_t)d, (uint32_t)n, mine, batchable, true, cfg.log_blowup_factor, cfg.log_last_layer_degree_bound,
-                                 cx[0]->c.tuning, pf, units, ring_need);
+                                 cx[0]->c.tuning, pf, units, ring_need, done, m->mem_cap_now(d), shrink);
+                for (const Unit& un : units) largest = std::max(largest, un.cnt);
                 auto bail_msg = [&](int rc, const std::string& msg) {
-                    if (status[d] == FRIEDA_OK) {
-                        status[d] = rc;
-                        what[d] = msg;
+                    if (pass_st == FRIEDA_OK) {
+                        pass_st = rc;
+                        pass_msg = msg;
                     }
-                    abort.store(true);
                 };
                 auto bail = [&](int rc, frieda_ctx* c) { bail_msg(rc, c->c.err); };
-                if (hipSetDevice(m->devices[d]) != hipSuccess) return bail_msg(FRIEDA_ERR_HIP, "hipSetDevice");
+                if (units.empty()) return;
                 std::string uw;
                 if (pf) {
                     const int rr = m->ensure_ring(d, ring_need, uw);
@@ -743,12 +838,29 @@ int frieda_prove_many(frieda_multi* m, const uint8_t* const* blobs, const size_t
                         if (rc != FRIEDA_OK) bail_msg(rc, uw);
                     }
                     const int rf = finish(u);
-                    if (rf != FRIEDA_OK && status[d] == FRIEDA_OK) bail(rf, cx[u & 1]);
-                    if (status[d] != FRIEDA_OK || abort.load()) {
+                    if (rf != FRIEDA_OK)
+                        bail(rf, cx[u & 1]);
+                    else
+                        done = units[u].slot + units[u].cnt;
+                    if (pass_st != FRIEDA_OK || abort.load()) {
                         if (next_begun) drain_ctx(cx[(u + 1) & 1]);  // the unit already enqueued: the context must stay reusable
                         return;
                     }
                 }
+                };  // pass
+                pass();
+                if (pass_st == FRIEDA_ERR_NOMEM && largest > 1 && !abort.load() && shrink < 16) {
+                    m->drop_device_workspace(d, pf);  // (synchronises the contexts' streams and the copy stream first)
+                    shrink++;
+                    continue;
+                }
+                if (pass_st != FRIEDA_OK) {
+                    status[d] = pass_st;
+                    what[d] = pass_msg;
+                    abort.store(true);
+                }
+                return;
+                }  // passes
               } catch (...) {  // nothing may unwind out of a worker thread
                   status[d] = FRIEDA_ERR_NOMEM;
                   what[d] = "host allocation failed";

@@ -1148,8 +1148,8 @@ uint32_t evaluate_plan(const Launch& L_, const uint32_t* d_coef, size_t coef_str
             Scope scope(L_, "ntt_last_fold2", enc_bytes / ((n_mid_fast ? n_mid_fast : n_mid_generic) + 1) + 36.0 * (double)N);
             const dim3 grid((unsigned)(N >> TILE_LOG), 1, 1);
             // below 512 tiles the four columns run side by side in 1024-thread workgroups (the launch is a latency chain there);
-            // needs the 68 KB dynamic-LDS opt-in the context obtained at creation (ntt_cpw == 4 says it did)
-            const bool side_by_side = (N >> TILE_LOG) < 512 && L_.tune->ntt_cpw == 4 && !L_.tune->ntt_no_cp;
+            // needs the 68 KB dynamic-LDS opt-in the context obtained at creation (Tuning::lds_opt_in_ok)
+            const bool side_by_side = (N >> TILE_LOG) < 512 && L_.tune->lds_opt_in_ok && L_.tune->ntt_cpw == 4 && !L_.tune->ntt_no_cp;
             const size_t cp_lds = (size_t)4 * TILE_WORDS * sizeof(uint32_t);
             if (side_by_side && fsink->accumulate)
                 ntt_last_fold_cp_kernel<true><<<grid, NTT_CP_THREADS, cp_lds, s>>>(fa);

@@ -356,6 +356,9 @@ struct ProveJob {
     // (o_tr) and the gather regions sit behind the workspaces
     uint32_t count = 1;
     size_t bstride = 0;
+    // the tree-skip threshold the trees of THIS job were built with (k::tree_skip_threshold at begin): the openings — device kernel
+    // and host-planner fallback — must use the same one even if frieda_ctx_set_option moved the knob between _begin and _finish
+    uint32_t skip_log = 0;
     struct Blob {
         Channel ch{};
         std::vector<Hash32> roots;
@@ -422,7 +425,13 @@ size_t workspace_bytes_per_blob(size_t len, uint32_t log_blowup, uint32_t log_la
 
 // ---- batch policy (host.h) ----
 uint64_t batch_budget_bytes(const k::Tuning& t) {
-    if (t.batch_budget_mb) return (uint64_t)t.batch_budget_mb << 20;
+    //  the figure below was measured on a 288 GB device; on a smaller one it must not ask for what the device does not have.
+    // What is FREE right now is the callers' business (multi.cpp asks hipMemGetInfo before it cuts a device's run, and halves on NOMEM).
+    if (t.batch_budget_mb) {
+        const uint64_t b = (uint64_t)t.batch_budget_mb << 20;
+        return t.device_mem_bytes ? std::min<uint64_t>(b, t.device_mem_bytes / 100 * 45) : b;
+    }
+    if (t.device_mem_bytes) return std::min<uint64_t>(batch_budget_bytes(k::tuning_defaults()), t.device_mem_bytes / 100 * 15);
     // measured at the headline size and stated in workspace bytes so that it carries over to every other size: sixteen proofs of a
     // 2^24 domain per call (15 MiB blobs: 2^22 felts -> 2^20 coefficients per column, blowup 2^4), ~43 GB per call in flight — two
     // calls in flight hold 30 % of a 288 GB MI355X.  With the compression's throughput form a call's fixed part (the narrow launches
@@ -492,7 +501,7 @@ static void launch_decommit(Ctx* ctx, const ProveJob& J, const k::Launch& LN) {
     a.hashes_off = J.dec_hashes_off;
     a.max_words = J.dec_max_words;
     a.max_hashes = J.dec_max_hashes;
-    a.skip_log = k::tree_skip_threshold(ctx->tuning, J.count);
+    a.skip_log = J.skip_log;
     a.vals[0] = reinterpret_cast<const uint32_t*>(A + J.first.o_vals);
     a.trees[0] = A + J.first.o_tree;
     for (uint32_t kx = 0; kx < J.n_inner; kx++) {
@@ -539,6 +548,7 @@ int prove_begin_batch(Ctx* ctx, const uint8_t* data, size_t data_stride, size_t 
     J.cfg = cfg;
     J.last = last;
     J.count = count;
+    J.skip_log = k::tree_skip_threshold(ctx->tuning, count);
     J.blobs.resize(count);
     const uint32_t n = J.n = sh.n, last_log = J.last_log = last + B;
     const size_t N = J.N = sh.N;
@@ -899,7 +909,7 @@ int prove_finish_batch(Ctx* ctx, uint8_t* out_commitments, std::vector<ProofData
             for (uint32_t b = 0; b < count; b++) {
                 const size_t boff = (size_t)b * J.bstride;
                 auto rebuild = [&](const FriLayerDev& lay) {
-                    if (lay.log < k::tree_skip_threshold(ctx->tuning, count)) return;
+                    if (lay.log < J.skip_log) return;
                     const uint32_t* c0 = reinterpret_cast<const uint32_t*>(A + lay.o_vals + boff);
                     const size_t cs = (size_t)1 << lay.log;
                     k::merkle_tree4(Lb, c0, c0 + cs, c0 + 2 * cs, c0 + 3 * cs, lay.log, A + lay.o_tree + boff);

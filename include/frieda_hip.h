@@ -56,6 +56,9 @@ uint32_t frieda_abi_version(void);
 const char* frieda_status_string(int status);
 /* detail of the last failure on this ctx (valid until the next call on it) */
 const char* frieda_last_error(const frieda_ctx* ctx);
+/* What context creation had to degrade on this device (an LDS opt-in refused ...), one line each; "" when nothing was.  A
+ * successful frieda_ctx_create leaves frieda_last_error empty: notes are not errors. */
+const char* frieda_ctx_notes(const frieda_ctx* ctx);
 
 /* ---- context -------------------------------------------------------------------------------- */
 /* stream: a hipStream_t to run on (e.g. torch's current stream), or NULL to create a private one */
@@ -224,6 +227,9 @@ uint64_t frieda_multi_gather_count(const frieda_multi* m);
  * the process's affinity; FRIEDA_MULTI_NO_NUMA_PIN=1 or a platform that reports none: not pinned).  Returns how many CPUs slot d's
  * worker is pinned to (0: not pinned) and writes up to cap of them. */
 uint32_t frieda_multi_near_cpus(const frieda_multi* m, uint32_t device_slot, int* out_cpus, size_t cap);
+/* Frees the device workspaces (two per device, up to the batch budget each) and upload rings the handle keeps between calls;
+ * twiddle caches stay.  The next call allocates again.  FRIEDA_ERR_ARG while a call is in flight. */
+int frieda_multi_release_workspace(frieda_multi* m);
 /* the first context of device slot d (e.g. to set a policy on it); owned by the handle */
 frieda_ctx* frieda_multi_ctx(frieda_multi* m, uint32_t device_slot);
 int frieda_commit_many(frieda_multi* m, const uint8_t* const* blobs, const size_t* lens, uint32_t count, uint32_t log_blowup_factor,

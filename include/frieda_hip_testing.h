@@ -19,6 +19,10 @@ int frieda_ctx_test_set_draw_bound(frieda_ctx* ctx, uint32_t bound);
  * nonce found is the minimum either way. */
 int frieda_ctx_test_set_grind_first_log(frieda_ctx* ctx, uint32_t log_first);
 
+/* A device with less memory than this one: workspace requests above `bytes` fail with FRIEDA_ERR_NOMEM (0 = no limit).  For the
+ * tests of frieda_prove_many / frieda_commit_many's retry with smaller calls. */
+int frieda_ctx_test_set_arena_limit(frieda_ctx* ctx, uint64_t bytes);
+
 /* The parser of sysfs CPU lists ("0-3,8,10-11\n") behind frieda_multi's NUMA placement, for the CPU tests: *n receives the count,
  * out_cpus (cap entries) the CPUs in order.  FRIEDA_ERR_FORMAT for malformed text, FRIEDA_ERR_ARG when cap is too small. */
 int frieda_test_parse_cpulist(const char* text, int* out_cpus, size_t cap, size_t* n);

@@ -634,6 +634,72 @@ def test_config4_eight_2p22_blobs_across_all_gpus_real_rccl(oracle, monkeypatch)
     mc.close()
 
 
+def test_many_entry_points_retry_with_smaller_calls_when_memory_runs_out(gpu_ctx, oracle):
+    """frieda_prove_many / frieda_commit_many on a device that cannot hold the batch policy's calls.  A test
+    limit on the workspace plays the smaller device: the first cut (6 blobs per call) and the second (3) are refused with
+    FRIEDA_ERR_NOMEM, the third (1 per call) fits — the results are those of the unconstrained run; a limit below ONE blob's
+    workspace fails loudly; release_workspace hands the memory back and the handle keeps working."""
+    import frieda_amd
+
+    L = gpu_ctx._L
+    blobs = [splitmix64_bytes(900 + i, 61440).tobytes() for i in range(12)]  # 2^16-domain proofs, one length: one run
+    seeds = list(range(12))
+    cfg = _cfg(frieda_amd, 8, 4, 0, 10)
+    ocfg = oracle.make_config(8, 4, 0, 10)
+    expected = [oracle.commit_and_generate_proof(b, s, ocfg) for b, s in zip(blobs, seeds)]
+    ws_prove = L.frieda_workspace_bytes(61440, 4, 0, 1)
+    ws_commit = L.frieda_workspace_bytes(61440, 4, 0, 0)
+    assert ws_prove > ws_commit > 0
+    mc = frieda_amd.MultiContext([0])
+    first = C.c_void_p(L.frieda_multi_ctx(mc._h, 0))
+    assert L.frieda_ctx_test_set_arena_limit(first, int(2.5 * ws_prove)) == 0
+    got = mc.prove_many(blobs, seeds, cfg)
+    assert [r for r, _ in got] == [r for r, _ in expected]
+    assert [p.serialize() for _, p in got] == [p.serialize() for _, p in expected]
+    assert L.frieda_ctx_test_set_arena_limit(first, int(2.5 * ws_commit)) == 0
+    assert mc.commit_many(blobs, 4) == [r for r, _ in expected]
+    # below one blob's workspace nothing can be cut smaller: the error comes back, with the device named
+    assert L.frieda_ctx_test_set_arena_limit(first, ws_commit // 2) == 0
+    with pytest.raises(frieda_amd.FriedaError) as ei:
+        mc.commit_many(blobs, 4)
+    assert ei.value.status == 4 and "device 0" in str(ei.value)  # FRIEDA_ERR_NOMEM
+    with pytest.raises(frieda_amd.FriedaError):
+        mc.prove_many(blobs, seeds, cfg)
+    # the handle stays usable; releasing the workspaces is not destroying it
+    assert L.frieda_ctx_test_set_arena_limit(first, 0) == 0
+    mc.release_workspace()
+    assert mc.commit_many(blobs[:3], 4) == [r for r, _ in expected[:3]]
+    mc.close()
+
+
+def test_batch_budget_is_a_share_of_the_device(gpu_ctx):
+    """the batch policy's budget is clamped to the device the context sits on — the default to 15 % of its memory, an
+    explicit FRIEDA_BATCH_BUDGET_MB to 45 % — so two calls in flight always fit; creating a context leaves last_error empty."""
+    import torch
+
+    L = gpu_ctx._L
+    total = torch.cuda.get_device_properties(0).total_memory
+    length = 15 << 20  # a 2^24-domain proof: ~2.7 GB of workspace
+    ws = L.frieda_workspace_bytes(length, 4, 0, 1)
+
+    def largest_call(ctx_handle, count):
+        calls = (C.c_uint32 * 4096)()
+        n = C.c_uint32()
+        assert L.frieda_batch_plan(ctx_handle, length, 4, 0, 1, count, 2, calls, 4096, C.byref(n)) == 0
+        assert sum(calls[: n.value]) == count
+        return max(calls[: n.value])
+
+    ctx = type(gpu_ctx)(0)
+    try:
+        assert L.frieda_last_error(ctx._h) == b"" and isinstance(L.frieda_ctx_notes(ctx._h), bytes)
+        assert largest_call(ctx._h, 4000) * ws <= 0.15 * total + ws
+        ctx.set_option("FRIEDA_BATCH_BUDGET_MB", 262144)  # 256 GiB asked for
+        assert largest_call(ctx._h, 4000) * ws <= 0.45 * total
+        assert largest_call(None, 4000) == 16  # without a context: the documented default, sixteen 2^24-domain proofs per call
+    finally:
+        ctx.close()
+
+
 def test_multi_context_python_and_rccl_failure_is_loud(gpu_ctx, oracle, monkeypatch):
     import frieda_amd
 
