@@ -151,6 +151,9 @@ extern "C" {
     pub fn frieda_fold_line(ctx: *mut frieda_ctx, d_src: *const u32, line_log: u32, log_domain: u32, alpha: *const u32, d_dst: *mut u32) -> c_int;
     /// evaluate + fold_circle_into_line + one fold_line in one pass over the evaluation (both challenges known to the caller)
     pub fn frieda_circle_evaluate_fold2(ctx: *mut frieda_ctx, d_coeffs: *const u32, log_size: u32, log_domain: u32, d_evals: *mut u32, alpha0: *const u32, accumulate_line1: c_int, d_line1: *mut u32, alpha1: *const u32, d_line2: *mut u32) -> c_int;
+    pub fn frieda_circle_extend(ctx: *mut frieda_ctx, d_coef: *const u32, ncols: u32, log_coef: u32, log_size: u32, d_out: *mut u32) -> c_int;
+    pub fn frieda_circle_eval_at_point(ctx: *mut frieda_ctx, d_coef: *const u32, ncols: u32, log_coef: u32, point_x: *const u32, point_y: *const u32, out: *mut u32) -> c_int;
+    pub fn frieda_fri_decompose(ctx: *mut frieda_ctx, d_eval: *const u32, log_size: u32, d_g: *mut u32, out_lambda: *mut u32) -> c_int;
     pub fn frieda_grind(ctx: *mut frieda_ctx, digest: *const u8, pow_bits: u32, nonce: *mut u64) -> c_int;
 }
 

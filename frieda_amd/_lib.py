@@ -164,6 +164,9 @@ def lib():
         "frieda_fold_circle_into_line": (C.c_int, [vp, vp, vp, u32, vp]),
         "frieda_fold_line": (C.c_int, [vp, vp, u32, u32, vp, vp]),
         "frieda_circle_evaluate_fold2": (C.c_int, [vp, vp, u32, u32, vp, vp, C.c_int, vp, vp, vp]),
+        "frieda_circle_extend": (C.c_int, [vp, vp, u32, u32, u32, vp]),
+        "frieda_circle_eval_at_point": (C.c_int, [vp, vp, u32, u32, vp, vp, vp]),
+        "frieda_fri_decompose": (C.c_int, [vp, vp, u32, vp, vp]),
         "frieda_grind": (C.c_int, [vp, vp, u32, u64p]),
     }
     for name, (res, args) in sig.items():

@@ -822,6 +822,61 @@ int frieda_fold_line(frieda_ctx* ctx, const uint32_t* d_src, uint32_t line_log, 
     FR_GUARD_END(ctx)
 }
 
+int frieda_circle_extend(frieda_ctx* ctx, const uint32_t* d_coef, uint32_t ncols, uint32_t log_coef, uint32_t log_size, uint32_t* d_out) {
+    if (!ctx || !d_coef || !d_out || ncols == 0 || ncols > 65535 || log_size > FRIEDA_MAX_LOG_DOMAIN) return FRIEDA_ERR_ARG;
+    if (log_size < log_coef) return ctx->c.fail(FRIEDA_ERR_INVARIANT, "extend: log_size smaller than the polynomial's (stwo asserts log_size >= poly.log_size())");
+    FR_GUARD_BEGIN
+    FR_HIP(&ctx->c, hipSetDevice(ctx->c.device));
+    k::circle_extend(ctx->c.launch(), d_coef, ncols, log_coef, log_size, d_out);
+    FR_HIP(&ctx->c, hipGetLastError());
+    return FRIEDA_OK;
+    FR_GUARD_END(ctx)
+}
+
+int frieda_circle_eval_at_point(frieda_ctx* ctx, const uint32_t* d_coef, uint32_t ncols, uint32_t log_coef, const uint32_t point_x[4],
+                                const uint32_t point_y[4], uint32_t* out) {
+    if (!ctx || !d_coef || !point_x || !point_y || !out || ncols == 0 || ncols > 65535 || log_coef > FRIEDA_MAX_LOG_DOMAIN) return FRIEDA_ERR_ARG;
+    for (int i = 0; i < 4; i++)
+        if (point_x[i] >= P31 || point_y[i] >= P31) return ctx->c.fail(FRIEDA_ERR_ARG, "eval_at_point: point coordinates must be canonical M31 words");
+    FR_NO_JOB(&ctx->c);
+    FR_GUARD_BEGIN
+    FR_HIP(&ctx->c, hipSetDevice(ctx->c.device));
+    int rc = ctx->c.ensure_arena(k::eval_at_point_scratch_bytes(ncols, log_coef));
+    if (rc) return rc;
+    // CpuBackend::eval_at_point: mappings = [y, x, double_x(x), ...]: the factor of coefficient-index bit b
+    k::EvalFactors f{};
+    const QM31 one{1, 0, 0, 0};
+    f.f[0] = QM31{point_y[0], point_y[1], point_y[2], point_y[3]};
+    QM31 x{point_x[0], point_x[1], point_x[2], point_x[3]};
+    for (uint32_t b = 1; b < 32; b++) {
+        f.f[b] = x;
+        const QM31 sq = qm_mul(x, x);
+        x = qm_sub(qm_add(sq, sq), one);
+    }
+    const uint32_t* d_res = k::circle_eval_at_point(ctx->c.launch(), d_coef, ncols, log_coef, f, reinterpret_cast<uint32_t*>(ctx->c.arena));
+    FR_HIP(&ctx->c, hipGetLastError());
+    FR_HIP(&ctx->c, hipMemcpyAsync(out, d_res, 16 * (size_t)ncols, hipMemcpyDeviceToHost, ctx->c.stream));
+    FR_HIP(&ctx->c, hipStreamSynchronize(ctx->c.stream));
+    return FRIEDA_OK;
+    FR_GUARD_END(ctx)
+}
+
+int frieda_fri_decompose(frieda_ctx* ctx, const uint32_t* d_eval, uint32_t log_size, uint32_t* d_g, uint32_t out_lambda[4]) {
+    if (!ctx || !d_eval || !d_g || !out_lambda || log_size > FRIEDA_MAX_LOG_DOMAIN) return FRIEDA_ERR_ARG;
+    FR_NO_JOB(&ctx->c);
+    FR_GUARD_BEGIN
+    FR_HIP(&ctx->c, hipSetDevice(ctx->c.device));
+    int rc = ctx->c.ensure_arena(k::decompose_scratch_bytes(log_size));
+    if (rc) return rc;
+    uint32_t* d_scratch = reinterpret_cast<uint32_t*>(ctx->c.arena);
+    k::fri_decompose(ctx->c.launch(), d_eval, log_size, d_g, d_scratch);
+    FR_HIP(&ctx->c, hipGetLastError());
+    FR_HIP(&ctx->c, hipMemcpyAsync(out_lambda, d_scratch, 16, hipMemcpyDeviceToHost, ctx->c.stream));
+    FR_HIP(&ctx->c, hipStreamSynchronize(ctx->c.stream));
+    return FRIEDA_OK;
+    FR_GUARD_END(ctx)
+}
+
 int frieda_grind(frieda_ctx* ctx, const uint8_t digest[32], uint32_t pow_bits, uint64_t* nonce) {
     if (!ctx || !digest || !nonce || pow_bits > 48) return FRIEDA_ERR_ARG;
     FR_NO_JOB(&ctx->c);

@@ -329,6 +329,18 @@ struct DecommitArgs {
 };
 void decommit(const Launch& L, const DecommitArgs& a, uint32_t wgs_per_blob);
 
+// ---- polyops.hip: PolyOps::{extend, eval_at_point}, FriOps::decompose (trait completeness; not on frieda's path) ----
+struct EvalFactors {
+    QM31 f[32];  // f[b]: the factor of coefficient-index bit b (f[0] = point.y, f[1] = point.x, f[b + 1] = 2 f[b]^2 - 1)
+};
+void circle_extend(const Launch& L, const uint32_t* d_coef, uint32_t ncols, uint32_t log_coef, uint32_t log_size, uint32_t* d_out);
+size_t eval_at_point_scratch_bytes(uint32_t ncols, uint32_t log_coef);
+// -> the device address (inside d_scratch) of the ncols x 4 result words, [col][4]
+const uint32_t* circle_eval_at_point(const Launch& L, const uint32_t* d_coef, uint32_t ncols, uint32_t log_coef, const EvalFactors& f, uint32_t* d_scratch);
+size_t decompose_scratch_bytes(uint32_t log_size);
+// d_eval, d_g: [4][2^log_size]; lambda is left in the first four words of d_scratch
+void fri_decompose(const Launch& L, const uint32_t* d_eval, uint32_t log_size, uint32_t* d_g, uint32_t* d_scratch);
+
 // ---- fri.hip ----
 struct Alpha {
     uint32_t v[4];

@@ -386,6 +386,21 @@ int frieda_circle_evaluate_fold2(frieda_ctx* ctx, const uint32_t* d_coeffs, uint
                                  const uint32_t alpha0[4], int accumulate_line1, uint32_t* d_line1, const uint32_t alpha1[4],
                                  uint32_t* d_line2);
 
+/* ---- the trait methods frieda's three functions never call (SURVEY.md §8b lists them on the plug-in surface behind `CpuBackend`,
+ * src/commit.rs:15-17, src/proof.rs:47-58): an `impl PolyOps / FriOps for HipBackend` needs them ----
+ * PolyOps::extend(poly, log_size): d_coef[ncols][2^log_coef] -> d_out[ncols][2^log_size], zero-extended (FRIEDA_ERR_INVARIANT for
+ * log_size < log_coef, stwo's assert).  Asynchronous on the ctx stream; the buffers must not overlap. */
+int frieda_circle_extend(frieda_ctx* ctx, const uint32_t* d_coef, uint32_t ncols, uint32_t log_coef, uint32_t log_size, uint32_t* d_out);
+/* PolyOps::eval_at_point(poly, point): each of the ncols polynomials d_coef[ncols][2^log_coef] at the circle point (x, y) over
+ * the secure field (QM31 coordinates as 4 canonical words each); out[ncols][4] on the host.  Synchronises the ctx stream. */
+int frieda_circle_eval_at_point(frieda_ctx* ctx, const uint32_t* d_coef, uint32_t ncols, uint32_t log_coef, const uint32_t point_x[4],
+                                const uint32_t point_y[4], uint32_t* out);
+/* FriOps::decompose(eval) -> (g, lambda): d_eval[4][2^log_size] (a SecureColumn in bit-reversed order) split into the part inside
+ * the FFT space, d_g[4][2^log_size], and the coefficient lambda of the half-coset vanishing polynomial (out_lambda, host):
+ * lambda = (sum of the first half - sum of the second half) / 2^log_size; g = eval -/+ lambda.  Synchronises the ctx stream;
+ * d_g may be d_eval. */
+int frieda_fri_decompose(frieda_ctx* ctx, const uint32_t* d_eval, uint32_t log_size, uint32_t* d_g, uint32_t out_lambda[4]);
+
 /* GrindOps::grind: smallest nonce with trailing_zeros(mix_u64(digest, nonce)) >= pow_bits */
 int frieda_grind(frieda_ctx* ctx, const uint8_t digest[32], uint32_t pow_bits, uint64_t* nonce);
 

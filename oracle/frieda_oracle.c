@@ -668,6 +668,58 @@ void fo_fold_line(const uint32_t* const src[4], uint32_t m, uint32_t domain_n, c
 }
 
 /* ------------------------------------------------------------------------------------------------
+ * The trait methods of the plug-in surface that frieda's three functions never call (PolyOps::{extend,
+ * eval_at_point}, FriOps::decompose behind `CpuBackend` at /root/reference/src/commit.rs:15-17, src/proof.rs:47-58).
+ * Restated from stwo-prover@19d12d7's published CpuBackend (backend/cpu/circle.rs, backend/cpu/fri.rs, core/poly/utils.rs::fold);
+ * the reference holds no known answer for them: parity unpinned, like the rest of the prove half.
+ * ---------------------------------------------------------------------------------------------- */
+/* CpuBackend::extend: coeffs.resize(1 << log_size, zero) */
+void fo_circle_extend(const uint32_t* coef, uint32_t log_coef, uint32_t log_size, uint32_t* out) {
+    size_t a = (size_t)1 << log_coef, b = (size_t)1 << log_size;
+    memcpy(out, coef, a * sizeof(uint32_t));
+    memset(out + a, 0, (b - a) * sizeof(uint32_t));
+}
+/* core/poly/utils.rs::fold: values split in halves, rhs scaled by the FIRST folding factor, recursively */
+static qm31 fold_rec_base(const uint32_t* values, size_t n, const qm31* factors) {
+    if (n == 1) return (qm31){{values[0], 0}, {0, 0}};
+    qm31 l = fold_rec_base(values, n / 2, factors + 1), r = fold_rec_base(values + n / 2, n / 2, factors + 1);
+    return qm_add(l, qm_mul(r, factors[0]));
+}
+/* CpuBackend::eval_at_point: mappings = [y, x, pi(x), pi^2(x), ...] (log_size entries), reversed, then fold; log_size 0: coeffs[0] */
+void fo_circle_eval_at_point(const uint32_t* coef, uint32_t log_coef, const uint32_t px[4], const uint32_t py[4], uint32_t out[4]) {
+    if (log_coef == 0) {
+        out[0] = coef[0];
+        out[1] = out[2] = out[3] = 0;
+        return;
+    }
+    qm31 map[32];
+    qm31 one = {{1, 0}, {0, 0}};
+    map[0] = qm_from(py);
+    qm31 x = qm_from(px);
+    for (uint32_t i = 1; i < log_coef; i++) {
+        map[i] = x;
+        qm31 sq = qm_mul(x, x);
+        x = qm_sub(qm_add(sq, sq), one); /* CirclePoint::double_x */
+    }
+    qm31 rev[32];
+    for (uint32_t i = 0; i < log_coef; i++) rev[i] = map[log_coef - 1 - i];
+    qm_to(fold_rec_base(coef, (size_t)1 << log_coef, rev), out);
+}
+/* CpuBackend::decompose + decomposition_coefficient: lambda = (sum of the first half - sum of the second half) / domain_size
+ * (the vanishing polynomial of the half-size canonic coset is + on the first half of a bit-reversed evaluation, - on the second);
+ * g = eval - lambda on the first half, eval + lambda on the second */
+void fo_fri_decompose(const uint32_t* const eval[4], uint32_t log_size, uint32_t* const g[4], uint32_t lambda_out[4]) {
+    size_t n = (size_t)1 << log_size, half = n / 2;
+    qm31 a = {{0, 0}, {0, 0}}, b = a;
+    for (size_t i = 0; i < half; i++) a = qm_add(a, col_at(eval, i));
+    for (size_t i = half; i < n; i++) b = qm_add(b, col_at(eval, i));
+    qm31 lambda = qm_scale(qm_sub(a, b), m31_inv((uint32_t)(n % P)));
+    for (size_t i = 0; i < half; i++) col_set(g, i, qm_sub(col_at(eval, i), lambda));
+    for (size_t i = half; i < n; i++) col_set(g, i, qm_add(col_at(eval, i), lambda));
+    qm_to(lambda, lambda_out);
+}
+
+/* ------------------------------------------------------------------------------------------------
  * Standard Blake2s-256 (RFC 7693; blake2 0.10.6 via stwo core/vcs/blake2_hash.rs) — channel only
  * ---------------------------------------------------------------------------------------------- */
 void fo_blake2s256(const uint8_t* in, size_t len, uint8_t out[32]) {

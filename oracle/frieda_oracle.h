@@ -96,6 +96,14 @@ void fo_fold_circle_into_line(uint32_t* const dst[4], const uint32_t* const src[
 void fo_fold_line(const uint32_t* const src[4], uint32_t line_log_size, uint32_t domain_n, const uint32_t alpha[4],
                   uint32_t* const dst[4]);
 
+/* ---- trait methods frieda's path never calls (stwo backend/cpu/circle.rs::{extend, eval_at_point}, backend/cpu/fri.rs::decompose;
+ * restated from the published code of stwo-prover@19d12d7, parity unpinned) ---- */
+void fo_circle_extend(const uint32_t* coef, uint32_t log_coef, uint32_t log_size, uint32_t* out);
+/* the polynomial of 2^log_coef coefficients at the circle point (px, py) over QM31 */
+void fo_circle_eval_at_point(const uint32_t* coef, uint32_t log_coef, const uint32_t px[4], const uint32_t py[4], uint32_t out[4]);
+/* eval, g: SoA QM31 columns of 2^log_size entries (bit-reversed order); lambda_out: the decomposition coefficient */
+void fo_fri_decompose(const uint32_t* const eval[4], uint32_t log_size, uint32_t* const g[4], uint32_t lambda_out[4]);
+
 /* ---- Fiat–Shamir channel (stwo core/channel/blake2s.rs) ---- */
 typedef struct {
     uint8_t digest[32];

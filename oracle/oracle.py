@@ -102,6 +102,9 @@ def lib():
         L.fo_merkle_layer_offset.argtypes = [C.c_uint32, C.c_uint32]
         L.fo_fold_circle_into_line.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_uint32, C.c_void_p]
         L.fo_fold_line.argtypes = [C.POINTER(C.c_void_p), C.c_uint32, C.c_uint32, C.c_void_p, C.POINTER(C.c_void_p)]
+        L.fo_circle_extend.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
+        L.fo_circle_eval_at_point.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.fo_fri_decompose.argtypes = [C.POINTER(C.c_void_p), C.c_uint32, C.POINTER(C.c_void_p), C.c_void_p]
         L.fo_blake2s256.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
         L.fo_blake2s_compress.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
         L.fo_channel_init.argtypes = [C.POINTER(Channel)]
@@ -304,6 +307,33 @@ def fold_line(src, domain_n, alpha):
     alpha = np.ascontiguousarray(alpha, dtype=np.uint32)
     lib().fo_fold_line(_ptr_array([src[i] for i in range(4)]), m, domain_n, alpha.ctypes.data, _ptr_array([dst[i] for i in range(4)]))
     return dst
+
+
+# ---- trait methods frieda's path never calls (PolyOps::extend / eval_at_point, FriOps::decompose) ---------------
+def circle_extend(coef, log_size):
+    coef = np.ascontiguousarray(coef, dtype=np.uint32)
+    out = np.empty(1 << log_size, dtype=np.uint32)
+    lib().fo_circle_extend(coef.ctypes.data, coef.size.bit_length() - 1, log_size, out.ctypes.data)
+    return out
+
+
+def circle_eval_at_point(coef, px, py):
+    """coef: 2^k M31 coefficients; (px, py): a circle point over QM31 (4 words each) -> QM31 value (4 words)"""
+    coef = np.ascontiguousarray(coef, dtype=np.uint32)
+    px = np.ascontiguousarray(px, dtype=np.uint32)
+    py = np.ascontiguousarray(py, dtype=np.uint32)
+    out = np.zeros(4, dtype=np.uint32)
+    lib().fo_circle_eval_at_point(coef.ctypes.data, coef.size.bit_length() - 1, px.ctypes.data, py.ctypes.data, out.ctypes.data)
+    return out
+
+
+def fri_decompose(ev):
+    """ev [4, 2^k] (SoA QM31, bit-reversed) -> (g [4, 2^k], lambda [4])"""
+    ev = np.ascontiguousarray(ev, dtype=np.uint32)
+    g = np.zeros_like(ev)
+    lam = np.zeros(4, dtype=np.uint32)
+    lib().fo_fri_decompose(_ptr_array([ev[i] for i in range(4)]), ev.shape[1].bit_length() - 1, _ptr_array([g[i] for i in range(4)]), lam.ctypes.data)
+    return g, lam
 
 
 # ---- API -----------------------------------------------------------------------------------------
