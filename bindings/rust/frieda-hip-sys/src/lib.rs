@@ -54,6 +54,7 @@ extern "C" {
     pub fn frieda_ctx_test_set_draw_bound(ctx: *mut frieda_ctx, bound: u32) -> c_int;
     pub fn frieda_ctx_test_set_grind_first_log(ctx: *mut frieda_ctx, log_first: u32) -> c_int;
     pub fn frieda_ctx_test_set_arena_limit(ctx: *mut frieda_ctx, bytes: u64) -> c_int;
+    pub fn frieda_test_near_cpus(sysfs_root: *const c_char, pci_bus_id: *const c_char, out_cpus: *mut c_int, cap: usize, n: *mut usize) -> c_int;
     pub fn frieda_test_parse_cpulist(text: *const c_char, out_cpus: *mut c_int, cap: usize, n: *mut usize) -> c_int;
     /// batch policy: device workspace one blob adds to a batched call; the cut of `count` equal-length blobs into calls
     pub fn frieda_workspace_bytes(len: usize, log_blowup_factor: u32, log_last_layer_degree_bound: u32, prove: c_int) -> usize;

@@ -116,6 +116,7 @@ def lib():
         "frieda_multi_ctx": (vp, [vp, u32]),
         "frieda_multi_release_workspace": (C.c_int, [vp]),
         "frieda_multi_near_cpus": (u32, [vp, u32, C.POINTER(C.c_int), sz]),
+        "frieda_test_near_cpus": (C.c_int, [C.c_char_p, C.c_char_p, C.POINTER(C.c_int), sz, C.POINTER(sz)]),
         "frieda_test_parse_cpulist": (C.c_int, [C.c_char_p, C.POINTER(C.c_int), sz, C.POINTER(sz)]),
         "frieda_commit_many": (C.c_int, [vp, pp, C.POINTER(sz), u32, u32, vp]),
         "frieda_prove_many": (C.c_int, [vp, pp, C.POINTER(sz), u32, u64p, PcsConfigC, vp, pp]),

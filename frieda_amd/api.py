@@ -12,6 +12,7 @@ rejections return False.  Every call runs on the MI355X through libfrieda_hip.so
 """
 import ctypes as C
 import threading
+import time
 from dataclasses import dataclass
 
 import numpy as np
@@ -531,8 +532,9 @@ class BatchPipeline:
 
     def __init__(self, device=0, depth=2):
         self.ctxs = [Context(device) for _ in range(depth)]
-        self.inflight = []  # (ctx, count), oldest first
+        self.inflight = []  # (ctx, count, time of _begin), oldest first
         self.free = list(self.ctxs)
+        self.call_latencies = []  # (blobs, seconds from _begin to the return of _finish) of every finished call; callers may clear it
 
     def plan(self, length, count, pcs_config, prove=True):
         """The library's cut of `count` equal-length blobs into calls for this pipeline's depth (frieda_batch_plan: workspace bytes in
@@ -556,20 +558,24 @@ class BatchPipeline:
     def submit_device(self, d_ptr, stride, length, count, seeds, pcs_config):
         done = None
         if not self.free:
-            ctx, cnt = self.inflight.pop(0)
-            done = ctx.prove_batch_finish(cnt)
-            self.free.append(ctx)
+            done = self._finish_oldest()
         ctx = self.free.pop(0)
+        t0 = time.perf_counter()
         ctx.prove_batch_begin_device(d_ptr, stride, length, count, seeds, pcs_config)
-        self.inflight.append((ctx, count))
+        self.inflight.append((ctx, count, t0))
+        return done
+
+    def _finish_oldest(self):
+        ctx, cnt, t0 = self.inflight.pop(0)
+        done = ctx.prove_batch_finish(cnt)
+        self.call_latencies.append((cnt, time.perf_counter() - t0))
+        self.free.append(ctx)
         return done
 
     def drain(self):
         out = []
         while self.inflight:
-            ctx, cnt = self.inflight.pop(0)
-            out.extend(ctx.prove_batch_finish(cnt))
-            self.free.append(ctx)
+            out.extend(self._finish_oldest())
         return out
 
     def close(self):

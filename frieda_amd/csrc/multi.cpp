@@ -127,22 +127,16 @@ bool read_small_file(const std::string& path, std::string& out) {
     out = buf;
     return true;
 }
-// the CPUs near HIP device `dev`, restricted to the process's affinity; empty: unknown / nothing to do
-std::vector<int> cpus_near_device(int dev) {
+// the CPUs of the NUMA node of the PCI function `bus` ("0000:c1:00.0") under `sysfs` ("/sys"; a fake tree in the CPU tests), restricted to
+// the process's affinity; empty: unknown / nothing to do
+std::vector<int> cpus_near_bus_id(const std::string& sysfs, std::string bus) {
     std::vector<int> out;
-    const char* off = getenv("FRIEDA_MULTI_NO_NUMA_PIN");
-    if (off && *off == '1') return out;
-    char bus[64] = {0};
-    if (hipDeviceGetPCIBusId(bus, (int)sizeof(bus), dev) != hipSuccess) {
-        (void)hipGetLastError();
-        return out;
-    }
-    for (char* c = bus; *c; c++) *c = (char)tolower(*c);
+    for (char& c : bus) c = (char)tolower(c);
     std::string node_s, list_s;
-    if (!read_small_file(std::string("/sys/bus/pci/devices/") + bus + "/numa_node", node_s)) return out;
+    if (!read_small_file(sysfs + "/bus/pci/devices/" + bus + "/numa_node", node_s)) return out;
     const long node = strtol(node_s.c_str(), nullptr, 10);
     if (node < 0) return out;  // -1: the platform reports no affinity
-    if (!read_small_file("/sys/devices/system/node/node" + std::to_string(node) + "/cpulist", list_s)) return out;
+    if (!read_small_file(sysfs + "/devices/system/node/node" + std::to_string(node) + "/cpulist", list_s)) return out;
     std::vector<int> near;
     if (!frieda::parse_cpulist(list_s.c_str(), near)) return out;
     cpu_set_t have;
@@ -151,6 +145,17 @@ std::vector<int> cpus_near_device(int dev) {
     for (int c : near)
         if (c < CPU_SETSIZE && CPU_ISSET(c, &have)) out.push_back(c);
     return out;
+}
+// the CPUs near HIP device `dev`
+std::vector<int> cpus_near_device(int dev) {
+    const char* off = getenv("FRIEDA_MULTI_NO_NUMA_PIN");
+    if (off && *off == '1') return {};
+    char bus[64] = {0};
+    if (hipDeviceGetPCIBusId(bus, (int)sizeof(bus), dev) != hipSuccess) {
+        (void)hipGetLastError();
+        return {};
+    }
+    return cpus_near_bus_id("/sys", bus);
 }
 void pin_this_thread(const std::vector<int>& cpus) {
     if (cpus.empty()) return;
@@ -514,6 +519,19 @@ uint32_t frieda_multi_near_cpus(const frieda_multi* m, uint32_t device_slot, int
     const std::vector<int>& v = m->near_cpus[device_slot];
     for (size_t i = 0; i < v.size() && i < cap && out_cpus; i++) out_cpus[i] = v[i];
     return (uint32_t)v.size();
+}
+int frieda_test_near_cpus(const char* sysfs_root, const char* pci_bus_id, int* out_cpus, size_t cap, size_t* n) {
+    if (!sysfs_root || !pci_bus_id || !n) return FRIEDA_ERR_ARG;
+    *n = 0;
+    try {
+        const std::vector<int> v = cpus_near_bus_id(sysfs_root, pci_bus_id);
+        *n = v.size();
+        if (v.size() > cap) return FRIEDA_ERR_ARG;
+        for (size_t i = 0; i < v.size() && out_cpus; i++) out_cpus[i] = v[i];
+        return FRIEDA_OK;
+    } catch (...) {
+        return FRIEDA_ERR_NOMEM;
+    }
 }
 int frieda_test_parse_cpulist(const char* text, int* out_cpus, size_t cap, size_t* n) {
     if (!n) return FRIEDA_ERR_ARG;

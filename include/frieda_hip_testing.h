@@ -27,6 +27,11 @@ int frieda_ctx_test_set_arena_limit(frieda_ctx* ctx, uint64_t bytes);
  * out_cpus (cap entries) the CPUs in order.  FRIEDA_ERR_FORMAT for malformed text, FRIEDA_ERR_ARG when cap is too small. */
 int frieda_test_parse_cpulist(const char* text, int* out_cpus, size_t cap, size_t* n);
 
+/* The NUMA placement rule of frieda_multi's worker threads on a sysfs tree of the caller's making (no GPU involved): the CPUs of
+ * <sysfs_root>/devices/system/node/node<k>/cpulist, k = <sysfs_root>/bus/pci/devices/<pci_bus_id>/numa_node, intersected with the
+ * process's affinity; *n = 0 when the tree says nothing (missing files, node -1, malformed list). */
+int frieda_test_near_cpus(const char* sysfs_root, const char* pci_bus_id, int* out_cpus, size_t cap, size_t* n);
+
 #ifdef __cplusplus
 }
 #endif

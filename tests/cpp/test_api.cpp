@@ -109,6 +109,15 @@ static int multi_mode(const std::vector<uint8_t>& blob, int n_slots, bool distin
         CHECK(sched_getaffinity(0, sizeof(have), &have) == 0);
         for (int d = 0; d < n_slots; d++)
             for (int c : mc.near_cpus(d)) CHECK(c >= 0 && c < CPU_SETSIZE && CPU_ISSET(c, &have));
+        // two workers either sit on the same NUMA node (the same CPU list) or on different ones (disjoint lists): never a partial overlap,
+        // and never one list for devices the platform puts on different nodes
+        for (int a = 0; a < n_slots; a++)
+            for (int b = a + 1; b < n_slots; b++) {
+                const std::vector<int> ca = mc.near_cpus(a), cb = mc.near_cpus(b);
+                size_t common = 0;
+                for (int c : ca) common += std::count(cb.begin(), cb.end(), c);
+                CHECK(common == 0 || (ca == cb));
+            }
         std::printf("near_cpus(slot 0): %zu\n", mc.near_cpus(0).size());
     }
     std::printf("multi n_slots=%d rccl=%d gathers=%llu: %s (%d failures)\n", n_slots, (int)mc.uses_rccl(), (unsigned long long)mc.gather_count(),

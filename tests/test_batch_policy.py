@@ -99,3 +99,45 @@ def test_cpulist_parser_rejects(text):
     out = (C.c_int * 16)()
     assert L.frieda_test_parse_cpulist(text.encode(), out, 16, C.byref(n)) == _lib.ERR_FORMAT
     assert L.frieda_test_parse_cpulist(b"0-31", out, 16, C.byref(n)) == _lib.ERR_ARG and n.value == 32
+
+
+def test_numa_placement_on_a_two_socket_tree(tmp_path):
+    """VERDICT r05 task 4c: on a node whose sysfs puts two GPUs on different NUMA nodes, their worker threads must get different CPU
+    sets — each the CPUs of its own node, inside the process's affinity — and devices of one node the same set.  A fake sysfs tree
+    plays the two-socket 8-GPU node (frieda_test_near_cpus runs the rule frieda_multi_create uses, multi.cpp cpus_near_bus_id)."""
+    import os
+
+    from frieda_amd import _lib
+
+    L = _lib.lib()
+    have = sorted(os.sched_getaffinity(0))
+    if len(have) < 2:
+        pytest.skip("needs two usable CPUs")
+    half = len(have) // 2
+    node_cpus = {0: have[:half], 1: have[half:]}
+    for k, cpus in node_cpus.items():
+        d = tmp_path / "devices" / "system" / "node" / f"node{k}"
+        d.mkdir(parents=True)
+        (d / "cpulist").write_text(",".join(str(c) for c in cpus) + ",9999\n")  # (a CPU outside the affinity mask must be dropped)
+    gpus = {f"0000:{0x05 + 0x10 * i:02x}:00.0": (0 if i < 4 else 1) for i in range(8)}  # GPUs 0 - 3 on socket 0, 4 - 7 on socket 1
+    for bus, node in gpus.items():
+        d = tmp_path / "bus" / "pci" / "devices" / bus
+        d.mkdir(parents=True)
+        (d / "numa_node").write_text(f"{node}\n")
+    (tmp_path / "bus" / "pci" / "devices" / "0000:ff:00.0").mkdir()
+    (tmp_path / "bus" / "pci" / "devices" / "0000:ff:00.0" / "numa_node").write_text("-1\n")  # a platform that reports no affinity
+
+    def near(bus):
+        n = C.c_size_t(0)
+        out = (C.c_int * 4096)()
+        assert L.frieda_test_near_cpus(str(tmp_path).encode(), bus.encode(), out, 4096, C.byref(n)) == _lib.OK
+        return [out[i] for i in range(n.value)]
+
+    sets = {bus: near(bus.upper() if i % 2 else bus) for i, bus in enumerate(gpus)}  # (hipDeviceGetPCIBusId's upper-case hex is folded)
+    for bus, node in gpus.items():
+        assert sets[bus] == node_cpus[node], (bus, sets[bus])
+    for a in gpus:
+        for b in gpus:
+            if gpus[a] != gpus[b]:
+                assert not set(sets[a]) & set(sets[b]), "two workers of different NUMA nodes share CPUs"
+    assert near("0000:ff:00.0") == [] and near("0000:ee:00.0") == []  # no affinity reported / unknown device: not pinned
