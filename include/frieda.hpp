@@ -201,6 +201,8 @@ class MultiContext {
         if (!c) throw Error(FRIEDA_ERR_ARG, "no such device slot");
         check(frieda_ctx_set_option(c, name, value));
     }
+    // hands the device workspaces the handle keeps between calls (two per device, up to the batch budget each) back; the next call allocates again
+    void release_workspace() { mcheck(frieda_multi_release_workspace(h_)); }
     // the CPUs the worker thread of device slot d is pinned to (its GPU's NUMA node); empty: not pinned
     std::vector<int> near_cpus(uint32_t device_slot) const {
         std::vector<int> v(frieda_multi_near_cpus(h_, device_slot, nullptr, 0));

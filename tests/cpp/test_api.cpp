@@ -96,6 +96,8 @@ static int multi_mode(const std::vector<uint8_t>& blob, int n_slots, bool distin
         CHECK(mc.commit_many(blobs, 4) == roots);
         again = mc.prove_many(provable, seeds.data(), PCS_CONFIG);
         for (size_t i = 0; i < again.size(); i++) CHECK(again[i].first == proofs[i].first && again[i].second.serialize() == proofs[i].second.serialize());
+        mc.release_workspace();  // the handle stays usable: the next call allocates again
+        CHECK(mc.commit_many(blobs, 4) == roots);
         bool refused = false;
         try {
             mc.set_option(0, "FRIEDA_BATCH_CALLS_PER_CTX", 0);
