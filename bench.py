@@ -368,10 +368,14 @@ def measure_config(frieda_amd, torch, device, n, workload, K, BSZ, D, cfg):
             run()  # sizes the workspaces, builds the twiddles
             run()
             torch.cuda.synchronize()
+            import gc
+
+            gc.disable()  # (no collector pause inside the timed region: see the measured loop of main)
             t0 = time.perf_counter()
             res = run()
             torch.cuda.synchronize()
             dt_ = (time.perf_counter() - t0) / K
+            gc.enable()
             assert len(res) == K and len({r for r, _ in res}) == K
             for r, p in res:
                 assert p.commitment == r and frieda_amd.verify(p, seed), "a timed proof does not verify"
@@ -1061,13 +1065,24 @@ def main():
     fence()
     if pipe is not None and hasattr(pipe, "call_latencies"):
         pipe.call_latencies.clear()
+    # The interpreter's cyclic collector must not run inside the timed region: with torch imported a full collection walks ~10^6 objects
+    # (40 - 65 ms), and whether one falls into the region depends on the allocation count of everything before it — a 256-blob stream of
+    # the 2^20 domain read 0.27 - 0.37 ms per blob instead of 0.12 when it did (profiles/r06_gc_pause.txt).
+    # The collector is switched off while the clock runs and back on after it stops; nothing the library does is affected.  (Collecting
+    # right before the region instead costs ~2 ms INSIDE it: the freed pages go back to the system and the region's own host
+    # allocations — proof objects, result lists — fault them in again: 1.55 vs 1.45 ms per blob at --steps 20.)
+    import gc
+
+    gc.disable()
     t0 = time.perf_counter()
     results = run_stream(K)
     gather_roots(results)
     fence()
     dt = time.perf_counter() - t0
+    gc.enable()
     #  a proof's LATENCY grows with the call it rides in: _begin to the return of _finish, per call of the timed region
     call_latency = None
+    pipe_phases = [c.last_prove_phases() for c in pipe.ctxs] if pipe is not None and os.environ.get("FRIEDA_BENCH_DEBUG_PHASES") else None
     if pipe is not None and getattr(pipe, "call_latencies", None):
         lat = [(c, 1e3 * t) for c, t in pipe.call_latencies]
         call_latency = {"calls": [{"blobs": c, "ms": round(t, 3)} for c, t in lat], "max_ms": max(t for _, t in lat),
@@ -1333,6 +1348,8 @@ def main():
         "env_defaults": env_defaults,
         "call_latency": call_latency,
     }
+    if pipe_phases:
+        out["pipeline_phase_marks_ms"] = pipe_phases
     if rank == 0 and world == 1 and not args.no_end_to_end and args.workload == "prove":
         k_e2e = max(8, min(32, (K // 8) * 8))
         try:  # (an extra block must never cost the line its headline: a failure here is reported in place)
@@ -1359,7 +1376,10 @@ def main():
                     continue  # that is `value` itself
                 if cn > n:
                     continue  # (small test runs: nothing above the headline size)
-                rows.append(measure_config(frieda_amd, torch, local_rank, cn, cw, 64 if cn <= 22 else 20, 0 if cw == "prove" else 1, 2 if cw == "prove" else 1, cfg))
+                # blobs per stream: enough for the batch policy to reach its cut at that size (2^20: 2 calls of 256, 2^22: 2 calls of 64 —
+                # a call's latency chain is ~0.5 ms whatever the size; profiles/r06_gc_pause.txt has the rate by stream length)
+                kk = {(20, "prove"): 512, (22, "prove"): 128}.get((cn, cw), 64 if cn <= 22 else 20)
+                rows.append(measure_config(frieda_amd, torch, local_rank, cn, cw, kk, 0 if cw == "prove" else 1, 2 if cw == "prove" else 1, cfg))
             if n >= 20:
                 rows.insert(0, measure_config2(frieda_amd, torch, local_rank, 20))
         except AssertionError:
