@@ -42,4 +42,5 @@ cp $(ls $OUT/stats_b/*/*kernel_stats.csv | head -1) $OUT/${TAG}_prove24_batched_
 rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAVES GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_sq -- python3 bench.py --steps 4 --warmup 1 $ONE > /dev/null 2> $OUT/pmc_sq_err.txt
 python tools/valu_util.py $OUT/pmc_sq > $OUT/${TAG}_valu_util_prove24.txt 2>> $OUT/pmc_sq_err.txt
 rm -rf $OUT/stats $OUT/stats22 $OUT/stats_b $OUT/pmc_sq $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_fetch_b $OUT/pmc_write_b
+bash tools/build_evidence.sh $OUT/${TAG}_build_evidence.txt  # clean-build wall time, offload bundles by target, kernel count (no GPU needed)
 ls -la $OUT
