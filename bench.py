@@ -1373,7 +1373,14 @@ def main():
         try:
             for (cn, cw) in ((20, "prove"), (22, "prove"), (24, "prove"), (22, "commit"), (24, "commit")):
                 if cn == n and cw == args.workload and BSZ == 0 and D == 2:
-                    continue  # that is `value` itself
+                    # that is `value` itself.   Like for like with BENCH_r01 .. r04, whose measured loop handed 4 blobs to every call:
+                    # the same workload through that cut on this run's device (20 blobs, two calls in flight, every proof verified)
+                    if cw == "prove":
+                        r4 = measure_config(frieda_amd, torch, local_rank, cn, cw, 20, 4, 2, cfg)
+                        out["value_fixed_batch4"] = {"measured_loop": r4["measured_loop"], "blobs": r4["blobs"], "ms_per_blob": r4["ms_per_blob"], "value": r4["value"],
+                                                     "frac_of_hbm_peak_wall": r4["frac_of_hbm_peak_wall"], "verified_proofs": r4.get("verified_proofs"),
+                                                     "note": "the 4-blobs-per-call cut of rounds 1 - 4: compare THIS with BENCH_r01 .. r04; `value` uses the library's batch policy"}
+                    continue
                 if cn > n:
                     continue  # (small test runs: nothing above the headline size)
                 # blobs per stream: enough for the batch policy to reach its cut at that size (2^20: 2 calls of 256, 2^22: 2 calls of 64 —
@@ -1387,11 +1394,6 @@ def main():
         except Exception as e:  # noqa: BLE001
             rows.append({"error": f"{type(e).__name__}: {e}"})
         out["by_config"] = rows
-        #  like for like with BENCH_r01 .. r04, whose measured loop handed 4 blobs to every call: the same workload through that
-        # cut, from the by_config row of this size (same blobs per call, same two calls in flight, every proof verified)
-        for row in rows:
-            if isinstance(row, dict) and row.get("log_domain") == n and row.get("workload") == "commit_and_generate_proof" and "fixed_batch4" in row:
-                out["value_fixed_batch4"] = dict(row["fixed_batch4"], note="the 4-blobs-per-call cut of rounds 1 - 4 on this run's device: compare THIS with BENCH_r01 .. r04; `value` uses the library's batch policy")
     # Every collective is behind us: leave the process group BEFORE rank 0's CPU legs, so that no rank waits on them (north_star wants
     # the CPU figure "in the same run" at 1, 2, 4 and 8 GPUs: an N > 1 line carries cpu_baseline, roofline and roofline_valu too).
     if use_dist:
