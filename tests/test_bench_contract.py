@@ -61,12 +61,18 @@ def test_bench_line_carries_the_other_baseline_configs():
     assert set(rows) == {(20, "commit_and_generate_proof"), (22, "commit")}
     for r in rows.values():
         assert r["ms_per_blob"] > 0 and 0 < r["frac_of_hbm_peak_wall"] < 1 and r["lone_call"]["ms"] >= r["ms_per_blob"] * 0.5 and r["dominant_kernel"]["frac"] > 0
-    assert rows[(20, "commit_and_generate_proof")]["verified_proofs"] == 64
+    assert rows[(20, "commit_and_generate_proof")]["verified_proofs"] == 512  # (a stream long enough for the policy's cut at this size, round 6)
     assert 0 < rows[(22, "commit")]["two_contexts"]["ms_per_blob"]  # the commit stream over two contexts taking turns
-    r20 = rows[(20, "commit_and_generate_proof")]  # the library's batch policy cuts the 64 blobs into 2 calls of 32 (workspace bytes in flight)
-    assert r20["measured_loop"].startswith("library batch policy (frieda_batch_plan): 2 calls of 32 / 32 blobs")
+    r20 = rows[(20, "commit_and_generate_proof")]  # the library's batch policy cuts the 512 blobs into 2 calls of 256 (workspace bytes in flight: 43 GB per call)
+    assert r20["measured_loop"].startswith("library batch policy (frieda_batch_plan): 2 calls of 256 / 256 blobs")
     fb = r20["fixed_batch4"]  # the 4-per-call cut of rounds 1-4, kept beside it for continuity
-    assert fb["measured_loop"].startswith("4 blobs") and 0 < r20["ms_per_blob"] < fb["ms_per_blob"] * 1.05 and fb["verified_proofs"] == 64
+    assert fb["measured_loop"].startswith("4 blobs") and 0 < r20["ms_per_blob"] < fb["ms_per_blob"] * 1.05 and fb["verified_proofs"] == 512
+    # round 6: what the fraction is, the counter traffic beside it, every call's latency, the environment defaults applied
+    assert "byte model" in d["roofline"]["frac_is"] and d["roofline"]["top_family_by_summed_time"]["ms_per_step"] > 0
+    assert d["call_latency"]["max_ms"] > 0 and sum(c["blobs"] for c in d["call_latency"]["calls"]) == 8
+    assert set(d["env_defaults"]) == {"HSA_ENABLE_IPC_MODE_LEGACY", "NCCL_SOCKET_IFNAME"}
+    v4 = d["value_fixed_batch4"]  # the headline's own workload through the 4-per-call cut of rounds 1 - 4 (like for like with BENCH_r01 .. r04)
+    assert v4["measured_loop"].startswith("4 blobs per call") and v4["verified_proofs"] == 20 and v4["ms_per_blob"] > 0
     assert d["roofline"]["traffic"] is None or d["roofline"]["traffic"] > 0
 
 
