@@ -192,6 +192,7 @@ class MultiContext {
     MultiContext& operator=(const MultiContext&) = delete;
     ~MultiContext() { frieda_multi_destroy(h_); }
 
+    frieda_multi* handle() { return h_; }  // for the C entry points this class does not wrap (owned by the object)
     bool uses_rccl() const { return frieda_multi_uses_rccl(h_) != 0; }
     uint64_t gather_count() const { return frieda_multi_gather_count(h_); }
     uint32_t device_count() const { return frieda_multi_device_count(h_); }

@@ -13,6 +13,7 @@
 #include <sched.h>
 
 #include "frieda.hpp"
+#include "frieda_hip_testing.h"
 
 using namespace frieda;
 
@@ -97,6 +98,34 @@ static int multi_mode(const std::vector<uint8_t>& blob, int n_slots, bool distin
         again = mc.prove_many(provable, seeds.data(), PCS_CONFIG);
         for (size_t i = 0; i < again.size(); i++) CHECK(again[i].first == proofs[i].first && again[i].second.serialize() == proofs[i].second.serialize());
         mc.release_workspace();  // the handle stays usable: the next call allocates again
+        CHECK(mc.commit_many(blobs, 4) == roots);
+        // every slot short of memory at once: a test limit of 1.5 blobs' workspace on each slot's contexts makes every worker's
+        // first cut of the equal-length run (3 or more blobs per call) fail with FRIEDA_ERR_NOMEM; the workers retry with halved calls,
+        // concurrently, and the results do not move.  Below one blob's workspace the call fails and names a device.
+        for (int d = 0; d < n_slots; d++) mc.set_option(d, "FRIEDA_BATCH_CALLS_PER_CTX", 1);
+        std::vector<std::vector<uint8_t>> run_blobs(blobs.end() - run_len, blobs.end());
+        std::vector<Commitment> run_roots(roots.end() - run_len, roots.end());
+        std::vector<uint64_t> run_seeds(seeds.end() - run_len, seeds.end());
+        const size_t ws_p = frieda_workspace_bytes(3000, 4, 0, 1), ws_c = frieda_workspace_bytes(3000, 4, 0, 0);
+        CHECK(ws_p > ws_c && ws_c > 0);
+        for (int d = 0; d < n_slots; d++) CHECK(frieda_ctx_test_set_arena_limit(frieda_multi_ctx(mc.handle(), d), ws_p + ws_p / 2) == FRIEDA_OK);
+        auto tight = mc.prove_many(run_blobs, run_seeds.data(), PCS_CONFIG);
+        CHECK(tight.size() == (size_t)run_len);
+        for (int i = 0; i < run_len; i++) {
+            const auto& want = proofs[proofs.size() - run_len + i];
+            CHECK(tight[i].first == want.first && tight[i].second.serialize() == want.second.serialize());
+        }
+        for (int d = 0; d < n_slots; d++) CHECK(frieda_ctx_test_set_arena_limit(frieda_multi_ctx(mc.handle(), d), ws_c + ws_c / 2) == FRIEDA_OK);
+        CHECK(mc.commit_many(run_blobs, 4) == run_roots);
+        for (int d = 0; d < n_slots; d++) CHECK(frieda_ctx_test_set_arena_limit(frieda_multi_ctx(mc.handle(), d), ws_c / 2) == FRIEDA_OK);
+        bool nomem = false;
+        try {
+            mc.commit_many(run_blobs, 4);
+        } catch (const Error& e) {
+            nomem = e.status == FRIEDA_ERR_NOMEM && std::string(e.what()).find("device") != std::string::npos;
+        }
+        CHECK(nomem);
+        for (int d = 0; d < n_slots; d++) CHECK(frieda_ctx_test_set_arena_limit(frieda_multi_ctx(mc.handle(), d), 0) == FRIEDA_OK);
         CHECK(mc.commit_many(blobs, 4) == roots);
         bool refused = false;
         try {
