@@ -179,7 +179,7 @@ int commit_batch_finish(Ctx* ctx, uint8_t* out_roots);
 // themselves: frieda_amd.BatchPipeline, bench.py) and the tests.
 size_t workspace_bytes_per_blob(size_t len, uint32_t log_blowup, uint32_t log_last_layer, bool prove, bool data_on_device);
 // FRIEDA_BATCH_BUDGET_MB, or the default: sixteen proofs of a 2^24 domain (blowup 2^4), ~43 GB — clamped to the device the context sits on:
-// the default to 15 % of its memory (two calls in flight: 30 %, what 43 GB are of an MI355X's 288 GB), an explicit value to 45 %
+// the default to 16 % of its memory (two calls in flight: a third; 43 GB are 15 % of an MI355X's 288 GB), an explicit value to 45 %
 uint64_t batch_budget_bytes(const k::Tuning& t);
 uint32_t batch_per_call(const k::Tuning& t, size_t ws_per_blob, uint32_t count, uint32_t in_flight);
 void batch_cut(uint32_t count, uint32_t per_call, uint32_t in_flight, std::vector<uint32_t>& calls);

@@ -431,7 +431,7 @@ uint64_t batch_budget_bytes(const k::Tuning& t) {
         const uint64_t b = (uint64_t)t.batch_budget_mb << 20;
         return t.device_mem_bytes ? std::min<uint64_t>(b, t.device_mem_bytes / 100 * 45) : b;
     }
-    if (t.device_mem_bytes) return std::min<uint64_t>(batch_budget_bytes(k::tuning_defaults()), t.device_mem_bytes / 100 * 15);
+    if (t.device_mem_bytes) return std::min<uint64_t>(batch_budget_bytes(k::tuning_defaults()), t.device_mem_bytes / 100 * 16);  // (16 %: a device that reports 288e9 bytes still gets the sixteen proofs the figure was measured with)
     // measured at the headline size and stated in workspace bytes so that it carries over to every other size: sixteen proofs of a
     // 2^24 domain per call (15 MiB blobs: 2^22 felts -> 2^20 coefficients per column, blowup 2^4), ~43 GB per call in flight — two
     // calls in flight hold 30 % of a 288 GB MI355X.  With the compression's throughput form a call's fixed part (the narrow launches
