@@ -43,11 +43,39 @@ using namespace treedev;
 
 constexpr int NTT_THREADS = 256;
 constexpr uint32_t TILE_LOG = 12;
-constexpr uint32_t TILE_WORDS = (1u << TILE_LOG) + (1u << (TILE_LOG - 4));  // padded
+#ifdef FRIEDA_NTT_OLD_PAD  // A/B build: the layout of rounds 1 - 5 (one pad word per 16 elements, stage groups in thread order)
+constexpr uint32_t TILE_WORDS = (1u << TILE_LOG) + (1u << (TILE_LOG - 4));
+#else
+constexpr uint32_t TILE_WORDS = (1u << TILE_LOG) + (1u << (TILE_LOG - 5));  // padded (pad below)
+#endif
 constexpr uint32_t MAX_COLS_PER_WG = 4;
 constexpr uint32_t MID_LOG_W = 4;  // 64-byte contiguous runs in the strided passes
 
+// Tile element e sits at LDS word e + (e >> 5) (round 6; e + (e >> 4) until then).  ds_read_b32 / ds_write_b32 / the two halves of a
+// ds_*2_b32 are served per 32-lane half with 32 banks (word mod 32).  With one pad word per 16 elements the stage on tile bits 8 .. 11 (a
+// half-wave touches 32 CONSECUTIVE elements: words e .. e + 15, e + 17 .. e + 32) and the 16-byte tile fill hit one bank twice in every
+// access: SQ_LDS_BANK_CONFLICT was a third of SQ_LDS_IDX_ACTIVE in ntt_tile12<3,0> and 40 % in ntt_tile12_rep (profiles/r06_lds_conflicts.txt).
+// With one pad word per 32 elements those two patterns and the stage on bits 0 .. 3 (16 g + r -> 16 g + (g >> 1) + r) are conflict-free,
+// and the stage on bits 4 .. 7 is once its groups are dealt to the threads by stage_group_base below.
+#ifdef FRIEDA_NTT_OLD_PAD
 __device__ __forceinline__ uint32_t pad(uint32_t e) { return e + (e >> 4); }
+#else
+__device__ __forceinline__ uint32_t pad(uint32_t e) { return e + (e >> 5); }
+#endif
+// The group of 16 elements thread g (< 256) handles in the radix-16 stage on tile bits lo .. lo + 3 (lo = 8, 4, 0): its base element.
+// lo = 4: the group with tile bits 0 .. 3 = g & 15 and bits 8 .. 11 = h, where h is g >> 4 with its two low bits swapped — a half-wave
+// (g >> 4 = 2 m, 2 m + 1) then reads 16 elements at h and 16 at h + 2, 512 elements = 528 words = 16 banks apart, instead of h and h + 1
+// (264 words = 8 banks apart: 8 of 16 banks twice).  A wave still owns the elements [1024 w, 1024 w + 1024) in this stage and the next.
+__device__ __forceinline__ uint32_t stage_group_base(uint32_t g, uint32_t lo) {
+#ifndef FRIEDA_NTT_OLD_PAD
+    if (lo == 4) {
+        const uint32_t t = g >> 4;
+        const uint32_t h = (t & ~3u) | ((t & 1u) << 1) | ((t >> 1) & 1u);
+        return (h << 8) | (g & 15u);
+    }
+#endif
+    return ((g >> lo) << (lo + 4)) | (g & ((1u << lo) - 1));
+}
 
 // ---- the four layers of a radix-16 stage on 16 register-resident values, eight butterflies at a time ----
 // Same idea as the hash kernels' throughput form (blake2s.h): the eight independent butterflies of a layer advance together, one
@@ -370,7 +398,7 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_tile12_kernel(NttArgs a) {
 #pragma unroll
     for (int s = 0; s < NS; s++) {
         const uint32_t lo = 8 - 4 * s;
-        const uint32_t base = ((g >> lo) << (lo + 4)) | (g & ((1u << lo) - 1));
+        const uint32_t base = stage_group_base(g, lo);
         pbase[s] = pad(base);
 #pragma unroll
         for (int q = 0; q < 4; q++) {
@@ -502,7 +530,7 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_tile12_rep_kernel(NttArgs a) 
 #pragma unroll
     for (int s = 0; s < NS; s++) {
         const uint32_t lo = 8 - 4 * s;
-        pbase[s] = pad(((g >> lo) << (lo + 4)) | (g & ((1u << lo) - 1)));
+        pbase[s] = pad(stage_group_base(g, lo));
     }
 
 #pragma unroll 1
@@ -513,7 +541,7 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_tile12_rep_kernel(NttArgs a) 
 #pragma unroll
         for (int s = 0; s < NS; s++) {
             const uint32_t lo = 8 - 4 * s;
-            const uint32_t base = ((g >> lo) << (lo + 4)) | (g & ((1u << lo) - 1));
+            const uint32_t base = stage_group_base(g, lo);
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 const uint32_t b = lo + 3 - q;
@@ -594,7 +622,7 @@ __device__ __forceinline__ void last_pass_four_columns(const NttArgs& a, uint32_
 #pragma unroll
     for (int s = 0; s < 3; s++) {
         const uint32_t lo = 8 - 4 * s;
-        const uint32_t base = ((g >> lo) << (lo + 4)) | (g & ((1u << lo) - 1));
+        const uint32_t base = stage_group_base(g, lo);
         pbase[s] = pad(base);
 #pragma unroll
         for (int q = 0; q < 4; q++) {
@@ -893,7 +921,7 @@ __global__ __launch_bounds__(NTT_CP_THREADS) void ntt_last_fold_cp_kernel(NttFol
 #pragma unroll
     for (int s = 0; s < 3; s++) {
         const uint32_t lo = 8 - 4 * s;
-        const uint32_t base = ((g >> lo) << (lo + 4)) | (g & ((1u << lo) - 1));
+        const uint32_t base = stage_group_base(g, lo);
         pbase[s] = pad(base);
 #pragma unroll
         for (int q = 0; q < 4; q++) {
