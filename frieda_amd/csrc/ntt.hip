@@ -43,7 +43,7 @@ using namespace treedev;
 
 constexpr int NTT_THREADS = 256;
 constexpr uint32_t TILE_LOG = 12;
-#ifdef FRIEDA_NTT_OLD_PAD  // A/B build: the layout of rounds 1 - 5 (one pad word per 16 elements, stage groups in thread order)
+#ifndef FRIEDA_NTT_PAD32  // the default: one pad word per 16 elements, stage groups in thread order (rounds 1 - 6); -DFRIEDA_NTT_PAD32: the conflict-free layout below
 constexpr uint32_t TILE_WORDS = (1u << TILE_LOG) + (1u << (TILE_LOG - 4));
 #else
 constexpr uint32_t TILE_WORDS = (1u << TILE_LOG) + (1u << (TILE_LOG - 5));  // padded (pad below)
@@ -51,13 +51,17 @@ constexpr uint32_t TILE_WORDS = (1u << TILE_LOG) + (1u << (TILE_LOG - 5));  // p
 constexpr uint32_t MAX_COLS_PER_WG = 4;
 constexpr uint32_t MID_LOG_W = 4;  // 64-byte contiguous runs in the strided passes
 
-// Tile element e sits at LDS word e + (e >> 5) (round 6; e + (e >> 4) until then).  ds_read_b32 / ds_write_b32 / the two halves of a
+// Tile element e sits at LDS word e + (e >> 4).  Round 6 found that this layout is NOT conflict-free (below) and built one that is
+// (-DFRIEDA_NTT_PAD32: e + (e >> 5) and stage_group_base's dealing of the stage on bits 4 .. 7): SQ_LDS_BANK_CONFLICT 0.33 - 0.40 -> 0.000 of
+// the LDS-array cycles, the strided pass -1.6 us, the contiguous pass unchanged, the fused last pass + tree launch of commitments 1 - 3 %
+// SLOWER — the LDS array is not what these kernels wait for.  The default therefore stays; the build flag keeps the A/B
+// (profiles/r06_lds_conflicts.txt, tools/lds_conflicts.sh).  The PAD32 layout:  ds_read_b32 / ds_write_b32 / the two halves of a
 // ds_*2_b32 are served per 32-lane half with 32 banks (word mod 32).  With one pad word per 16 elements the stage on tile bits 8 .. 11 (a
 // half-wave touches 32 CONSECUTIVE elements: words e .. e + 15, e + 17 .. e + 32) and the 16-byte tile fill hit one bank twice in every
 // access: SQ_LDS_BANK_CONFLICT was a third of SQ_LDS_IDX_ACTIVE in ntt_tile12<3,0> and 40 % in ntt_tile12_rep (profiles/r06_lds_conflicts.txt).
 // With one pad word per 32 elements those two patterns and the stage on bits 0 .. 3 (16 g + r -> 16 g + (g >> 1) + r) are conflict-free,
 // and the stage on bits 4 .. 7 is once its groups are dealt to the threads by stage_group_base below.
-#ifdef FRIEDA_NTT_OLD_PAD
+#ifndef FRIEDA_NTT_PAD32
 __device__ __forceinline__ uint32_t pad(uint32_t e) { return e + (e >> 4); }
 #else
 __device__ __forceinline__ uint32_t pad(uint32_t e) { return e + (e >> 5); }
@@ -67,7 +71,7 @@ __device__ __forceinline__ uint32_t pad(uint32_t e) { return e + (e >> 5); }
 // (g >> 4 = 2 m, 2 m + 1) then reads 16 elements at h and 16 at h + 2, 512 elements = 528 words = 16 banks apart, instead of h and h + 1
 // (264 words = 8 banks apart: 8 of 16 banks twice).  A wave still owns the elements [1024 w, 1024 w + 1024) in this stage and the next.
 __device__ __forceinline__ uint32_t stage_group_base(uint32_t g, uint32_t lo) {
-#ifndef FRIEDA_NTT_OLD_PAD
+#ifdef FRIEDA_NTT_PAD32
     if (lo == 4) {
         const uint32_t t = g >> 4;
         const uint32_t h = (t & ~3u) | ((t & 1u) << 1) | ((t >> 1) & 1u);
