@@ -72,6 +72,19 @@ __global__ __launch_bounds__(256) void rate_kernel(uint32_t* out, int iters) {
                     asm volatile("v_mad_u64_u32 %0, vcc, s2, %1, 0" : "=v"(p) : "v"(x) : "vcc");
                     x = (uint32_t)p;
                 }
+                // round 6: the 64-bit ops of the fold arithmetic (field.h m31_reduce64: v_lshl_add_u64, v_lshrrev_b64) and their 32-bit stand-ins
+                if (OP == 49 || OP == 50 || OP == 51 || OP == 52) {
+                    uint64_t q = ((uint64_t)y << 32) | x;
+                    if (OP == 49) asm volatile("v_lshrrev_b64 %0, 31, %0" : "+v"(q));
+                    if (OP == 50) asm volatile("v_lshl_add_u64 %0, %0, 1, %1" : "+v"(q) : "v"(q));
+                    if (OP == 51) asm volatile("v_lshlrev_b64 %0, 1, %0" : "+v"(q));
+                    if (OP == 52) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(q) : "v"(x), "v"(z) : "vcc");
+                    x = (uint32_t)q;
+                }
+                if (OP == 53) asm volatile("v_lshlrev_b32 %0, 7, %0" : "+v"(x));
+                if (OP == 54) asm volatile("v_and_b32 %0, 0x7fffffff, %0" : "+v"(x));
+                if (OP == 55) asm volatile("v_sub_u32 %0, %0, %1" : "+v"(x) : "v"(y));
+                if (OP == 56) asm volatile("v_lshl_add_u32 %0, %0, 1, %1" : "+v"(x) : "v"(y));
                 if (OP == 46) asm volatile("v_add_u32 %0, s2, %0" : "+v"(x));
                 if (OP == 47) asm volatile("v_alignbit_b32 %0, %0, %1, s2" : "+v"(x) : "v"(y));
                 if (OP == 48) asm volatile("v_min_u32 %0, s2, %0" : "+v"(x));
@@ -155,5 +168,13 @@ int main() {
     run<46>("v_add_u32 (sgpr operand)");
     run<47>("v_alignbit_b32 (sgpr shift)");
     run<48>("v_min_u32 (sgpr operand)");
+    run<49>("v_lshrrev_b64 (by 31)");
+    run<50>("v_lshl_add_u64");
+    run<51>("v_lshlrev_b64 (by 1)");
+    run<52>("v_mad_u64_u32 (64-bit accumulate)");
+    run<53>("v_lshlrev_b32");
+    run<54>("v_and_b32 (literal)");
+    run<55>("v_sub_u32");
+    run<56>("v_lshl_add_u32");
     return 0;
 }
