@@ -1274,15 +1274,24 @@ def main():
         n_node = sum(n_leaf / (1 << l) for l in range(1, n_levels))
         t_launch = k["total_ms"] * 1e-3 / k["launches"]
         ideal = n_leaf / leaf_rate + n_node / node_rate
-        return {"kernel": name, "bound": "int32 VALU (Blake2s compression)", "achieved": (n_leaf + n_node) / t_launch / 1e9,
+        #  next to the ceiling measured with the product's own code: a pipe model that owes nothing to it — every
+        # slow-class instruction (v_alignbit, v_add3) takes the SIMD 4 cycles per wave, every fast-class one is hidden behind another wave's
+        # slow one; instruction counts from the generator (tools/gen_blake2s_asm.py: 350 slow per leaf, 476 per node compression; a CPU test
+        # pins them), 1024 SIMDs x 64 lanes, at the nominal 2.4 GHz and at the clock the ceiling probe read in this run
+        S_LEAF, S_NODE, SIMDS = 350, 476, 1024
+        model_cycles = (n_leaf * S_LEAF + n_node * S_NODE) * 4.0 / 64.0 / SIMDS  # SIMD cycles the launch needs under the model
+        pipe = {"model": "slow-class instruction = 4 SIMD cycles per wave, every fast-class instruction hidden behind another wave's slow one",
+                "cycles_per_wave_compression": {"leaf": 4 * S_LEAF, "node": 4 * S_NODE},
+                "frac_at_2.4_ghz": model_cycles / 2.4e9 / t_launch, "frac_at_probe_clock": model_cycles / (ceil["node_clock_ghz"] * 1e9) / t_launch}
+        return {"kernel": name, "bound": "int32 VALU (Blake2s compression)", "achieved": (n_leaf + n_node) / t_launch / 1e9, "vs_pipe_model": pipe,
                 "peak": (n_leaf + n_node) / ideal / 1e9, "unit": "G compressions/s", "frac": ideal / t_launch, "note": note,
                 "clock_ghz": ceil["node_clock_ghz"], "ceiling_cycles_per_wave_compression": {"leaf": ceil["leaf_cycles_per_wave_compression"], "node": ceil["node_cycles_per_wave_compression"]},
                 "peak_source": f"measured in this run on this device: {leaf_rate / 1e9:.2f} G leaf / {node_rate / 1e9:.2f} G node compressions/s "
                                f"on register-resident data at an in-kernel clock of {ceil['node_clock_ghz']:.2f} GHz (s_memtime / s_memrealtime, "
                                "frieda_ctx_blake2s_ceiling_ex), every lane chaining compressions in the product's own throughput form (runs of one "
-                               "VALU rate class, the wave's priority raised for its slow runs, blake2s.h) at 8 waves per SIMD: ~2250 (leaf) / ~2400 (node) SIMD cycles "
-                               "per wave-compression, against ~3950 for the scheduler's own fine interleave (rounds 1-4) and ~3150 / ~3300 with idle issue "
-                               "states instead of priorities (first half of round 5)"}
+                               "VALU rate class, the wave's priority raised for its slow runs; one generated asm block per message shape since round 6, blake2s_asm.h) "
+                               "at 8 waves per SIMD: ~2130 (leaf) / ~2270 (node) SIMD cycles per wave-compression, against ~2225 / ~2330 for the pinned C++ form of "
+                               "round 5, ~3950 for the scheduler's own fine interleave (rounds 1-4) and ~3150 / ~3300 with idle issue states instead of priorities"}
 
     if args.only_measured_loop:
         valu = {"skipped": "--only-measured-loop: neither the ceiling nor the per-kernel replay was measured"}

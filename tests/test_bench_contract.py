@@ -69,6 +69,8 @@ def test_bench_line_carries_the_other_baseline_configs():
     assert fb["measured_loop"].startswith("4 blobs") and 0 < r20["ms_per_blob"] < fb["ms_per_blob"] * 1.05 and fb["verified_proofs"] == 512
     # round 6: what the fraction is, the counter traffic beside it, every call's latency, the environment defaults applied
     assert "byte model" in d["roofline"]["frac_is"] and d["roofline"]["top_family_by_summed_time"]["ms_per_step"] > 0
+    pm = d["roofline_valu"][0]["vs_pipe_model"]  # the dominant launch against a pipe model that owes nothing to the product code
+    assert 0 < pm["frac_at_2.4_ghz"] < pm["frac_at_probe_clock"] < 1 and pm["cycles_per_wave_compression"] == {"leaf": 1400, "node": 1904}
     assert d["call_latency"]["max_ms"] > 0 and sum(c["blobs"] for c in d["call_latency"]["calls"]) == 8
     assert set(d["env_defaults"]) == {"HSA_ENABLE_IPC_MODE_LEGACY", "NCCL_SOCKET_IFNAME"}
     v4 = d["value_fixed_batch4"]  # the headline's own workload through the 4-per-call cut of rounds 1 - 4 (like for like with BENCH_r01 .. r04)
