@@ -325,6 +325,37 @@ FR_HD void b2_merkle_leaf(uint32_t v0, uint32_t v1, uint32_t v2, uint32_t v3, ui
         b2_merkle_block<IDLE>(m, out);
 }
 
+// ---- the proof-of-work compression (round 6): Blake2sChannel::mix_u64 with the nonce = F(digest, [nonce_lo, nonce_hi, 0 x 14], 0, 0, 0, 0), of
+// which GrindOps::grind (src/proof.rs:58) only needs the trailing zeros.  b2_grind_word0 returns word 0 of the result — enough to decide
+// trailing_zeros >= pow_bits for pow_bits <= 32 and to pre-select for more (the caller recomputes a survivor in full: one nonce in 2^pow_bits).
+// Of round 0's column step only the first quadruple sees the nonce: b2_grind_prepare runs the other three ONCE for a digest (12 state words, plus
+// h0 and h4 passed through); the generated block (blake2s_asm.h b2_asm_grind) starts from there and ends the last half-round where out[0] is
+// known: 895 instead of ~955 instructions, as one asm block instead of the pinned C++ form (profiles/r06_grind_asm.txt).
+FR_HD void b2_grind_prepare(const uint32_t (&h)[8], uint32_t (&pre)[14]) {
+    using b2detail::IV;
+    uint32_t v1 = h[1], v5 = h[5], v9 = IV[1], v13 = IV[5], v2 = h[2], v6 = h[6], v10 = IV[2], v14 = IV[6], v3 = h[3], v7 = h[7], v11 = IV[3], v15 = IV[7];
+    FR_B2_G(v1, v5, v9, v13, 0u, 0u);  // message words 2 .. 7 are zero
+    FR_B2_G(v2, v6, v10, v14, 0u, 0u);
+    FR_B2_G(v3, v7, v11, v15, 0u, 0u);
+    pre[0] = h[0], pre[1] = h[4];
+    pre[2] = v1, pre[3] = v5, pre[4] = v9, pre[5] = v13;
+    pre[6] = v2, pre[7] = v6, pre[8] = v10, pre[9] = v14;
+    pre[10] = v3, pre[11] = v7, pre[12] = v11, pre[13] = v15;
+}
+// word 0 of F(h, [m0, m1, 0 x 14], 0, 0, 0, 0); `pre` from b2_grind_prepare(h)
+FR_HD uint32_t b2_grind_word0(const uint32_t (&h)[8], const uint32_t (&pre)[14], uint32_t m0, uint32_t m1) {
+#if defined(FRIEDA_B2_ASM_BLOCK) && !defined(FRIEDA_B2_NO_RUNS) && !defined(FRIEDA_B2_GRIND_FULL)  // (-DFRIEDA_B2_GRIND_FULL: the whole pinned compression, A/B)
+    (void)h;
+    return b2_asm_grind(m0, m1, pre);
+#else
+    (void)pre;
+    const uint32_t m[16] = {m0, m1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    uint32_t r[8];
+    b2_compress_tp<FRIEDA_B2_IDLE_GRIND>(h, m, 0, 0, 0, 0, r);
+    return r[0];
+#endif
+}
+
 // Standard unkeyed Blake2s-256 of a message given as little-endian words, at most one... any number of
 // 64-byte blocks; `len` in bytes, `words` must be zero padded to a multiple of 16 words.
 FR_HD void b2s256_words(const uint32_t* words, uint32_t len, uint32_t (&out)[8]) {

@@ -1145,9 +1145,13 @@ __global__ __launch_bounds__(256) void grind_dev_kernel(GrindArgs a) {
         __syncthreads();
         if (cb == ~0u) return;
         DevTranscript* tr = a.tr + cb;
-        uint32_t h[8];
+        uint32_t h[8], pre[14];
 #pragma unroll
         for (int i = 0; i < 8; i++) h[i] = tr->ch.digest[i];
+        b2_grind_prepare(h, pre);  // the part of round 0 that does not see the nonce: once per claim (blake2s.h)
+        // trailing_zeros >= pow_bits needs the low min(pow_bits, 32) bits of word 0 clear: decided from word 0 alone; a survivor (one nonce
+        // in 2^pow_bits) is recomputed in full below
+        const uint32_t low_mask = a.pow_bits >= 32 ? 0xFFFFFFFFu : ((1u << a.pow_bits) - 1u);
         const unsigned long long first = a.base + (unsigned long long)cw * GRIND_WINDOW + t;
         // (the claim may reach past the range's last unit: only whole units below n_windows are scanned)
         const uint32_t my_units = a.n_windows - cw < a.units ? a.n_windows - cw : a.units;
@@ -1155,9 +1159,10 @@ __global__ __launch_bounds__(256) void grind_dev_kernel(GrindArgs a) {
             const unsigned long long nonce = first + 256ull * i;
             // a smaller qualifying nonce is already known: nothing this lane finds from here on can lower the minimum
             if (__hip_atomic_load(&tr->nonce, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < nonce) break;
+            if ((b2_grind_word0(h, pre, (uint32_t)nonce, (uint32_t)(nonce >> 32)) & low_mask) != 0) continue;  // (a chip-filling launch: the throughput form)
             const uint32_t m[16] = {(uint32_t)nonce, (uint32_t)(nonce >> 32), 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
             uint32_t r[8];
-            b2_compress_tp<FRIEDA_B2_IDLE_GRIND>(h, m, 0, 0, 0, 0, r);  // (a chip-filling launch: the throughput form, blake2s.h)
+            b2_compress(h, m, 0, 0, 0, 0, r);  // the survivor, in full (plain form: one lane in 2^pow_bits gets here)
             uint32_t tz;
             if (r[0])
                 tz = __ffs(r[0]) - 1;

@@ -95,3 +95,6 @@ def test_generated_header_is_current_and_correct():
     n_leaf, _, cl = G.build("leaf", G.VARIANTS)
     assert (n_node, cn["slow"], cn["fast"]) == (16, 476, 488)
     assert (n_leaf, cl["slow"], cl["fast"]) == (4, 350, 591)
+    # the proof-of-work shape: word 0 only, round 0's nonce-free quadruples hoisted, the last half-round cut where out[0] is known
+    _, _, cg = G.build("grind", G.VARIANTS)
+    assert (cg["slow"], cg["fast"]) == (316, 579)

@@ -68,12 +68,12 @@ class Gen:
         if v is None:
             return self.reg(i)
         if isinstance(v, tuple):
-            return self.reg(v[1])
+            return "%%%d" % v[1] if v[0] == "in" else self.reg(v[1])  # ('in', k): asm input operand %k; ('alias', j): state word j's register
         return lit(v)
 
     # -- the steps of G over one (a, b, c, d) quadruple.  Each returns a list of (class, text); constants fold, `x ^ 0` aliases.
     def written(self, i):
-        assert not any(isinstance(v, tuple) and v[1] == i for v in self.val), "a register is overwritten while an alias still reads it"
+        assert not any(isinstance(v, tuple) and v[0] == "alias" and v[1] == i for v in self.val), "a register is overwritten while an alias still reads it"
         self.val[i] = None
 
     def add_abm(self, a, b, j):
@@ -113,6 +113,7 @@ class Gen:
             ops = [("fast", "v_xor_b32 %s, %s, %s" % (self.reg(d), lit(va), self.src(d)))]
         elif isinstance(vd, int):
             if vd == 0:
+                assert self.val[a] is None or self.val[a][0] == "alias"
                 self.val[d] = ("alias", a if self.val[a] is None else self.val[a][1])
                 return []
             ops = [("fast", "v_xor_b32 %s, %s, %s" % (self.reg(d), lit(vd), self.src(a)))]
@@ -175,22 +176,55 @@ class Gen:
                 self.setprio("fast" if o[0] == "fast" else kind)
                 self.emit(*o)
 
-    def half_round(self, r, h):
+    def half_round(self, r, h, steps=None):
+        """steps: None = the whole half-round; else {q: n}: only quadruples q, each up to its first n of the twelve operations of G
+        (a += b + x, d ^= a, rot 16, c += d, b ^= c, rot 12, a += b + y, d ^= a, rot 8, c += d, b ^= c, rot 7)"""
         a = [0, 1, 2, 3]
         b = [5, 6, 7, 4] if h else [4, 5, 6, 7]
         c = [10, 11, 8, 9] if h else [8, 9, 10, 11]
         d = [15, 12, 13, 14] if h else [12, 13, 14, 15]
         o = 8 * h
-        Q = range(4)
-        self.run("add3", [self.add_abm(a[q], b[q], SIGMA[r][o + 2 * q]) for q in Q])
-        self.run("fast", [self.xor_into(d[q], a[q]) for q in Q])
-        self.run("rot" if self.rot16 != "pk" else "fast", [self.rot(d[q], 16) for q in Q])
-        self.run("fast", [self.add_cd(c[q], d[q]) for q in Q] + [self.xor_into(b[q], c[q]) for q in Q])
-        self.run("add3", [self.rot(b[q], 12) for q in Q] + [self.add_abm(a[q], b[q], SIGMA[r][o + 2 * q + 1]) for q in Q])
-        self.run("fast", [self.xor_into(d[q], a[q]) for q in Q])
-        self.run("rot", [self.rot(d[q], 8) for q in Q])
-        self.run("fast", [self.add_cd(c[q], d[q]) for q in Q] + [self.xor_into(b[q], c[q]) for q in Q])
-        self.run("rot", [self.rot(b[q], 7) for q in Q])
+        lim = {q: 12 for q in range(4)} if steps is None else steps
+
+        def Q(k):  # the quadruples that still take operation k (1-based)
+            return [q for q in sorted(lim) if lim[q] >= k]
+
+        self.run("add3", [self.add_abm(a[q], b[q], SIGMA[r][o + 2 * q]) for q in Q(1)])
+        self.run("fast", [self.xor_into(d[q], a[q]) for q in Q(2)])
+        self.run("rot" if self.rot16 != "pk" else "fast", [self.rot(d[q], 16) for q in Q(3)])
+        self.run("fast", [self.add_cd(c[q], d[q]) for q in Q(4)] + [self.xor_into(b[q], c[q]) for q in Q(5)])
+        self.run("add3", [self.rot(b[q], 12) for q in Q(6)] + [self.add_abm(a[q], b[q], SIGMA[r][o + 2 * q + 1]) for q in Q(7)])
+        self.run("fast", [self.xor_into(d[q], a[q]) for q in Q(8)])
+        self.run("rot", [self.rot(d[q], 8) for q in Q(9)])
+        self.run("fast", [self.add_cd(c[q], d[q]) for q in Q(10)] + [self.xor_into(b[q], c[q]) for q in Q(11)])
+        self.run("rot", [self.rot(b[q], 7) for q in Q(12)])
+
+    # ---- the proof-of-work shape (Blake2sChannel::mix_u64 with the nonce: F(digest, [nonce_lo, nonce_hi, 0 x 14], 0, 0, 0, 0)) ----
+    # Only the low word of the output is produced (trailing zeros up to 32 bits are decided by it; the caller recomputes the rare survivor in
+    # full).  Of round 0's column step only G(v0, v4, v8, v12, m0, m1) depends on the nonce: the other three quadruples are the same for every
+    # nonce of a blob and come in as inputs (GRIND_IN below), computed once per claim.  The last half-round runs only what out[0] = h0 ^ v0 ^ v8
+    # needs: G(v0, v5, v10, v15) up to its second a += b + y, G(v2, v7, v8, v13) up to its second c += d.
+    GRIND_IN = [0, 4, 1, 5, 9, 13, 2, 6, 10, 14, 3, 7, 11, 15]  # state words that arrive in input operands %18 .. %31 (m0 = %16, m1 = %17)
+
+    def grind(self):
+        assert self.n_msg == 2
+        for k, i in enumerate(self.GRIND_IN):
+            self.val[i] = ("in", 18 + k)
+        self.val[8], self.val[12] = IV[0], IV[4]
+        self.half_round(0, 0, {0: 12})
+        self.half_round(0, 1)
+        for r in range(1, 9):
+            self.half_round(r, 0)
+            self.half_round(r, 1)
+        self.half_round(9, 0)
+        self.half_round(9, 1, {0: 7, 2: 10})
+        self.setprio("fast")
+        self.emit("fast", "v_xor_b32 %s, %s, %s" % (self.reg(0), self.reg(0), self.reg(8)))
+        self.emit("fast", "v_xor_b32 %s, %s, %s" % (self.reg(0), self.reg(0), "%18"))  # ^ h0
+        if self.cur_prio not in (None, 0):
+            self.lines.append("s_setprio 0")
+            self.count["s"] += 1
+        return self.lines
 
     def compression(self):
         for r in range(10):
@@ -211,9 +245,11 @@ def lit(k):
     return "0x%x" % k if k > 64 else "%d" % k
 
 
-def reference_compress(m):
-    """plain Python F(0, m, 0, 0): the generator's own check of the emitted dataflow (tests/test_host_logic.py runs it)"""
-    v = [0] * 8 + list(IV)
+def reference_compress(m, h=None, only_column_quads=None):
+    """plain Python F(h, m, 0, 0) (h = None: the zero state): the generator's own check of the emitted dataflow (tests/test_isa_structure.py
+    runs it).  only_column_quads: stop after these quadruples of round 0's column step and return the 16 state words (the grind's inputs)."""
+    h = [0] * 8 if h is None else list(h)
+    v = list(h) + list(IV)
     rotr = lambda x, r: ((x >> r) | (x << (32 - r))) & M32
 
     def G(a, b, c, d, x, y):
@@ -226,6 +262,11 @@ def reference_compress(m):
         v[c] = (v[c] + v[d]) & M32
         v[b] = rotr(v[b] ^ v[c], 7)
 
+    if only_column_quads is not None:
+        s = SIGMA[0]
+        for q in only_column_quads:
+            G(q, 4 + q, 8 + q, 12 + q, m[s[2 * q]], m[s[2 * q + 1]])
+        return v
     for r in range(10):
         s = SIGMA[r]
         G(0, 4, 8, 12, m[s[0]], m[s[1]])
@@ -236,11 +277,11 @@ def reference_compress(m):
         G(1, 6, 11, 12, m[s[10]], m[s[11]])
         G(2, 7, 8, 13, m[s[12]], m[s[13]])
         G(3, 4, 9, 14, m[s[14]], m[s[15]])
-    return [v[i] ^ v[8 + i] for i in range(8)]
+    return [h[i] ^ v[i] ^ v[8 + i] for i in range(8)]
 
 
-def interpret(lines, m):
-    """executes the emitted text on integers (operands %0..%15 state, %16.. message): the generator checks itself"""
+def interpret(lines, m, n_out=8):
+    """executes the emitted text on integers (operands %0..%15 state, %16.. the inputs `m`): the generator checks itself"""
     regs = {}
 
     def val(tok):
@@ -273,7 +314,7 @@ def interpret(lines, m):
             regs[dst] = rotr(s[0], 16)
         else:
             raise ValueError(ln)
-    return [regs[i] for i in range(8)]
+    return [regs[i] for i in range(n_out)]
 
 
 # name -> (message registers, generator options).  `node` / `leaf` are the product's forms: the run order and priorities of
@@ -281,6 +322,7 @@ def interpret(lines, m):
 VARIANTS = {
     "node": (16, dict(prio_rot=3, prio_add3=2, prio_fast=0)),
     "leaf": (4, dict(prio_rot=3, prio_add3=2, prio_fast=0)),
+    "grind": (2, dict(prio_rot=3, prio_add3=2, prio_fast=0)),  # the proof-of-work shape (Gen.grind): out[0] only
 }
 BENCH_VARIANTS = {
     "node_p2": (16, dict(prio_rot=2, prio_add3=2, prio_fast=0)),
@@ -300,7 +342,7 @@ BENCH_VARIANTS = {
 def build(name, variants):
     n_msg, opt = variants[name]
     g = Gen(n_msg, **opt)
-    return n_msg, g.compression(), g.count
+    return n_msg, (g.grind() if name.startswith("grind") else g.compression()), g.count
 
 
 def emit_function(name, n_msg, lines, count, out):
@@ -321,12 +363,39 @@ def emit_function(name, n_msg, lines, count, out):
     out.append("")
 
 
+def emit_grind_function(name, lines, count, out):
+    out.append("// %s: F(h, [m0, m1, 0 x 14], 0, 0, 0, 0) word 0 only; %d slow-class + %d fast-class VALU instructions, %d s_setprio.  pre[14] = the state words"
+               % (name, count["slow"], count["fast"], count["s"]))
+    out.append("// %s in this order: h0, h4, then the three quadruples of round 0's column step that do not see the nonce (b2_grind_prepare)"
+               % ", ".join("v%d" % i for i in Gen.GRIND_IN))
+    out.append("__device__ __forceinline__ uint32_t b2_asm_%s(uint32_t m0, uint32_t m1, const uint32_t (&pre)[14]) {" % name)
+    out.append("    uint32_t " + ", ".join("v%d" % i for i in range(16)) + ";")
+    out.append("    asm volatile(")
+    for ln in lines:
+        out.append('        "%s\\n\\t"' % ln)
+    outs = ", ".join('"=&v"(v%d)' % i for i in range(16))
+    ins = '"v"(m0), "v"(m1), ' + ", ".join('"v"(pre[%d])' % j for j in range(14))
+    out.append("        : " + outs)
+    out.append("        : " + ins + ");")
+    out.append("    return v0;")
+    out.append("}")
+    out.append("")
+
+
 def selfcheck(variants):
     import random
 
     rnd = random.Random(7)
     for name in variants:
         n_msg, lines, _ = build(name, variants)
+        if name.startswith("grind"):
+            for _ in range(5):
+                h = [rnd.getrandbits(32) for _ in range(8)]
+                m = [rnd.getrandbits(32), rnd.getrandbits(32)] + [0] * 14
+                st = reference_compress(m, h, only_column_quads=[1, 2, 3])
+                inputs = m[:2] + [st[i] for i in Gen.GRIND_IN]
+                assert interpret(lines, inputs, 1)[0] == reference_compress(m, h)[0], name
+            continue
         for _ in range(3):
             m = [rnd.getrandbits(32) if j < n_msg else 0 for j in range(16)]
             assert interpret(lines, m) == reference_compress(m), name
@@ -349,7 +418,10 @@ def main():
     out.append("")
     for name in variants:
         n_msg, lines, count = build(name, variants)
-        emit_function(name, n_msg, lines, count, out)
+        if name.startswith("grind"):
+            emit_grind_function(name, lines, count, out)
+        else:
+            emit_function(name, n_msg, lines, count, out)
     out.append("}  // namespace frieda")
     sys.stdout.write("\n".join(out) + "\n")
 
