@@ -20,13 +20,18 @@ ctx = frieda_amd.Context(0)
 
 
 def timed(fn, reps):
+    import gc
+
     fn()
     torch.cuda.synchronize()
+    gc.disable()  # a full collection of the interpreter (40 - 65 ms with torch imported) must not land in a timed loop: profiles/r06_gc_pause.txt
     t0 = time.perf_counter()
     for _ in range(reps):
         fn()
     torch.cuda.synchronize()
-    return (time.perf_counter() - t0) / reps
+    dt = (time.perf_counter() - t0) / reps
+    gc.enable()
+    return dt
 
 
 ctx2 = frieda_amd.Context(0)
@@ -35,6 +40,14 @@ ctx2 = frieda_amd.Context(0)
 def overlapped(dev, size, count, seeds, rounds):
     """two contexts alternating begin / finish: the planning of one batch runs under the device work of the next"""
     cs = [ctx, ctx2]
+    import gc
+
+    # both contexts sized for this call before the clock starts (the second context's first call at a size allocates its workspace and its
+    # pinned block: ~0.5 s at 1024 blobs of 64 KiB, which the two-round loop below used to average in: 5 K instead of 29 K proofs per second)
+    for c in cs:
+        c.prove_batch_begin_device(dev.data_ptr(), size, size, count, seeds, cfg)
+        c.prove_batch_finish(count)
+    gc.disable()  # (as in timed())
     cs[0].prove_batch_begin_device(dev.data_ptr(), size, size, count, seeds, cfg)
     t0 = time.perf_counter()
     for r in range(rounds):
@@ -42,6 +55,7 @@ def overlapped(dev, size, count, seeds, rounds):
         cs[r & 1].prove_batch_finish(count)
     dt = time.perf_counter() - t0
     cs[rounds & 1].prove_batch_finish(count)
+    gc.enable()
     return dt / rounds
 
 
